@@ -1,0 +1,242 @@
+"""ctypes binding of include/eilev.h.
+
+Both shared libraries export the same symbols; this module only describes the ABI and
+builds the weight structs from a ``name -> address`` callback.  It contains no arithmetic
+and no fallback: ``load_hip()`` raises if ``libeilev_hip.so`` is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libeilev_hip.so")
+
+vp = C.c_void_p
+
+
+class Dims(C.Structure):
+    _fields_ = [
+        ("image_size", C.c_int32), ("patch_size", C.c_int32), ("v_hidden", C.c_int32),
+        ("v_inter", C.c_int32), ("v_layers", C.c_int32), ("v_heads", C.c_int32), ("v_eps", C.c_float),
+        ("q_hidden", C.c_int32), ("q_inter", C.c_int32), ("q_layers", C.c_int32), ("q_heads", C.c_int32),
+        ("q_cross_freq", C.c_int32), ("num_query", C.c_int32), ("q_eps", C.c_float),
+        ("t_hidden", C.c_int32), ("t_ffn", C.c_int32), ("t_layers", C.c_int32), ("t_heads", C.c_int32),
+        ("vocab", C.c_int32), ("max_pos", C.c_int32), ("t_eps", C.c_float),
+        ("emulate_bf16", C.c_int32),
+    ]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, vp) for f in fields]})
+
+
+VIT_LAYER_FIELDS = ["ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
+                    "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+QF_LAYER_FIELDS = ["sq_w", "sq_b", "sk_w", "sk_b", "sv_w", "sv_b", "so_w", "so_b", "sln_w", "sln_b",
+                   "cq_w", "cq_b", "ck_w", "ck_b", "cv_w", "cv_b", "co_w", "co_b", "cln_w", "cln_b",
+                   "fi_w", "fi_b", "fo_w", "fo_b", "fln_w", "fln_b"]
+OPT_LAYER_FIELDS = ["ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",
+                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+
+VitLayer = _ptr_struct("VitLayer", VIT_LAYER_FIELDS)
+QfLayer = _ptr_struct("QfLayer", QF_LAYER_FIELDS)
+OptLayer = _ptr_struct("OptLayer", OPT_LAYER_FIELDS)
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("patch_w", vp), ("patch_b", vp), ("cls", vp), ("pos", vp), ("post_ln_w", vp),
+                ("post_ln_b", vp), ("layers", C.POINTER(VitLayer))]
+
+
+class QfWeights(C.Structure):
+    _fields_ = [("query_tokens", vp), ("ln_w", vp), ("ln_b", vp), ("layers", C.POINTER(QfLayer))]
+
+
+class OptWeights(C.Structure):
+    _fields_ = [("embed_tokens", vp), ("embed_positions", vp), ("final_ln_w", vp), ("final_ln_b", vp),
+                ("layers", C.POINTER(OptLayer))]
+
+
+# HF state-dict key suffixes for each struct field.
+_VIT_KEYS = {
+    "ln1_w": "layer_norm1.weight", "ln1_b": "layer_norm1.bias",
+    "qkv_w": "self_attn.qkv.weight", "qkv_b": "self_attn.qkv.bias",
+    "proj_w": "self_attn.projection.weight", "proj_b": "self_attn.projection.bias",
+    "ln2_w": "layer_norm2.weight", "ln2_b": "layer_norm2.bias",
+    "fc1_w": "mlp.fc1.weight", "fc1_b": "mlp.fc1.bias", "fc2_w": "mlp.fc2.weight", "fc2_b": "mlp.fc2.bias",
+}
+_QF_KEYS = {
+    "sq_w": "attention.attention.query.weight", "sq_b": "attention.attention.query.bias",
+    "sk_w": "attention.attention.key.weight", "sk_b": "attention.attention.key.bias",
+    "sv_w": "attention.attention.value.weight", "sv_b": "attention.attention.value.bias",
+    "so_w": "attention.output.dense.weight", "so_b": "attention.output.dense.bias",
+    "sln_w": "attention.output.LayerNorm.weight", "sln_b": "attention.output.LayerNorm.bias",
+    "cq_w": "crossattention.attention.query.weight", "cq_b": "crossattention.attention.query.bias",
+    "ck_w": "crossattention.attention.key.weight", "ck_b": "crossattention.attention.key.bias",
+    "cv_w": "crossattention.attention.value.weight", "cv_b": "crossattention.attention.value.bias",
+    "co_w": "crossattention.output.dense.weight", "co_b": "crossattention.output.dense.bias",
+    "cln_w": "crossattention.output.LayerNorm.weight", "cln_b": "crossattention.output.LayerNorm.bias",
+    "fi_w": "intermediate_query.dense.weight", "fi_b": "intermediate_query.dense.bias",
+    "fo_w": "output_query.dense.weight", "fo_b": "output_query.dense.bias",
+    "fln_w": "output_query.LayerNorm.weight", "fln_b": "output_query.LayerNorm.bias",
+}
+_OPT_KEYS = {
+    "ln1_w": "self_attn_layer_norm.weight", "ln1_b": "self_attn_layer_norm.bias",
+    "q_w": "self_attn.q_proj.weight", "q_b": "self_attn.q_proj.bias",
+    "k_w": "self_attn.k_proj.weight", "k_b": "self_attn.k_proj.bias",
+    "v_w": "self_attn.v_proj.weight", "v_b": "self_attn.v_proj.bias",
+    "o_w": "self_attn.out_proj.weight", "o_b": "self_attn.out_proj.bias",
+    "ln2_w": "final_layer_norm.weight", "ln2_b": "final_layer_norm.bias",
+    "fc1_w": "fc1.weight", "fc1_b": "fc1.bias", "fc2_w": "fc2.weight", "fc2_b": "fc2.bias",
+}
+
+VIT_PREFIX = "vision_model.encoder.layers.{}."
+QF_PREFIX = "qformer.encoder.layer.{}."
+OPT_PREFIX = "language_model.model.decoder.layers.{}."
+
+
+def vit_layer_keys(i):
+    return {f: VIT_PREFIX.format(i) + s for f, s in _VIT_KEYS.items()}
+
+
+def qf_layer_keys(i, has_cross):
+    return {f: QF_PREFIX.format(i) + s for f, s in _QF_KEYS.items() if has_cross or not f.startswith("c")}
+
+
+def opt_layer_keys(i):
+    return {f: OPT_PREFIX.format(i) + s for f, s in _OPT_KEYS.items()}
+
+
+def dims_from_config(config, emulate_bf16: bool = False) -> Dims:
+    """Fill EilevDims from a transformers Blip2Config (eps/sizes are read, never hard-coded)."""
+    v, q, t = config.vision_config, config.qformer_config, config.text_config
+    if getattr(t, "model_type", "opt") != "opt":
+        raise NotImplementedError("only the decoder-only OPT language model is built on the HIP path so far")
+    if not getattr(t, "do_layer_norm_before", True) or getattr(t, "word_embed_proj_dim", t.hidden_size) != t.hidden_size:
+        raise NotImplementedError("OPT variants with post-LN or projected embeddings (opt-350m) are not supported")
+    d = Dims()
+    d.image_size, d.patch_size = v.image_size, v.patch_size
+    d.v_hidden, d.v_inter, d.v_layers, d.v_heads = v.hidden_size, v.intermediate_size, v.num_hidden_layers, v.num_attention_heads
+    d.v_eps = v.layer_norm_eps
+    d.q_hidden, d.q_inter, d.q_layers, d.q_heads = q.hidden_size, q.intermediate_size, q.num_hidden_layers, q.num_attention_heads
+    d.q_cross_freq, d.num_query, d.q_eps = q.cross_attention_frequency, config.num_query_tokens, q.layer_norm_eps
+    d.t_hidden, d.t_ffn, d.t_layers, d.t_heads = t.hidden_size, t.ffn_dim, t.num_hidden_layers, t.num_attention_heads
+    d.vocab, d.max_pos, d.t_eps = t.vocab_size, t.max_position_embeddings, 1e-5  # nn.LayerNorm default (hf modeling_opt.py:215)
+    d.emulate_bf16 = int(emulate_bf16)
+    return d
+
+
+class WeightPack:
+    """The three weight structs plus the ctypes arrays they point to (kept alive here)."""
+
+    def __init__(self, dims: Dims, addr):
+        """``addr(key) -> int`` returns the address of the state-dict tensor ``key``."""
+        self.dims = dims
+        self._vit_layers = (VitLayer * dims.v_layers)()
+        for i in range(dims.v_layers):
+            for f, k in vit_layer_keys(i).items():
+                setattr(self._vit_layers[i], f, addr(k))
+        self.vit = VitWeights(
+            addr("vision_model.embeddings.patch_embedding.weight"), addr("vision_model.embeddings.patch_embedding.bias"),
+            addr("vision_model.embeddings.class_embedding"), addr("vision_model.embeddings.position_embedding"),
+            addr("vision_model.post_layernorm.weight"), addr("vision_model.post_layernorm.bias"),
+            C.cast(self._vit_layers, C.POINTER(VitLayer)))
+        self._qf_layers = (QfLayer * dims.q_layers)()
+        for i in range(dims.q_layers):
+            for f, k in qf_layer_keys(i, i % dims.q_cross_freq == 0).items():
+                setattr(self._qf_layers[i], f, addr(k))
+        self.qf = QfWeights(addr("query_tokens"), addr("qformer.layernorm.weight"), addr("qformer.layernorm.bias"),
+                            C.cast(self._qf_layers, C.POINTER(QfLayer)))
+        self._opt_layers = (OptLayer * dims.t_layers)()
+        for i in range(dims.t_layers):
+            for f, k in opt_layer_keys(i).items():
+                setattr(self._opt_layers[i], f, addr(k))
+        self.opt = OptWeights(
+            addr("language_model.model.decoder.embed_tokens.weight"),
+            addr("language_model.model.decoder.embed_positions.weight"),
+            addr("language_model.model.decoder.final_layer_norm.weight"),
+            addr("language_model.model.decoder.final_layer_norm.bias"),
+            C.cast(self._opt_layers, C.POINTER(OptLayer)))
+        self.proj_w = addr("language_projection.weight")
+        self.proj_b = addr("language_projection.bias")
+
+
+EXPORTS = [
+    "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward",
+    "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
+    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_greedy_select",
+    "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
+    "eilev_prof_collect",
+]
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    i64, i32, f32, sz = C.c_int64, C.c_int, C.c_float, C.c_size_t
+    DP = C.POINTER(Dims)
+    lib.eilev_abi_version.restype = i32
+    lib.eilev_backend.restype = C.c_char_p
+    lib.eilev_vit_workspace_bytes.restype = sz
+    lib.eilev_vit_workspace_bytes.argtypes = [DP, i64, i64]
+    lib.eilev_vit_forward.restype = i32
+    lib.eilev_vit_forward.argtypes = [DP, C.POINTER(VitWeights), vp, i32, i64, i64, vp, vp, vp, sz, vp]
+    lib.eilev_qformer_workspace_bytes.restype = sz
+    lib.eilev_qformer_workspace_bytes.argtypes = [DP, i64, i64]
+    lib.eilev_qformer_forward.restype = i32
+    lib.eilev_qformer_forward.argtypes = [DP, C.POINTER(QfWeights), vp, i64, i64, vp, vp, sz, vp]
+    lib.eilev_project_rows.restype = i32
+    lib.eilev_project_rows.argtypes = [DP, vp, vp, vp, i64, vp, vp]
+    lib.eilev_embed_scatter.restype = i32
+    lib.eilev_embed_scatter.argtypes = [DP, vp, vp, vp, vp, i64, i64, i64, vp, vp]
+    lib.eilev_opt_workspace_bytes.restype = sz
+    lib.eilev_opt_workspace_bytes.argtypes = [DP, i64, i64]
+    lib.eilev_opt_kv_cache_bytes.restype = sz
+    lib.eilev_opt_kv_cache_bytes.argtypes = [DP, i64, i64]
+    lib.eilev_opt_prefill.restype = i32
+    lib.eilev_opt_prefill.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.eilev_greedy_select.restype = i32
+    lib.eilev_greedy_select.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp, i64, vp]
+    lib.eilev_opt_decode_step.restype = i32
+    lib.eilev_opt_decode_step.argtypes = [DP, C.POINTER(OptWeights), vp, vp, vp, vp, i64, i64, vp, i64, vp, vp,
+                                          i64, i64, vp, i64, vp, sz, vp]
+    lib.eilev_linear.restype = i32
+    lib.eilev_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.eilev_layernorm.restype = i32
+    lib.eilev_layernorm.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
+    lib.eilev_attention.restype = i32
+    lib.eilev_attention.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
+    lib.eilev_prof_enable.restype = i32
+    lib.eilev_prof_enable.argtypes = [i32]
+    lib.eilev_prof_collect.restype = i32
+    lib.eilev_prof_collect.argtypes = [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return lib
+
+
+def load_library(path: str) -> C.CDLL:
+    lib = bind(C.CDLL(path))
+    if lib.eilev_abi_version() != 1:
+        raise RuntimeError(f"{path}: ABI version mismatch")
+    return lib
+
+
+_hip = None
+
+
+def load_hip() -> C.CDLL:
+    """Load the HIP product library.  No fallback: a missing build is an error."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(
+                f"{HIP_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback on the product path.")
+        _hip = load_library(HIP_LIB_PATH)
+        if _hip.eilev_backend() != b"hip-gfx950":
+            raise RuntimeError("libeilev_hip.so reports an unexpected backend")
+    return _hip
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        names = {-1: "EILEV_E_BADARG", -2: "EILEV_E_UNSUPPORTED", -3: "EILEV_E_WORKSPACE"}
+        raise RuntimeError(f"{what} failed: {names.get(rc, f'hipError {rc}')}")

@@ -1,0 +1,56 @@
+"""Named model configurations (plain dicts accepted by ``transformers.Blip2Config``).
+
+``opt27`` is the benchmark model (eilev-blip2-opt-2.7b: ViT-g/14 39L, Q-Former 12L,
+OPT-2.7B 32L; dims from ref:SURVEY §8 / hf Blip2Config defaults).  ``mid`` keeps the
+awkward head sizes of the real model (ViT 88, Q-Former 64, OPT 80) at toy widths so
+that every padded-head code path of the HIP kernels is exercised by the golden
+fixtures.  ``tiny`` mirrors the shape regime of the reference's own unit tests
+(ref:tests/model/test_model_v2.py:93-140) and is used to pin the CPU oracle only.
+"""
+from __future__ import annotations
+
+CONFIGS = {
+    "tiny": dict(
+        vision_config=dict(hidden_size=16, intermediate_size=32, num_hidden_layers=2,
+                           num_attention_heads=2, patch_size=8, image_size=32),
+        qformer_config=dict(hidden_size=16, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=32, encoder_hidden_size=16),
+        text_config=dict(model_type="opt", hidden_size=16, num_hidden_layers=2, ffn_dim=32,
+                         num_attention_heads=2, vocab_size=128, max_position_embeddings=64,
+                         word_embed_proj_dim=16),
+        num_query_tokens=4,
+    ),
+    "mid": dict(
+        vision_config=dict(hidden_size=176, intermediate_size=352, num_hidden_layers=2,
+                           num_attention_heads=2, patch_size=14, image_size=56),
+        qformer_config=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=256, encoder_hidden_size=176),
+        text_config=dict(model_type="opt", hidden_size=160, num_hidden_layers=2, ffn_dim=320,
+                         num_attention_heads=2, vocab_size=512, max_position_embeddings=128,
+                         word_embed_proj_dim=160),
+        num_query_tokens=8,
+    ),
+    "opt27": dict(
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                            intermediate_size=3072, encoder_hidden_size=1408),
+        text_config=dict(model_type="opt", hidden_size=2560, num_hidden_layers=32, ffn_dim=10240,
+                         num_attention_heads=32, vocab_size=50272, max_position_embeddings=2048,
+                         word_embed_proj_dim=2560),
+        num_query_tokens=32,
+    ),
+}
+
+
+def blip2_config(name: str):
+    """Build a ``transformers.Blip2Config`` for a named configuration."""
+    from transformers import Blip2Config
+
+    c = CONFIGS[name]
+    return Blip2Config(
+        vision_config=dict(c["vision_config"]),
+        qformer_config=dict(c["qformer_config"]),
+        text_config=dict(c["text_config"]),
+        num_query_tokens=c["num_query_tokens"],
+    )

@@ -1,0 +1,209 @@
+/*
+ * eilev.h — C ABI of the MI355X-native VideoBLIP / EILeV forward path.
+ *
+ * The reference (yukw777/EILEV) has no FFI: its boundary for this path is the Python class
+ * eilev.model.v2.VideoBlipForConditionalGeneration (ref:eilev/model/v2.py:106-324), whose
+ * arithmetic is executed by third-party `transformers` modules.  This header is the C-ABI a
+ * maintainer binds (ctypes stub in INTEGRATION.md) so that the stages of that class's
+ * forward()/generate() run on hand-written gfx950 kernels.  Each entry point names the
+ * reference code it replaces.
+ *
+ * Two shared libraries export exactly these symbols:
+ *   eilev_amd/csrc/libeilev_hip.so  — the product: HIP kernels for gfx950.  All data pointers
+ *                                     are DEVICE pointers; parameters/activations are bf16
+ *                                     (uint16 storage) unless stated; `stream` is a hipStream_t.
+ *   oracle/libeilev_ref.so          — TEST INFRASTRUCTURE ONLY: plain-C CPU restatement.  All
+ *                                     pointers are HOST pointers; parameters/activations fp32;
+ *                                     `stream` is ignored.
+ *
+ * Conventions: the caller owns every buffer (weights, activations, workspace, KV cache); the
+ * library never allocates device memory and never synchronises the stream.  Returns 0 on
+ * success, a negative EILEV_E_* for bad arguments / unsupported dimensions, a positive value
+ * = passthrough hipError_t.  No global mutable state besides the optional kernel profiler.
+ * Linear weights are in the checkpoint's layout: [out_features, in_features] row-major.
+ */
+#ifndef EILEV_H
+#define EILEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EILEV_ABI_VERSION 1
+
+#define EILEV_OK 0
+#define EILEV_E_BADARG (-1)
+#define EILEV_E_UNSUPPORTED (-2)
+#define EILEV_E_WORKSPACE (-3)
+
+/* element types of `pixels` */
+#define EILEV_F32 0
+#define EILEV_BF16 1
+
+/* Model dimensions: the fields of Blip2Config the path reads (hf:models/blip_2/configuration_blip_2.py). */
+typedef struct EilevDims {
+    /* vision (ViT) */
+    int32_t image_size, patch_size, v_hidden, v_inter, v_layers, v_heads;
+    float v_eps;
+    /* Q-Former */
+    int32_t q_hidden, q_inter, q_layers, q_heads, q_cross_freq, num_query;
+    float q_eps;
+    /* text model (OPT, pre-LN, ReLU, learned positions with offset 2) */
+    int32_t t_hidden, t_ffn, t_layers, t_heads, vocab, max_pos;
+    float t_eps;
+    /* oracle only: 1 = round activations to bf16 where the HIP path stores bf16 */
+    int32_t emulate_bf16;
+} EilevDims;
+
+/* One ViT block: hf Blip2EncoderLayer (modeling_blip_2.py:383-402). */
+typedef struct EilevVitLayer {
+    const void *ln1_w, *ln1_b;     /* [Dv] */
+    const void *qkv_w, *qkv_b;     /* [3Dv, Dv], [3Dv] (k-bias slots stored, structurally 0) */
+    const void *proj_w, *proj_b;   /* [Dv, Dv], [Dv] */
+    const void *ln2_w, *ln2_b;     /* [Dv] */
+    const void *fc1_w, *fc1_b;     /* [Fv, Dv], [Fv] */
+    const void *fc2_w, *fc2_b;     /* [Dv, Fv], [Dv] */
+} EilevVitLayer;
+
+typedef struct EilevVitWeights {
+    const void *patch_w, *patch_b; /* [Dv, 3, P, P], [Dv] */
+    const void *cls, *pos;         /* [Dv], [1 + (image/patch)^2, Dv] */
+    const void *post_ln_w, *post_ln_b;
+    const EilevVitLayer *layers;   /* host array, v_layers entries */
+} EilevVitWeights;
+
+/* One Q-Former block: hf Blip2QFormerLayer (modeling_blip_2.py:701-752). cross_* are NULL on
+ * layers without cross-attention (layer_idx % q_cross_freq != 0). */
+typedef struct EilevQfLayer {
+    const void *sq_w, *sq_b, *sk_w, *sk_b, *sv_w, *sv_b; /* self-attn q/k/v [Dq,Dq] */
+    const void *so_w, *so_b, *sln_w, *sln_b;             /* self output dense + LayerNorm */
+    const void *cq_w, *cq_b;                             /* cross query [Dq,Dq] */
+    const void *ck_w, *ck_b, *cv_w, *cv_b;               /* cross key/value [Dq,Dv] */
+    const void *co_w, *co_b, *cln_w, *cln_b;             /* cross output dense + LayerNorm */
+    const void *fi_w, *fi_b;                             /* intermediate_query [Fq,Dq] */
+    const void *fo_w, *fo_b, *fln_w, *fln_b;             /* output_query [Dq,Fq] + LayerNorm */
+} EilevQfLayer;
+
+typedef struct EilevQfWeights {
+    const void *query_tokens;      /* [num_query, Dq] */
+    const void *ln_w, *ln_b;       /* qformer.layernorm */
+    const EilevQfLayer *layers;    /* host array, q_layers entries */
+} EilevQfWeights;
+
+/* One OPT block: hf OPTDecoderLayer (modeling_opt.py:202-253). */
+typedef struct EilevOptLayer {
+    const void *ln1_w, *ln1_b;                           /* self_attn_layer_norm */
+    const void *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;       /* [Dt,Dt] */
+    const void *o_w, *o_b;                               /* out_proj */
+    const void *ln2_w, *ln2_b;                           /* final_layer_norm (of the block) */
+    const void *fc1_w, *fc1_b, *fc2_w, *fc2_b;           /* [Ft,Dt], [Dt,Ft] */
+} EilevOptLayer;
+
+typedef struct EilevOptWeights {
+    const void *embed_tokens;      /* [vocab, Dt]; also the tied lm_head */
+    const void *embed_positions;   /* [max_pos + 2, Dt] */
+    const void *final_ln_w, *final_ln_b;
+    const EilevOptLayer *layers;   /* host array, t_layers entries */
+} EilevOptWeights;
+
+int eilev_abi_version(void);
+/* "hip-gfx950" or "cpu-oracle" */
+const char *eilev_backend(void);
+
+/* ---- stage 1: vision encoder --------------------------------------------------------------
+ * Replaces VideoBlipVisionModel.forward (ref:eilev/model/v2.py:24-103) =
+ * Blip2VisionEmbeddings + 39 x Blip2EncoderLayer + post_layernorm (hf modeling_blip_2.py:243-255,
+ * 383-402, 505-533).  pixels: (N, 3, T, H, W) contiguous, f32 or bf16 (the (n,t) flatten of
+ * v2.py:57 is done by addressing, nothing is materialised).  image_embeds: (N, T*tokens, Dv).
+ * pooler: nullable (N, T, Dv) = post_layernorm applied twice to each frame's CLS row. */
+size_t eilev_vit_workspace_bytes(const EilevDims *d, int64_t n_clips, int64_t frames);
+int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
+                      int64_t n_clips, int64_t frames, void *image_embeds, void *pooler,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- stage 2: Q-Former --------------------------------------------------------------------
+ * Replaces Blip2QFormerModel.forward as called from ref:eilev/model/v2.py:291-300 with
+ * all-ones masks (hf modeling_blip_2.py:889-949).  image_embeds: (N, kv_len, Dv).
+ * query_out: (N, num_query, Dq). */
+size_t eilev_qformer_workspace_bytes(const EilevDims *d, int64_t n_clips, int64_t kv_len);
+int eilev_qformer_forward(const EilevDims *d, const EilevQfWeights *w, const void *image_embeds,
+                          int64_t n_clips, int64_t kv_len, void *query_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- stage 3: language projection + token embedding + scatter ---------------------------------
+ * Replaces ref:eilev/model/v2.py:308-316 (language_projection, get_input_embeddings()(input_ids),
+ * inputs_embeds[video_input_mask] = video_features).  query_out: (n_rows, Dq) with
+ * n_rows = N*num_query; the k-th nonzero of video_mask (row-major over (B, L)) receives projected
+ * row k.  n_rows must equal the number of nonzeros (else EILEV_E_BADARG, like torch's index_put
+ * shape error).  video_feats: nullable (n_rows, Dt) copy of the projected rows (what the RCCL
+ * all-gather exchanges).  If query_out is NULL and video_feats_in is given, rows are taken from
+ * video_feats_in (already projected, e.g. gathered from other ranks). */
+int eilev_project_rows(const EilevDims *d, const void *proj_w, const void *proj_b, const void *query_out,
+                       int64_t n_rows, void *video_feats, void *stream);
+int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens, const int64_t *input_ids,
+                        const uint8_t *video_mask, const void *video_feats, int64_t n_rows,
+                        int64_t batch, int64_t seq_len, void *inputs_embeds, void *stream);
+
+/* ---- stage 4: OPT prefill -----------------------------------------------------------------
+ * Replaces OPTForCausalLM.forward on inputs_embeds (hf modeling_opt.py:321-396, 464-524) as called
+ * from ref:eilev/model/v2.py:220-227 (forward) and through GenerationMixin._prefill from
+ * v2.py:318-322 (generate).  attn_mask: (B, L) int32, 1 = attend (left or right padding).
+ * kv_cache: [t_layers][2][B][t_heads][kv_capacity][head_dim]; logits_last: (B, vocab) f32 of the
+ * last position; logits_all: nullable (B, L, vocab) f32. */
+size_t eilev_opt_workspace_bytes(const EilevDims *d, int64_t batch, int64_t seq_len);
+size_t eilev_opt_kv_cache_bytes(const EilevDims *d, int64_t batch, int64_t kv_capacity);
+int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
+                      const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache,
+                      int64_t kv_capacity, float *logits_last, float *logits_all,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- stage 5: greedy decode ---------------------------------------------------------------
+ * Replaces one iteration of GenerationMixin._sample with do_sample=False
+ * (hf generation/utils.py:2876-2937): argmax of the fp32 last-row logits, pad-after-EOS,
+ * unfinished bookkeeping.  eilev_greedy_select consumes logits (B, vocab) and writes
+ * tokens[b] (the token fed to the next step) and out_tokens[b*max_new + state[0]'s step].
+ *
+ * state (int32, device for the HIP library): [0] = number of tokens generated so far (step),
+ * [1] = number of unfinished rows.  finished: (B) uint8.  eos_id < 0 disables EOS.
+ * eilev_opt_decode_step runs one full step: embed tokens[b] at position n_valid[b] + step - 1,
+ * 32 blocks against the KV cache (slot seq_len + step - 1), final LN, lm_head, then
+ * eilev_greedy_select.  Every launch parameter that changes between steps is read from `state`
+ * on the device, so the call can be captured once into a hipGraph and replayed. */
+int eilev_greedy_select(const float *logits, int64_t batch, int64_t vocab, int32_t *state,
+                        uint8_t *finished, int64_t eos_id, int64_t pad_id, int64_t *tokens,
+                        int64_t *out_tokens, int64_t max_new, void *stream);
+int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *w, int64_t *tokens, int32_t *state,
+                          const int32_t *attn_mask, const int32_t *n_valid, int64_t batch,
+                          int64_t seq_len, void *kv_cache, int64_t kv_capacity, float *logits,
+                          uint8_t *finished, int64_t eos_id, int64_t pad_id, int64_t *out_tokens,
+                          int64_t max_new, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- building blocks exported for unit parity tests and the roofline probe --------------------
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]); epilogue: 0 none, 1 GELU(erf),
+ * 2 ReLU.  out_f32 != 0 writes f32 instead of bf16 (HIP library). */
+int eilev_linear(const void *a, const void *w, const void *bias, const void *residual, void *c,
+                 int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream);
+int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y, int64_t rows,
+                    int64_t cols, float eps, void *stream);
+/* Multi-head attention over packed projections. q: rows of length ldq with head h at column
+ * h*head_dim (same for k, v with ldk, ldv); o: (batch, sq, heads*head_dim).  causal != 0 applies
+ * key <= query + (skv - sq); key_mask: nullable (batch, skv) int32. scale multiplies q.k. */
+int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads,
+                    int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                    float scale, int causal, const int32_t *key_mask, void *stream);
+
+/* ---- kernel profiler (HIP library; no-ops returning 0 in the oracle) ----------------------------
+ * When enabled, the dominant GEMM launches are bracketed with hipEvents on the launch stream.
+ * eilev_prof_collect synchronises those events and returns per-kind launch count, total ms and
+ * total algorithmic FLOPs since the last reset.  kind: 0 = all tiled GEMMs, 1 = ViT fc1,
+ * 2 = ViT fc2, 3 = ViT qkv, 4 = ViT proj. */
+int eilev_prof_enable(int on);
+int eilev_prof_collect(int kind, int64_t *launches, double *total_ms, double *total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EILEV_H */

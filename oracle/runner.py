@@ -1,0 +1,214 @@
+"""numpy driver of the CPU oracle (oracle/libeilev_ref.so).
+
+*** TEST INFRASTRUCTURE, NOT PRODUCT. ***  Imported only by tests/, __graft_entry__.smoke()
+and the cpu_baseline leg of bench.py.  Nothing under eilev_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from eilev_amd import abi
+from eilev_amd.synth import synth_param
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeilev_ref.so")
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(_HERE, "eilev_ref.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libeilev_ref.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_oracle()
+        _lib = abi.load_library(LIB_PATH)
+        assert _lib.eilev_backend() == b"cpu-oracle"
+    return _lib
+
+
+def state_dict_shapes(config):
+    """(key -> shape) of the VideoBLIP state dict for a Blip2Config (names: SURVEY §8a-W)."""
+    v, q, t = config.vision_config, config.qformer_config, config.text_config
+    Dv, Fv, Dq, Fq, Dt, Ft = v.hidden_size, v.intermediate_size, q.hidden_size, q.intermediate_size, t.hidden_size, t.ffn_dim
+    tok = (v.image_size // v.patch_size) ** 2 + 1
+    s = {"query_tokens": (1, config.num_query_tokens, Dq),
+         "vision_model.embeddings.class_embedding": (1, 1, Dv),
+         "vision_model.embeddings.position_embedding": (1, tok, Dv),
+         "vision_model.embeddings.patch_embedding.weight": (Dv, 3, v.patch_size, v.patch_size),
+         "vision_model.embeddings.patch_embedding.bias": (Dv,),
+         "vision_model.post_layernorm.weight": (Dv,), "vision_model.post_layernorm.bias": (Dv,),
+         "qformer.layernorm.weight": (Dq,), "qformer.layernorm.bias": (Dq,),
+         "language_projection.weight": (Dt, Dq), "language_projection.bias": (Dt,),
+         "language_model.model.decoder.embed_tokens.weight": (t.vocab_size, Dt),
+         "language_model.model.decoder.embed_positions.weight": (t.max_position_embeddings + 2, Dt),
+         "language_model.model.decoder.final_layer_norm.weight": (Dt,),
+         "language_model.model.decoder.final_layer_norm.bias": (Dt,)}
+    vs = {"ln1_w": (Dv,), "ln1_b": (Dv,), "qkv_w": (3 * Dv, Dv), "qkv_b": (3 * Dv,), "proj_w": (Dv, Dv), "proj_b": (Dv,),
+          "ln2_w": (Dv,), "ln2_b": (Dv,), "fc1_w": (Fv, Dv), "fc1_b": (Fv,), "fc2_w": (Dv, Fv), "fc2_b": (Dv,)}
+    for i in range(v.num_hidden_layers):
+        for f, k in abi.vit_layer_keys(i).items():
+            s[k] = vs[f]
+    for i in range(q.num_hidden_layers):
+        cross = i % q.cross_attention_frequency == 0
+        for f, k in abi.qf_layer_keys(i, cross).items():
+            if f in ("ck_w", "cv_w"):
+                shp = (Dq, q.encoder_hidden_size)
+            elif f == "fi_w":
+                shp = (Fq, Dq)
+            elif f == "fi_b":
+                shp = (Fq,)
+            elif f == "fo_w":
+                shp = (Dq, Fq)
+            elif f.endswith("_w") and "ln" not in f:
+                shp = (Dq, Dq)
+            else:
+                shp = (Dq,)
+            s[k] = shp
+    os_ = {"fc1_w": (Ft, Dt), "fc1_b": (Ft,), "fc2_w": (Dt, Ft)}
+    for i in range(t.num_hidden_layers):
+        for f, k in abi.opt_layer_keys(i).items():
+            s[k] = os_.get(f, (Dt, Dt) if f in ("q_w", "k_w", "v_w", "o_w") else (Dt,))
+    return s
+
+
+def synth_state_dict(config, mode: str = "fanin", seed: int = 0):
+    """Deterministic fp32 numpy state dict (bf16-exact values), identical to tools/make_goldens.py."""
+    return {k: synth_param(k, shp, mode, seed) for k, shp in state_dict_shapes(config).items()}
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleModel:
+    """Runs the reference arithmetic on CPU through the oracle's C ABI."""
+
+    def __init__(self, config, weights: dict, emulate_bf16: bool = False):
+        self.config = config
+        self.w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+        self.dims = abi.dims_from_config(config, emulate_bf16)
+        self.pack = abi.WeightPack(self.dims, lambda k: self.w[k].ctypes.data)
+        self.lib = lib()
+        self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
+
+    # ---- stages -------------------------------------------------------------------------
+    def vit(self, pixels: np.ndarray, want_pooler: bool = False):
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        N, _, T = px.shape[:3]
+        d = self.dims
+        out = np.empty((N, T * self.tokens_per_frame, d.v_hidden), np.float32)
+        pool = np.empty((N, T, d.v_hidden), np.float32) if want_pooler else None
+        nbytes = self.lib.eilev_vit_workspace_bytes(C.byref(d), N, T)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_vit_forward(C.byref(d), C.byref(self.pack.vit), _p(px), abi_f32(), N, T, _p(out),
+                                             _p(pool), _p(ws), nbytes, None), "oracle vit")
+        return (out, pool) if want_pooler else out
+
+    def qformer(self, image_embeds: np.ndarray):
+        img = np.ascontiguousarray(image_embeds, dtype=np.float32)
+        N, kv = img.shape[:2]
+        d = self.dims
+        out = np.empty((N, d.num_query, d.q_hidden), np.float32)
+        nbytes = self.lib.eilev_qformer_workspace_bytes(C.byref(d), N, kv)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_qformer_forward(C.byref(d), C.byref(self.pack.qf), _p(img), N, kv, _p(out), _p(ws),
+                                                 nbytes, None), "oracle qformer")
+        return out
+
+    def project(self, query_out: np.ndarray):
+        q = np.ascontiguousarray(query_out, dtype=np.float32).reshape(-1, self.dims.q_hidden)
+        out = np.empty((q.shape[0], self.dims.t_hidden), np.float32)
+        abi.check(self.lib.eilev_project_rows(C.byref(self.dims), self.pack.proj_w, self.pack.proj_b, _p(q), q.shape[0],
+                                              _p(out), None), "oracle project")
+        return out
+
+    def embed_scatter(self, input_ids, video_mask, video_feats):
+        ids = np.ascontiguousarray(input_ids, dtype=np.int64)
+        B, L = ids.shape
+        vm = None if video_mask is None else np.ascontiguousarray(video_mask != 0, dtype=np.uint8)
+        vf = None if video_feats is None else np.ascontiguousarray(video_feats, dtype=np.float32)
+        out = np.empty((B, L, self.dims.t_hidden), np.float32)
+        abi.check(self.lib.eilev_embed_scatter(C.byref(self.dims), self.pack.opt.embed_tokens, _p(ids), _p(vm), _p(vf),
+                                               0 if vf is None else vf.shape[0], B, L, _p(out), None), "oracle embed_scatter")
+        return out
+
+    def encode(self, pixels, input_ids, video_mask):
+        img = self.vit(pixels)
+        feats = self.project(self.qformer(img))
+        return self.embed_scatter(input_ids, video_mask, feats)
+
+    def prefill(self, inputs_embeds, attn_mask, kv_capacity=None, all_logits=True):
+        x = np.ascontiguousarray(inputs_embeds, dtype=np.float32)
+        B, L, _ = x.shape
+        d = self.dims
+        cap = int(kv_capacity or L)
+        am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        kv = np.zeros(self.lib.eilev_opt_kv_cache_bytes(C.byref(d), B, cap) // 4, np.float32)
+        last = np.empty((B, d.vocab), np.float32)
+        alll = np.empty((B, L, d.vocab), np.float32) if all_logits else None
+        nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, L)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_opt_prefill(C.byref(d), C.byref(self.pack.opt), _p(x), _p(am), B, L, _p(kv), cap, _p(last),
+                                             _p(alll), _p(ws), nbytes, None), "oracle prefill")
+        return last, alll, kv
+
+    def forward_logits(self, pixels, input_ids, attn_mask, video_mask):
+        """= reference forward(...).logits (ref:eilev/model/v2.py:132-252)."""
+        emb = self.encode(pixels, input_ids, video_mask)
+        _, alll, _ = self.prefill(emb, attn_mask)
+        return alll
+
+    def generate(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, eos_id=-1, pad_id=1,
+                 return_logits=False):
+        """Greedy = reference generate(num_beams=1, do_sample=False) (ref:eilev/model/v2.py:254-324)."""
+        d = self.dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        B, L, _ = emb.shape
+        cap = L + max_new_tokens
+        am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        last, _, kv = self.prefill(emb, am, kv_capacity=cap, all_logits=False)
+        state = np.zeros(2, np.int32)
+        state[1] = B
+        finished = np.zeros(B, np.uint8)
+        tokens = np.zeros(B, np.int64)
+        out = np.full((B, max_new_tokens), pad_id, np.int64)
+        step_logits = [last.copy()]
+        abi.check(self.lib.eilev_greedy_select(_p(last), B, d.vocab, _p(state), _p(finished), eos_id, pad_id, _p(tokens),
+                                               _p(out), max_new_tokens, None), "oracle select")
+        n_valid = am.sum(axis=1).astype(np.int32)
+        nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, 1)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        logits = np.empty((B, d.vocab), np.float32)
+        while state[0] < max_new_tokens and state[1] > 0:
+            abi.check(self.lib.eilev_opt_decode_step(C.byref(d), C.byref(self.pack.opt), _p(tokens), _p(state), _p(am),
+                                                     _p(n_valid), B, L, _p(kv), cap, _p(logits), _p(finished), eos_id,
+                                                     pad_id, _p(out), max_new_tokens, _p(ws), nbytes, None), "oracle decode")
+            step_logits.append(logits.copy())
+        ids = out[:, : int(state[0])]
+        return (ids, step_logits) if return_logits else ids
+
+
+def abi_f32():
+    return 0
+
+
+def shifted_ce_loss(logits: np.ndarray, labels: np.ndarray) -> float:
+    """HF ForCausalLM loss: mean CE over shifted positions with label != -100."""
+    lg = logits[:, :-1].astype(np.float64)
+    lb = labels[:, 1:]
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    sel = lb != -100
+    picked = np.take_along_axis(lg, np.where(sel, lb, 0)[..., None], -1)[..., 0]
+    return float(((lse - picked) * sel).sum() / sel.sum())

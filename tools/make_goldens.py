@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Generate golden fixtures from the REFERENCE implementation (run in the build container only).
+
+    PYTHONPATH=/root/reference python tools/make_goldens.py
+
+Imports ``eilev.model.v2.VideoBlipForConditionalGeneration`` from /root/reference (never
+copied, never shipped) together with the installed ``transformers``; feeds it the
+deterministic tensors of ``eilev_amd.synth`` and stores only inputs-by-recipe and
+OUTPUTS as small ``.npz`` files under tests/golden/.  The fixtures pin the CPU oracle
+(``oracle/``) in fp32 and give the bf16 reference outputs the HIP path is judged against.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.append("/root/reference")  # reference package is named `eilev`; ours is `eilev_amd`
+
+import transformers  # noqa: E402
+from eilev.model.v2 import VideoBlipForConditionalGeneration as RefModel  # noqa: E402  (REFERENCE)
+
+from eilev_amd.configs import CONFIGS, blip2_config  # noqa: E402
+from eilev_amd.synth import synth_interleaved_ids, synth_param, synth_pixels  # noqa: E402
+
+CASES = {
+    # name: (config, frames T, rows=[(clips_per_block, text_lens)], new_tokens)
+    "tiny_b1": ("tiny", 2, [([1, 1, 1], [5, 5, 4])], 6),
+    "tiny_b2": ("tiny", 1, [([1, 1], [4, 6]), ([2], [3])], 6),
+    "mid_b1": ("mid", 2, [([1, 1, 1], [5, 5, 4])], 6),
+    "mid_b2": ("mid", 2, [([1, 1], [6, 7]), ([1, 1], [3, 3])], 6),
+}
+
+
+def build_inputs(cfg_name, frames, rows):
+    c = CONFIGS[cfg_name]
+    nq = c["num_query_tokens"]
+    vocab = c["text_config"]["vocab_size"]
+    image = c["vision_config"]["image_size"]
+    ids_rows, mask_rows = [], []
+    for r, (clips, lens) in enumerate(rows):
+        ids, vm = synth_interleaved_ids(clips, lens, nq, vocab, seed=1 + r)
+        ids_rows.append(ids)
+        mask_rows.append(vm)
+    L = max(len(x) for x in ids_rows)
+    B = len(rows)
+    input_ids = np.full((B, L), 1, dtype=np.int64)  # pad id 1, LEFT padding (generation convention)
+    attn = np.zeros((B, L), dtype=np.int64)
+    vmask = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = len(ids_rows[b])
+        input_ids[b, L - n:] = ids_rows[b]
+        attn[b, L - n:] = 1
+        vmask[b, L - n:] = mask_rows[b]
+    nclips = sum(sum(clips) for clips, _ in rows)
+    pixels = synth_pixels(nclips, frames, image)
+    labels = np.where((attn == 1) & (vmask == 0), input_ids, -100)
+    return pixels, input_ids, attn, vmask, labels
+
+
+def load_det_weights(model, mode="fanin"):
+    sd = model.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k == "language_model.lm_head.weight":
+            continue
+        new[k] = torch.from_numpy(synth_param(k, tuple(v.shape), mode)).to(v.dtype)
+    new["language_model.lm_head.weight"] = new["language_model.model.decoder.embed_tokens.weight"]
+    model.load_state_dict(new)
+
+
+@torch.no_grad()
+def run_case(name):
+    cfg_name, frames, rows, new_tokens = CASES[name]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, labels = build_inputs(cfg_name, frames, rows)
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        px = t(pixels).to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=px,
+              video_input_mask=t(vmask), labels=t(labels), return_dict=True)
+        out[f"{tag}_vit"] = o.vision_outputs.last_hidden_state.float().numpy()
+        out[f"{tag}_pooler"] = o.vision_outputs.pooler_output.float().numpy()
+        out[f"{tag}_qformer"] = o.qformer_outputs.last_hidden_state.float().numpy()
+        out[f"{tag}_logits"] = o.logits.float().numpy()
+        out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
+        vocab = cfg.text_config.vocab_size
+        free = None
+        for never in range(vocab - 1, 3, -1):
+            g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask),
+                           attention_mask=t(attn), max_new_tokens=new_tokens, num_beams=1,
+                           do_sample=False, eos_token_id=never)
+            if not (g == never).any():
+                free = g
+                break
+        assert free is not None and free.shape == (len(rows), new_tokens), free.shape
+        out[f"{tag}_greedy_free"] = free.numpy().astype(np.int64)
+        eos = int(free[0, 2])
+        g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask),
+                       attention_mask=t(attn), max_new_tokens=new_tokens, num_beams=1,
+                       do_sample=False, eos_token_id=eos)
+        out[f"{tag}_greedy_eos"] = g.numpy().astype(np.int64)
+        out[f"{tag}_eos_id"] = np.asarray(eos, dtype=np.int64)
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens,
+                weight_mode="fanin", torch=torch.__version__, transformers=transformers.__version__,
+                attn_implementation=str(getattr(cfg, "_attn_implementation", None)),
+                generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py")
+    out["input_ids"] = input_ids
+    out["attention_mask"] = attn
+    out["video_input_mask"] = vmask
+    out["labels"] = labels
+    out["meta"] = np.asarray(json.dumps(meta))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"},
+          os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or CASES):
+        run_case(n)
