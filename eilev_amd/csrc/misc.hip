@@ -1,0 +1,415 @@
+// misc.hip — the HBM-bound glue kernels of the path: patch gather (im2col), embedding gather/scatter,
+// OPT position ids, KV-cache writes, single-query decode attention, greedy selection.
+#include "common.h"
+
+namespace {
+
+// ---- patch gather -------------------------------------------------------------------------------
+// Conv2d(3->D, k=P, s=P) of hf modeling_blip_2.py:246 as a GEMM: row (n, t, py, px) gathers 3*P*P pixels of
+// frame t of clip n straight from the (N, 3, T, H, W) tensor (the permute+flatten of
+// ref:eilev/model/v2.py:57 is pure addressing).  K is zero-padded to KP (multiple of 64).
+template <typename T>
+__global__ void im2col_kernel(const T *__restrict__ pix, bf16 *__restrict__ out, int64_t rows, int frames, int img,
+                              int patch, int kp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int chunks = kp >> 3;
+    if (idx >= rows * chunks) return;
+    const int64_t row = idx / chunks;
+    const int c = (int)(idx - row * chunks);
+    const int g = img / patch, gg = g * g, pp = patch * patch;
+    const int64_t f = row / gg;
+    const int p = (int)(row - f * gg), py = p / g, px = p - py * g;
+    const int64_t n = f / frames;
+    const int t = (int)(f - n * frames);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = c * 8 + e;
+        float val = 0.0f;
+        if (k < 3 * pp) {
+            const int ch = k / pp, rem = k - ch * pp, dy = rem / patch, dx = rem - dy * patch;
+            val = (float)pix[(((n * 3 + ch) * frames + t) * img + py * patch + dy) * (int64_t)img + px * patch + dx];
+        }
+        v[e] = val;
+    }
+    *reinterpret_cast<bf16x8 *>(out + row * kp + c * 8) = pack8(v);
+}
+
+__global__ void pad_rows_kernel(const bf16 *__restrict__ w, bf16 *__restrict__ out, int rows, int k, int kp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * kp) return;
+    const int r = idx / kp, c = idx - r * kp;
+    out[idx] = c < k ? w[(int64_t)r * k + c] : (bf16)0.0f;
+}
+
+__global__ void cls_rows_kernel(const bf16 *__restrict__ cls, const bf16 *__restrict__ pos, bf16 *__restrict__ x,
+                                int64_t frames_total, int tok, int d) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= frames_total * d) return;
+    const int64_t f = idx / d;
+    const int c = (int)(idx - f * d);
+    x[f * tok * (int64_t)d + c] = (bf16)((float)cls[c] + (float)pos[c]);
+}
+
+__global__ void broadcast_rows_kernel(const bf16 *__restrict__ src, bf16 *__restrict__ dst, int64_t copies, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= copies * n) return;
+    dst[idx] = src[idx % n];
+}
+
+// ---- embedding gather + video-feature scatter (ref:eilev/model/v2.py:314-316) -----------------------
+// Pass 1 (one workgroup): exclusive rank of every set bit of video_mask in row-major (B, L) order, parked
+// in the first 4 bytes of the destination row.  Pass 2 (workgroup per row): copy either
+// video_feats[rank] or embed_tokens[id].
+__global__ __launch_bounds__(1024) void mask_rank_kernel(const uint8_t *__restrict__ mask, bf16 *__restrict__ out,
+                                                         int64_t total, int d) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < total; start += 1024) {
+        const int64_t i = start + tid;
+        const int bit = (i < total && mask && mask[i]) ? 1 : 0;
+        int incl = bit;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int rank = base + woff + incl - bit;
+        if (i < total) *reinterpret_cast<int *>(out + i * (int64_t)d) = bit ? rank : -1;
+        __syncthreads();
+        if (tid == 1023) base = base + woff + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_rows_kernel(const bf16 *__restrict__ embed, const int64_t *__restrict__ ids,
+                                                         const bf16 *__restrict__ feats, int64_t n_rows, int vocab,
+                                                         bf16 *__restrict__ out, int d) {
+    __shared__ int rank_s;
+    const int64_t i = blockIdx.x;
+    bf16 *dst = out + i * (int64_t)d;
+    if (threadIdx.x == 0) rank_s = *reinterpret_cast<const int *>(dst);
+    __syncthreads();
+    const int rank = rank_s;
+    const bf16 *src;
+    if (rank >= 0 && feats && rank < n_rows) {
+        src = feats + (int64_t)rank * d;
+    } else {
+        int64_t id = ids[i];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = embed + id * d;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < (d >> 3); c += 256)
+        *reinterpret_cast<bf16x8 *>(dst + c * 8) = *reinterpret_cast<const bf16x8 *>(src + c * 8);
+}
+
+// ---- OPT learned positions: pid = cumsum(mask) * mask - 1 + 2 (hf modeling_opt.py:64-70) ---------------
+__global__ __launch_bounds__(1024) void pos_ids_kernel(const int32_t *__restrict__ mask, int32_t *__restrict__ pid, int L) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t b = blockIdx.x;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < L; start += 1024) {
+        const int i = start + tid;
+        const int bit = (i < L && mask[b * L + i] != 0) ? 1 : 0;
+        int incl = bit;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int cum = base + woff + incl;
+        if (i < L) pid[b * L + i] = cum * bit - 1 + 2;
+        __syncthreads();
+        if (tid == 1023) base = cum;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(const bf16 *__restrict__ emb, const bf16 *__restrict__ pos,
+                                                      const int32_t *__restrict__ pid, bf16 *__restrict__ h, int d) {
+    const int64_t i = blockIdx.x;
+    const bf16 *e = emb + i * d, *p = pos + (int64_t)pid[i] * d;
+    for (int c = threadIdx.x; c < (d >> 3); c += 256) {
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const bf16x8 *>(e + c * 8), x);
+        unpack8(*reinterpret_cast<const bf16x8 *>(p + c * 8), y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += y[k];
+        *reinterpret_cast<bf16x8 *>(h + i * d + c * 8) = pack8(x);
+    }
+}
+
+// decode: h[b] = embed[tokens[b]] + pos[n_valid[b] + step - 1 + 2], step = state[0]
+__global__ __launch_bounds__(256) void decode_embed_kernel(const bf16 *__restrict__ embed, const bf16 *__restrict__ pos,
+                                                           const int64_t *__restrict__ tokens,
+                                                           const int32_t *__restrict__ n_valid,
+                                                           const int32_t *__restrict__ state, int vocab, int max_pid,
+                                                           bf16 *__restrict__ h, int d) {
+    const int b = blockIdx.x;
+    int64_t id = tokens[b];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pidx = n_valid[b] + state[0] - 1 + 2;
+    pidx = pidx > max_pid ? max_pid : pidx;
+    const bf16 *e = embed + id * d, *p = pos + (int64_t)pidx * d;
+    for (int c = threadIdx.x; c < (d >> 3); c += 256) {
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const bf16x8 *>(e + c * 8), x);
+        unpack8(*reinterpret_cast<const bf16x8 *>(p + c * 8), y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += y[k];
+        *reinterpret_cast<bf16x8 *>(h + (int64_t)b * d + c * 8) = pack8(x);
+    }
+}
+
+// ---- KV cache: [B][H][cap][hd] per layer and per k/v (DynamicCache.update, hf modeling_opt.py:161) ----
+// qkv: rows of 3*D (q | k | v).  Prefill: rows_per_b = L, slot0 = 0.  Decode: rows_per_b = 1, slot from state.
+__global__ __launch_bounds__(256) void kv_write_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc,
+                                                       bf16 *__restrict__ vc, int rows_per_b, int heads, int hd, int cap,
+                                                       int seq_len, const int32_t *__restrict__ state) {
+    const int64_t row = blockIdx.x;  // b * rows_per_b + r
+    const int b = (int)(row / rows_per_b), r = (int)(row - (int64_t)b * rows_per_b);
+    const int slot = state ? (seq_len + state[0] - 1) : r;
+    const int d = heads * hd, ch = hd >> 3;
+    const bf16 *src = qkv + row * 3 * (int64_t)d;
+    for (int c = threadIdx.x; c < 2 * heads * ch; c += 256) {
+        const int which = c / (heads * ch), rem = c - which * heads * ch, hh = rem / ch, cc = rem - hh * ch;
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + (1 + which) * d + hh * hd + cc * 8);
+        bf16 *dst = (which ? vc : kc) + (((int64_t)b * heads + hh) * cap + slot) * hd + cc * 8;
+        *reinterpret_cast<bf16x8 *>(dst) = v;
+    }
+}
+
+// ---- single-query attention against the cache (decode step) ---------------------------------------------
+// grid (heads, batch).  kv_total = seq_len + state[0]; keys < seq_len obey attn_mask, newer ones are visible.
+// Phase 1: 16 lanes per key (one 16-byte chunk each) -> score; phase 2: workgroup max / sum; phase 3:
+// thread = (key subset, d chunk) accumulates p * v, reduced through LDS.
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ kc,
+                                                          const bf16 *__restrict__ vc, bf16 *__restrict__ out,
+                                                          const int32_t *__restrict__ attn_mask,
+                                                          const int32_t *__restrict__ state, int seq_len, int cap,
+                                                          int heads, int hd) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *sc = dsm;                 // [cap]
+    float *red = dsm + cap;          // [nks][hd]
+    __shared__ float wred[4];
+    __shared__ float bc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int d = heads * hd, nch = hd >> 3;
+    const int kv_total = min(cap, seq_len + state[0]);
+    const bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd;
+    const bf16 *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+
+    // phase 1
+    const int l15 = lane & 15, sub = lane >> 4;
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = 0.0f;
+    if (l15 < nch) unpack8(*reinterpret_cast<const bf16x8 *>(qkv + (int64_t)b * 3 * d + h * hd + l15 * 8), qv);
+    float lmax = -1e30f;
+    for (int j = wid * 4 + sub; j < kv_total; j += 16) {
+        float s = 0.0f;
+        if (l15 < nch) {
+            float kvv[8];
+            unpack8(*reinterpret_cast<const bf16x8 *>(kbase + (int64_t)j * hd + l15 * 8), kvv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qv[e] * kvv[e];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        const bool vis = j >= seq_len || attn_mask[(int64_t)b * seq_len + j] != 0;
+        s = vis ? s : -1e30f;
+        if (l15 == 0) sc[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) wred[wid] = lmax;
+    __syncthreads();
+    if (tid == 0) bc[0] = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    __syncthreads();
+    const float mx = bc[0];
+    // phase 2
+    float lsum = 0.0f;
+    for (int j = tid; j < kv_total; j += 256) {
+        const float s = sc[j];
+        const float p = s > -1e29f ? __expf(s - mx) : 0.0f;
+        sc[j] = p;
+        lsum += p;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if (lane == 0) wred[wid] = lsum;
+    __syncthreads();
+    if (tid == 0) bc[1] = wred[0] + wred[1] + wred[2] + wred[3];
+    __syncthreads();
+    const float inv = bc[1] > 0.0f ? 1.0f / bc[1] : 0.0f;
+    // phase 3
+    const int nks = 256 / nch;
+    const int c = tid % nch, ks = tid / nch;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    if (ks < nks) {
+        for (int j = ks; j < kv_total; j += nks) {
+            // P is rounded to bf16 like the prefill kernel's MFMA operand
+            const float p = (float)(bf16)sc[j];
+            float vv[8];
+            unpack8(*reinterpret_cast<const bf16x8 *>(vbase + (int64_t)j * hd + c * 8), vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * vv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[ks * hd + c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float v = 0.0f;
+        for (int k2 = 0; k2 < nks; ++k2) v += red[k2 * hd + tid];
+        out[(int64_t)b * d + h * hd + tid] = (bf16)(v * inv);
+    }
+}
+
+// ---- greedy selection (hf generation/utils.py:2894-2937) ------------------------------------------------
+__global__ __launch_bounds__(1024) void select_kernel(const float *__restrict__ logits, int vocab,
+                                                      const int32_t *__restrict__ state, uint8_t *__restrict__ finished,
+                                                      int64_t eos_id, int64_t pad_id, int64_t *__restrict__ tokens,
+                                                      int64_t *__restrict__ out_tokens, int64_t max_new) {
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float *lr = logits + (int64_t)b * vocab;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < vocab; i += 1024) {
+        const float v = lr[i];
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        wv[wid] = best;
+        wi[wid] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (wv[w] > best || (wv[w] == best && wi[w] < bi)) {
+                best = wv[w];
+                bi = wi[w];
+            }
+        if (bi == 0x7fffffff) bi = 0;
+        const int step = state[0];
+        const int64_t tok = finished[b] ? pad_id : (int64_t)bi;
+        tokens[b] = tok;
+        if (step < max_new) out_tokens[(int64_t)b * max_new + step] = tok;
+        if (eos_id >= 0 && tok == eos_id) finished[b] = 1;
+    }
+}
+
+__global__ void finalize_step_kernel(int32_t *__restrict__ state, const uint8_t *__restrict__ finished, int batch) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int unf = 0;
+        for (int b = 0; b < batch; ++b) unf += finished[b] ? 0 : 1;
+        state[0] = state[0] + 1;
+        state[1] = unf;
+    }
+}
+
+}  // namespace
+
+// ---- host launchers ------------------------------------------------------------------------------------
+int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s) {
+    const int64_t total = rows * (kp >> 3);
+    const dim3 grid((unsigned)ceil_div64(total, 256)), block(256);
+    if (dtype == EILEV_F32) hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, (const float *)pix, out, rows, frames, img, patch, kp);
+    else if (dtype == EILEV_BF16) hipLaunchKernelGGL(im2col_kernel<bf16>, grid, block, 0, s, (const bf16 *)pix, out, rows, frames, img, patch, kp);
+    else return EILEV_E_UNSUPPORTED;
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_pad_rows(const bf16 *w, bf16 *out, int rows, int k, int kp, hipStream_t s) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((rows * kp + 255) / 256), dim3(256), 0, s, w, out, rows, k, kp);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_total, int tok, int d, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)ceil_div64(frames_total * d, 256)), dim3(256), 0, s, cls, pos, x, frames_total, tok, d);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_broadcast_rows(const bf16 *src, bf16 *dst, int64_t copies, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)ceil_div64(copies * n, 256)), dim3(256), 0, s, src, dst, copies, n);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *mask, const bf16 *feats, int64_t n_rows,
+                         int64_t total, int vocab, bf16 *out, int d, hipStream_t s) {
+    hipLaunchKernelGGL(mask_rank_kernel, dim3(1), dim3(1024), 0, s, mask, out, total, d);
+    EILEV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)total), dim3(256), 0, s, embed, ids, feats, n_rows, vocab, out, d);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s) {
+    hipLaunchKernelGGL(pos_ids_kernel, dim3(batch), dim3(1024), 0, s, mask, pid, L);
+    EILEV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(add_pos_kernel, dim3(batch * L), dim3(256), 0, s, emb, pos, pid, h, d);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *tokens, const int32_t *n_valid, const int32_t *state,
+                        int vocab, int max_pid, bf16 *h, int batch, int d, hipStream_t s) {
+    hipLaunchKernelGGL(decode_embed_kernel, dim3(batch), dim3(256), 0, s, embed, pos, tokens, n_valid, state, vocab, max_pid, h, d);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
+                    const int32_t *state, hipStream_t s) {
+    hipLaunchKernelGGL(kv_write_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, qkv, kc, vc, rows_per_b, heads, hd, cap, seq_len, state);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
+                       int batch, int seq_len, int cap, int heads, int hd, hipStream_t s) {
+    const int nks = 256 / (hd >> 3);
+    const size_t smem = sizeof(float) * ((size_t)cap + (size_t)nks * hd);
+    if (smem > 60 * 1024) return EILEV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(heads, batch), dim3(256), smem, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, hd);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
+                  int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s) {
+    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new);
+    EILEV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_step_kernel, dim3(1), dim3(64), 0, s, state, finished, batch);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

@@ -1,0 +1,74 @@
+// norm.hip — LayerNorm over rows of bf16 (fp32 statistics, two-pass in registers).
+// Replaces nn.LayerNorm at hf modeling_blip_2.py:390,397,522 (ViT), :619,:675,:913 (Q-Former) and
+// hf modeling_opt.py:215,226,387 (OPT).  One 64-lane wave per row, 16-byte loads/stores, the row is
+// held in registers between the mean and the variance pass (matches torch's biased variance).
+// HBM-bound: reads and writes each element once.
+#include "common.h"
+
+namespace {
+
+template <int MAXC>  // max 16-byte chunks per lane: cols <= MAXC * 512
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16 *__restrict__ x, int64_t ldx,
+                                                        const bf16 *__restrict__ gamma,
+                                                        const bf16 *__restrict__ beta, bf16 *__restrict__ y,
+                                                        int64_t ldy, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;
+    const bf16 *xr = x + row * ldx;
+    float v[MAXC][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            bf16x8 t = *reinterpret_cast<const bf16x8 *>(xr + c * 8);
+            unpack8(t, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)cols;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)cols + eps);
+    bf16 *yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            float gv[8], bv[8], o[8];
+            unpack8(*reinterpret_cast<const bf16x8 *>(gamma + c * 8), gv);
+            unpack8(*reinterpret_cast<const bf16x8 *>(beta + c * 8), bv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gv[e] + bv[e];
+            *reinterpret_cast<bf16x8 *>(yr + c * 8) = pack8(o);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
+                     int cols, float eps, hipStream_t s) {
+    if (rows <= 0) return EILEV_OK;
+    if (!x || !g || !b || !y) return EILEV_E_BADARG;
+    if ((cols & 7) || (ldx & 7) || (ldy & 7) || cols > 8 * 512) return EILEV_E_UNSUPPORTED;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (cols <= 3 * 512) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, ldx, g, b, y, ldy, rows, cols, eps);
+    else if (cols <= 5 * 512) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, x, ldx, g, b, y, ldy, rows, cols, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, g, b, y, ldy, rows, cols, eps);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

@@ -1,0 +1,501 @@
+// pipeline.hip — the C ABI of include/eilev.h on top of the gfx950 kernels: stage orchestration only
+// (which kernel runs on which buffer); no arithmetic lives here.  Every launch goes to the caller's
+// stream, nothing allocates or synchronises (except eilev_prof_collect), so a whole stage can be captured
+// into a hipGraph by the caller.
+#include <vector>
+
+#include "common.h"
+
+int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s);
+int launch_pad_rows(const bf16 *w, bf16 *out, int rows, int k, int kp, hipStream_t s);
+int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_total, int tok, int d, hipStream_t s);
+int launch_broadcast_rows(const bf16 *src, bf16 *dst, int64_t copies, int64_t n, hipStream_t s);
+int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *mask, const bf16 *feats, int64_t n_rows,
+                         int64_t total, int vocab, bf16 *out, int d, hipStream_t s);
+int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s);
+int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *tokens, const int32_t *n_valid, const int32_t *state,
+                        int vocab, int max_pid, bf16 *h, int batch, int d, hipStream_t s);
+int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
+                    const int32_t *state, hipStream_t s);
+int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
+                       int batch, int seq_len, int cap, int heads, int hd, hipStream_t s);
+int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
+                  int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
+
+#define RC(expr)                 \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---- kernel profiler --------------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    int kind;
+    double flops;
+};
+std::vector<ProfRec> g_recs;
+size_t g_used = 0;
+bool g_prof_on = false;
+constexpr size_t kMaxRecs = 65536;
+}  // namespace
+
+void prof_begin(int kind, double flops, hipStream_t s) {
+    if (!g_prof_on || g_used >= kMaxRecs) return;
+    if (g_used == g_recs.size()) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_recs.push_back(r);
+    }
+    g_recs[g_used].kind = kind;
+    g_recs[g_used].flops = flops;
+    hipEventRecord(g_recs[g_used].a, s);
+}
+void prof_end(hipStream_t s) {
+    if (!g_prof_on || g_used >= kMaxRecs || g_used >= g_recs.size()) return;
+    hipEventRecord(g_recs[g_used].b, s);
+    ++g_used;
+}
+
+extern "C" int eilev_prof_enable(int on) {
+    g_prof_on = on != 0;
+    g_used = 0;
+    return 0;
+}
+extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms, double *total_flops) {
+    int64_t n = 0;
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < g_used; ++i) {
+        if (kind != 0 && g_recs[i].kind != kind) continue;
+        if (hipEventSynchronize(g_recs[i].b) != hipSuccess) continue;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, g_recs[i].a, g_recs[i].b) != hipSuccess) continue;
+        ms += t;
+        fl += g_recs[i].flops;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    return 0;
+}
+
+extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
+extern "C" const char *eilev_backend(void) { return "hip-gfx950"; }
+
+namespace {
+
+struct Carver {
+    char *p;
+    char *end;
+    template <typename T>
+    T *take(size_t n) {
+        char *q = p;
+        p += align_up(n * sizeof(T), 256);
+        return reinterpret_cast<T *>(q);
+    }
+    bool ok() const { return p <= end; }
+};
+
+GemmArgs mk_gemm(const bf16 *A, int64_t lda, const void *W, int64_t ldw, const void *bias, const bf16 *resid, int64_t ldr,
+                 void *C, int64_t ldc, int64_t M, int N, int K, int epi) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = (const bf16 *)W; g.ldw = ldw; g.bias = (const bf16 *)bias; g.resid = resid; g.ldr = ldr;
+    g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.epi = epi; g.out_f32 = 0; g.scale = 1.0f; g.scale_cols = 0;
+    g.patch_group = 0; g.scratch = nullptr; g.scratch_bytes = 0;
+    return g;
+}
+
+inline int64_t vit_tok(const EilevDims *d) {
+    const int64_t g = d->image_size / d->patch_size;
+    return g * g + 1;
+}
+inline int patch_kp(const EilevDims *d) { return (3 * d->patch_size * d->patch_size + 63) / 64 * 64; }
+
+bool dims_ok_vit(const EilevDims *d) {
+    return d->v_hidden % 8 == 0 && d->v_inter % 8 == 0 && d->v_heads > 0 && d->v_hidden % d->v_heads == 0 &&
+           (d->v_hidden / d->v_heads) % 8 == 0 && d->v_hidden / d->v_heads <= 128 && d->v_hidden <= 4096 &&
+           d->image_size % d->patch_size == 0;
+}
+bool dims_ok_qf(const EilevDims *d) {
+    return d->q_hidden % 8 == 0 && d->q_inter % 8 == 0 && d->q_heads > 0 && d->q_hidden % d->q_heads == 0 &&
+           (d->q_hidden / d->q_heads) % 8 == 0 && d->q_hidden / d->q_heads <= 128 && d->q_hidden <= 4096 && d->q_cross_freq > 0;
+}
+bool dims_ok_opt(const EilevDims *d) {
+    return d->t_hidden % 8 == 0 && d->t_ffn % 8 == 0 && d->t_heads > 0 && d->t_hidden % d->t_heads == 0 &&
+           (d->t_hidden / d->t_heads) % 8 == 0 && d->t_hidden / d->t_heads <= 128 && d->t_hidden <= 4096;
+}
+
+constexpr size_t kSkinnyScratch = 8u << 20;
+
+}  // namespace
+
+// =====================================================================================================
+// Stage 1: ViT
+// =====================================================================================================
+extern "C" size_t eilev_vit_workspace_bytes(const EilevDims *d, int64_t n_clips, int64_t frames) {
+    const int64_t M = n_clips * frames * vit_tok(d);
+    size_t b = 0;
+    b += align_up((size_t)M * d->v_hidden * 2, 256) * 3;      // x, ln, att
+    b += align_up((size_t)M * d->v_hidden * 3 * 2, 256);       // qkv
+    b += align_up((size_t)M * (d->v_inter > patch_kp(d) ? d->v_inter : patch_kp(d)) * 2, 256);  // mlp / patch rows
+    b += align_up((size_t)d->v_hidden * patch_kp(d) * 2, 256);  // padded patch weight
+    return b + 256;
+}
+
+extern "C" int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
+                                 int64_t n_clips, int64_t frames, void *image_embeds, void *pooler, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (!d || !w || !pixels || !image_embeds || !workspace || n_clips <= 0 || frames <= 0) return EILEV_E_BADARG;
+    if (!dims_ok_vit(d)) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_vit_workspace_bytes(d, n_clips, frames)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->v_hidden, Fi = d->v_inter, H = d->v_heads, hd = D / H;
+    const int64_t tok = vit_tok(d), G2 = tok - 1, F = n_clips * frames, M = F * tok;
+    if (M > 0x7fffffff / 2) return EILEV_E_UNSUPPORTED;
+    const int KP = patch_kp(d), PK = 3 * d->patch_size * d->patch_size;
+    Carver cv{(char *)workspace, (char *)workspace + workspace_bytes};
+    bf16 *x = cv.take<bf16>((size_t)M * D), *ln = cv.take<bf16>((size_t)M * D), *att = cv.take<bf16>((size_t)M * D);
+    bf16 *qkv = cv.take<bf16>((size_t)M * 3 * D);
+    bf16 *mlp = cv.take<bf16>((size_t)M * (Fi > KP ? Fi : KP));
+    bf16 *wpad = cv.take<bf16>((size_t)D * KP);
+    if (!cv.ok()) return EILEV_E_WORKSPACE;
+
+    // patch embedding (+ bias + position, CLS rows): hf modeling_blip_2.py:243-255
+    RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
+    RC(launch_pad_rows((const bf16 *)w->patch_w, wpad, D, PK, KP, s));
+    {
+        GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
+        g.patch_group = (int)G2;
+        RC(launch_gemm(g, 5, s));
+    }
+    RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
+
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < d->v_layers; ++l) {
+        const EilevVitLayer *L = &w->layers[l];
+        RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
+        RC(launch_gemm(mk_gemm(ln, D, L->qkv_w, D, L->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0), 3, s));
+        AttnArgs a;
+        a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.o = att;
+        a.q_bs = a.k_bs = a.v_bs = tok * 3 * (int64_t)D; a.o_bs = tok * (int64_t)D;
+        a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+        a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+        a.batch = (int)F; a.heads = H; a.sq = (int)tok; a.skv = (int)tok; a.hd = hd; a.scale = scale; a.causal = 0;
+        a.key_mask = nullptr; a.mask_ld = 0;
+        RC(launch_attention(a, s));
+        RC(launch_gemm(mk_gemm(att, D, L->proj_w, D, L->proj_b, x, D, x, D, M, D, D, 0), 4, s));
+        RC(launch_layernorm(x, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, ln, D, M, D, d->v_eps, s));
+        RC(launch_gemm(mk_gemm(ln, D, L->fc1_w, D, L->fc1_b, nullptr, 0, mlp, Fi, M, Fi, D, 1), 1, s));
+        RC(launch_gemm(mk_gemm(mlp, Fi, L->fc2_w, Fi, L->fc2_b, x, D, x, D, M, D, Fi, 0), 2, s));
+    }
+    RC(launch_layernorm(x, D, (const bf16 *)w->post_ln_w, (const bf16 *)w->post_ln_b, (bf16 *)image_embeds, D, M, D, d->v_eps, s));
+    if (pooler)
+        RC(launch_layernorm((const bf16 *)image_embeds, tok * D, (const bf16 *)w->post_ln_w, (const bf16 *)w->post_ln_b,
+                            (bf16 *)pooler, D, F, D, d->v_eps, s));
+    return EILEV_OK;
+}
+
+// =====================================================================================================
+// Stage 2: Q-Former
+// =====================================================================================================
+extern "C" size_t eilev_qformer_workspace_bytes(const EilevDims *d, int64_t n_clips, int64_t kv_len) {
+    const int64_t R = n_clips * d->num_query;
+    size_t b = 0;
+    b += align_up((size_t)R * d->q_hidden * 2, 256) * 3;          // h, a, t
+    b += align_up((size_t)R * d->q_hidden * 3 * 2, 256);           // qkv
+    b += align_up((size_t)R * d->q_inter * 2, 256);                // f
+    b += align_up((size_t)n_clips * kv_len * d->q_hidden * 2 * 2, 256);  // cross k|v
+    b += align_up((size_t)d->num_query * d->q_hidden * 2, 256);    // normed query tokens
+    return b + 256;
+}
+
+extern "C" int eilev_qformer_forward(const EilevDims *d, const EilevQfWeights *w, const void *image_embeds, int64_t n_clips,
+                                     int64_t kv_len, void *query_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !image_embeds || !query_out || !workspace || n_clips <= 0 || kv_len <= 0) return EILEV_E_BADARG;
+    if (!dims_ok_qf(d) || d->v_hidden % 8) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_qformer_workspace_bytes(d, n_clips, kv_len)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->q_hidden, Fi = d->q_inter, nq = d->num_query, H = d->q_heads, hd = D / H, Dv = d->v_hidden;
+    const int64_t R = n_clips * nq, MK = n_clips * kv_len;
+    Carver cv{(char *)workspace, (char *)workspace + workspace_bytes};
+    bf16 *h = cv.take<bf16>((size_t)R * D), *a_ = cv.take<bf16>((size_t)R * D), *t = cv.take<bf16>((size_t)R * D);
+    bf16 *qkv = cv.take<bf16>((size_t)R * 3 * D), *f = cv.take<bf16>((size_t)R * Fi);
+    bf16 *ckv = cv.take<bf16>((size_t)MK * 2 * D), *q0 = cv.take<bf16>((size_t)nq * D);
+    if (!cv.ok()) return EILEV_E_WORKSPACE;
+    const bf16 *img = (const bf16 *)image_embeds;
+    const float scale = 1.0f / sqrtf((float)hd);
+
+    // embedding_output = layernorm(query_tokens), same for every clip (hf :913)
+    RC(launch_layernorm((const bf16 *)w->query_tokens, D, (const bf16 *)w->ln_w, (const bf16 *)w->ln_b, q0, D, nq, D, d->q_eps, s));
+    RC(launch_broadcast_rows(q0, h, n_clips, (int64_t)nq * D, s));
+
+    for (int l = 0; l < d->q_layers; ++l) {
+        const EilevQfLayer *L = &w->layers[l];
+        // self-attention q|k|v: one GEMM when the three weights are packed contiguously
+        const bf16 *sq = (const bf16 *)L->sq_w;
+        const bool fused = (const bf16 *)L->sk_w == sq + (size_t)D * D && (const bf16 *)L->sv_w == sq + 2 * (size_t)D * D &&
+                           (const bf16 *)L->sk_b == (const bf16 *)L->sq_b + D && (const bf16 *)L->sv_b == (const bf16 *)L->sq_b + 2 * D;
+        if (fused) {
+            RC(launch_gemm(mk_gemm(h, D, L->sq_w, D, L->sq_b, nullptr, 0, qkv, 3 * D, R, 3 * D, D, 0), 5, s));
+        } else {
+            RC(launch_gemm(mk_gemm(h, D, L->sq_w, D, L->sq_b, nullptr, 0, qkv, 3 * D, R, D, D, 0), 5, s));
+            RC(launch_gemm(mk_gemm(h, D, L->sk_w, D, L->sk_b, nullptr, 0, qkv + D, 3 * D, R, D, D, 0), 5, s));
+            RC(launch_gemm(mk_gemm(h, D, L->sv_w, D, L->sv_b, nullptr, 0, qkv + 2 * D, 3 * D, R, D, D, 0), 5, s));
+        }
+        AttnArgs a;
+        a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.o = a_;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)nq * 3 * D; a.o_bs = (int64_t)nq * D;
+        a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+        a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+        a.batch = (int)n_clips; a.heads = H; a.sq = nq; a.skv = nq; a.hd = hd; a.scale = scale; a.causal = 0;
+        a.key_mask = nullptr; a.mask_ld = 0;
+        RC(launch_attention(a, s));
+        RC(launch_gemm(mk_gemm(a_, D, L->so_w, D, L->so_b, h, D, t, D, R, D, D, 0), 5, s));
+        RC(launch_layernorm(t, D, (const bf16 *)L->sln_w, (const bf16 *)L->sln_b, h, D, R, D, d->q_eps, s));
+        if (L->cq_w) {
+            RC(launch_gemm(mk_gemm(h, D, L->cq_w, D, L->cq_b, nullptr, 0, qkv, 3 * D, R, D, D, 0), 5, s));
+            const bf16 *ck = (const bf16 *)L->ck_w;
+            const bool kvf = (const bf16 *)L->cv_w == ck + (size_t)D * Dv && (const bf16 *)L->cv_b == (const bf16 *)L->ck_b + D;
+            if (kvf) {
+                RC(launch_gemm(mk_gemm(img, Dv, L->ck_w, Dv, L->ck_b, nullptr, 0, ckv, 2 * D, MK, 2 * D, Dv, 0), 5, s));
+            } else {
+                RC(launch_gemm(mk_gemm(img, Dv, L->ck_w, Dv, L->ck_b, nullptr, 0, ckv, 2 * D, MK, D, Dv, 0), 5, s));
+                RC(launch_gemm(mk_gemm(img, Dv, L->cv_w, Dv, L->cv_b, nullptr, 0, ckv + D, 2 * D, MK, D, Dv, 0), 5, s));
+            }
+            AttnArgs c;
+            c.q = qkv; c.k = ckv; c.v = ckv + D; c.o = a_;
+            c.q_bs = (int64_t)nq * 3 * D; c.k_bs = c.v_bs = kv_len * 2 * (int64_t)D; c.o_bs = (int64_t)nq * D;
+            c.q_hs = c.k_hs = c.v_hs = c.o_hs = hd;
+            c.ldq = 3 * D; c.ldk = c.ldv = 2 * D; c.ldo = D;
+            c.batch = (int)n_clips; c.heads = H; c.sq = nq; c.skv = (int)kv_len; c.hd = hd; c.scale = scale; c.causal = 0;
+            c.key_mask = nullptr; c.mask_ld = 0;
+            RC(launch_attention(c, s));
+            RC(launch_gemm(mk_gemm(a_, D, L->co_w, D, L->co_b, h, D, t, D, R, D, D, 0), 5, s));
+            RC(launch_layernorm(t, D, (const bf16 *)L->cln_w, (const bf16 *)L->cln_b, h, D, R, D, d->q_eps, s));
+        }
+        RC(launch_gemm(mk_gemm(h, D, L->fi_w, D, L->fi_b, nullptr, 0, f, Fi, R, Fi, D, 1), 5, s));
+        RC(launch_gemm(mk_gemm(f, Fi, L->fo_w, Fi, L->fo_b, h, D, t, D, R, D, Fi, 0), 5, s));
+        RC(launch_layernorm(t, D, (const bf16 *)L->fln_w, (const bf16 *)L->fln_b,
+                            l == d->q_layers - 1 ? (bf16 *)query_out : h, D, R, D, d->q_eps, s));
+    }
+    return EILEV_OK;
+}
+
+// =====================================================================================================
+// Stage 3: projection, embedding, scatter
+// =====================================================================================================
+extern "C" int eilev_project_rows(const EilevDims *d, const void *proj_w, const void *proj_b, const void *query_out,
+                                  int64_t n_rows, void *video_feats, void *stream) {
+    if (!d || !proj_w || !query_out || !video_feats) return EILEV_E_BADARG;
+    return launch_gemm(mk_gemm((const bf16 *)query_out, d->q_hidden, proj_w, d->q_hidden, proj_b, nullptr, 0, video_feats,
+                               d->t_hidden, n_rows, d->t_hidden, d->q_hidden, 0), 5, (hipStream_t)stream);
+}
+
+extern "C" int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens, const int64_t *input_ids,
+                                   const uint8_t *video_mask, const void *video_feats, int64_t n_rows, int64_t batch,
+                                   int64_t seq_len, void *inputs_embeds, void *stream) {
+    if (!d || !embed_tokens || !input_ids || !inputs_embeds || batch <= 0 || seq_len <= 0) return EILEV_E_BADARG;
+    if (d->t_hidden % 8) return EILEV_E_UNSUPPORTED;
+    // (the count of set mask bits == n_rows contract is validated by the host wrapper; the kernel only
+    //  guards against out-of-range ranks)
+    return launch_embed_scatter((const bf16 *)embed_tokens, input_ids, video_mask, (const bf16 *)video_feats, n_rows,
+                                batch * seq_len, d->vocab, (bf16 *)inputs_embeds, d->t_hidden, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+// Stage 4/5: OPT
+// =====================================================================================================
+extern "C" size_t eilev_opt_workspace_bytes(const EilevDims *d, int64_t batch, int64_t seq_len) {
+    const int64_t M = batch * (seq_len > 1 ? seq_len : 1);
+    size_t b = 0;
+    b += align_up((size_t)M * d->t_hidden * 2, 256) * 3;       // h, x, att
+    b += align_up((size_t)M * d->t_hidden * 3 * 2, 256);        // qkv
+    b += align_up((size_t)M * d->t_ffn * 2, 256);               // ffn
+    b += align_up((size_t)M * 4, 256);                          // position ids
+    b += kSkinnyScratch;
+    return b + 256;
+}
+
+extern "C" size_t eilev_opt_kv_cache_bytes(const EilevDims *d, int64_t batch, int64_t kv_capacity) {
+    return (size_t)d->t_layers * 2 * batch * kv_capacity * d->t_hidden * 2;
+}
+
+namespace {
+
+struct OptBufs {
+    bf16 *h, *x, *att, *qkv, *ffn;
+    int32_t *pid;
+    float *scratch;
+};
+
+bool carve_opt(const EilevDims *d, int64_t M, void *ws, size_t bytes, OptBufs &b) {
+    Carver cv{(char *)ws, (char *)ws + bytes};
+    b.h = cv.take<bf16>((size_t)M * d->t_hidden);
+    b.x = cv.take<bf16>((size_t)M * d->t_hidden);
+    b.att = cv.take<bf16>((size_t)M * d->t_hidden);
+    b.qkv = cv.take<bf16>((size_t)M * 3 * d->t_hidden);
+    b.ffn = cv.take<bf16>((size_t)M * d->t_ffn);
+    b.pid = cv.take<int32_t>((size_t)M);
+    b.scratch = cv.take<float>(kSkinnyScratch / sizeof(float));
+    return cv.ok();
+}
+
+// q|k|v projection of x into b.qkv (q pre-scaled by head_dim^-0.5, hf modeling_opt.py:151)
+int opt_qkv(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_t M, hipStream_t s) {
+    const int D = d->t_hidden;
+    const float scaling = 1.0f / sqrtf((float)(D / d->t_heads));
+    const bf16 *qw = (const bf16 *)L->q_w;
+    const bool fused = (const bf16 *)L->k_w == qw + (size_t)D * D && (const bf16 *)L->v_w == qw + 2 * (size_t)D * D &&
+                       (const bf16 *)L->k_b == (const bf16 *)L->q_b + D && (const bf16 *)L->v_b == (const bf16 *)L->q_b + 2 * D;
+    if (fused) {
+        GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
+        g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+        return launch_gemm(g, 5, s);
+    }
+    GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, D, D, 0);
+    g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    RC(launch_gemm(g, 5, s));
+    g = mk_gemm(b.x, D, L->k_w, D, L->k_b, nullptr, 0, b.qkv + D, 3 * D, M, D, D, 0);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    RC(launch_gemm(g, 5, s));
+    g = mk_gemm(b.x, D, L->v_w, D, L->v_b, nullptr, 0, b.qkv + 2 * D, 3 * D, M, D, D, 0);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    return launch_gemm(g, 5, s);
+}
+
+// out_proj + residual, LN, fc1 + ReLU, fc2 + residual (hf modeling_opt.py:178-179, 226-247)
+int opt_tail(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_t M, hipStream_t s) {
+    const int D = d->t_hidden, Ft = d->t_ffn;
+    GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    RC(launch_gemm(g, 5, s));
+    RC(launch_layernorm(b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, b.x, D, M, D, d->t_eps, s));
+    g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    RC(launch_gemm(g, 5, s));
+    g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    return launch_gemm(g, 5, s);
+}
+
+}  // namespace
+
+extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
+                                 const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
+                                 float *logits_last, float *logits_all, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !inputs_embeds || !attn_mask || !kv_cache || !workspace || batch <= 0 || seq_len <= 0) return EILEV_E_BADARG;
+    if (seq_len > kv_capacity || seq_len > d->max_pos) return EILEV_E_BADARG;
+    if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_opt_workspace_bytes(d, batch, seq_len)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->t_hidden, H = d->t_heads, hd = D / H;
+    const int64_t M = batch * seq_len;
+    OptBufs b;
+    if (!carve_opt(d, M, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    RC(launch_pos_embed((const bf16 *)inputs_embeds, (const bf16 *)w->embed_positions, attn_mask, b.pid, b.h, (int)batch,
+                        (int)seq_len, D, s));
+    const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    for (int l = 0; l < d->t_layers; ++l) {
+        const EilevOptLayer *L = &w->layers[l];
+        bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+        RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, M, D, d->t_eps, s));
+        RC(opt_qkv(d, L, b, M, s));
+        RC(launch_kv_write(b.qkv, kc, vc, (int)batch, (int)seq_len, H, hd, (int)kv_capacity, (int)seq_len, nullptr, s));
+        AttnArgs a;
+        a.q = b.qkv; a.k = b.qkv + D; a.v = b.qkv + 2 * D; a.o = b.att;
+        a.q_bs = a.k_bs = a.v_bs = seq_len * 3 * (int64_t)D; a.o_bs = seq_len * (int64_t)D;
+        a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+        a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+        a.batch = (int)batch; a.heads = H; a.sq = (int)seq_len; a.skv = (int)seq_len; a.hd = hd; a.scale = 1.0f; a.causal = 1;
+        a.key_mask = attn_mask; a.mask_ld = seq_len;
+        RC(launch_attention(a, s));
+        RC(opt_tail(d, L, b, M, s));
+    }
+    RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, M, D, d->t_eps, s));
+    if (logits_all) {
+        GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits_all, d->vocab, M, d->vocab, D, 0);
+        g.out_f32 = 1;
+        RC(launch_gemm(g, 5, s));
+    }
+    if (logits_last) {
+        // last position of every row: a strided [batch, D] view of x
+        GemmArgs g = mk_gemm(b.x + (seq_len - 1) * (int64_t)D, seq_len * (int64_t)D, w->embed_tokens, D, nullptr, nullptr, 0,
+                             logits_last, d->vocab, batch, d->vocab, D, 0);
+        g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+        RC(launch_gemm(g, 5, s));
+    }
+    return EILEV_OK;
+}
+
+extern "C" int eilev_greedy_select(const float *logits, int64_t batch, int64_t vocab, int32_t *state, uint8_t *finished,
+                                   int64_t eos_id, int64_t pad_id, int64_t *tokens, int64_t *out_tokens, int64_t max_new,
+                                   void *stream) {
+    if (!logits || !state || !finished || !tokens || !out_tokens || batch <= 0) return EILEV_E_BADARG;
+    return launch_select(logits, (int)batch, (int)vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new,
+                         (hipStream_t)stream);
+}
+
+extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *w, int64_t *tokens, int32_t *state,
+                                     const int32_t *attn_mask, const int32_t *n_valid, int64_t batch, int64_t seq_len,
+                                     void *kv_cache, int64_t kv_capacity, float *logits, uint8_t *finished, int64_t eos_id,
+                                     int64_t pad_id, int64_t *out_tokens, int64_t max_new, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!d || !w || !tokens || !state || !attn_mask || !n_valid || !kv_cache || !logits || !finished || !out_tokens || !workspace)
+        return EILEV_E_BADARG;
+    if (batch <= 0 || batch > 16 || seq_len + max_new > kv_capacity + 1) return EILEV_E_BADARG;
+    if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_opt_workspace_bytes(d, batch, 1)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->t_hidden, H = d->t_heads, hd = D / H;
+    OptBufs b;
+    if (!carve_opt(d, batch, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab,
+                           d->max_pos + 1, b.h, (int)batch, D, s));
+    const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    for (int l = 0; l < d->t_layers; ++l) {
+        const EilevOptLayer *L = &w->layers[l];
+        bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+        RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
+        RC(opt_qkv(d, L, b, batch, s));
+        RC(launch_kv_write(b.qkv, kc, vc, (int)batch, 1, H, hd, (int)kv_capacity, (int)seq_len, state, s));
+        RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd, s));
+        RC(opt_tail(d, L, b, batch, s));
+    }
+    RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, batch, D, d->t_eps, s));
+    GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
+    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    RC(launch_gemm(g, 5, s));
+    return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
+}
+
+// =====================================================================================================
+// Building blocks (unit parity tests, roofline probe)
+// =====================================================================================================
+extern "C" int eilev_linear(const void *a, const void *w, const void *bias, const void *residual, void *c, int64_t m,
+                            int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
+    if (!a || !w || !c || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;
+    GemmArgs g = mk_gemm((const bf16 *)a, k, w, k, bias, (const bf16 *)residual, n, c, n, m, (int)n, (int)k, epilogue);
+    g.out_f32 = out_f32;
+    return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
+extern "C" int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y, int64_t rows, int64_t cols,
+                               float eps, void *stream) {
+    return launch_layernorm((const bf16 *)x, cols, (const bf16 *)gamma, (const bf16 *)beta, (bf16 *)y, cols, rows, (int)cols,
+                            eps, (hipStream_t)stream);
+}
+
+extern "C" int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq,
+                               int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal,
+                               const int32_t *key_mask, void *stream) {
+    AttnArgs a;
+    a.q = (const bf16 *)q; a.k = (const bf16 *)k; a.v = (const bf16 *)v; a.o = (bf16 *)o;
+    a.q_bs = sq * ldq; a.k_bs = skv * ldk; a.v_bs = skv * ldv; a.o_bs = sq * heads * head_dim;
+    a.q_hs = a.k_hs = a.v_hs = a.o_hs = head_dim;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = heads * head_dim;
+    a.batch = (int)batch; a.heads = (int)heads; a.sq = (int)sq; a.skv = (int)skv; a.hd = (int)head_dim; a.scale = scale;
+    a.causal = causal; a.key_mask = key_mask; a.mask_ld = skv;
+    return launch_attention(a, (hipStream_t)stream);
+}

@@ -1,0 +1,246 @@
+"""Host-side driver of the HIP library: owns bf16 device weights, workspaces and the decode graph.
+
+PyTorch is plumbing here (device memory, the current HIP stream, graph capture); every FLOP of the
+path is executed by ``libeilev_hip.so`` through the C ABI of include/eilev.h.  There is no fallback:
+constructing an engine without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import abi
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipEngine:
+    """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
+
+    def __init__(self, config, named_tensors: dict, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = abi.load_hip()
+        self.config = config
+        self.dims = abi.dims_from_config(config)
+        self.device = torch.device(device) if device is not None else next(iter(named_tensors.values())).device
+        if self.device.type != "cuda":
+            raise RuntimeError(f"HipEngine weights must live on the GPU, got {self.device}")
+        self._keep = {}
+        self._ws = {}
+        self._load(named_tensors)
+        self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def _load(self, named):
+        d = self.dims
+        bf = lambda t: t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        store = {}
+
+        def pack(keys):
+            """Concatenate tensors along dim 0 into one buffer; return per-key views (contiguous in memory)."""
+            parts = [bf(named[k]) for k in keys]
+            flat = torch.cat([p.reshape(-1) for p in parts])
+            off = 0
+            for k, p in zip(keys, parts):
+                store[k] = flat[off: off + p.numel()].view(p.shape)
+                off += p.numel()
+
+        for i in range(d.t_layers):
+            p = abi.OPT_PREFIX.format(i) + "self_attn."
+            pack([p + "q_proj.weight", p + "k_proj.weight", p + "v_proj.weight"])
+            pack([p + "q_proj.bias", p + "k_proj.bias", p + "v_proj.bias"])
+        for i in range(d.q_layers):
+            p = abi.QF_PREFIX.format(i)
+            pack([p + f"attention.attention.{n}.weight" for n in ("query", "key", "value")])
+            pack([p + f"attention.attention.{n}.bias" for n in ("query", "key", "value")])
+            if i % d.q_cross_freq == 0:
+                pack([p + f"crossattention.attention.{n}.weight" for n in ("key", "value")])
+                pack([p + f"crossattention.attention.{n}.bias" for n in ("key", "value")])
+
+        def addr(key):
+            if key not in store:
+                store[key] = bf(named[key])
+            return store[key].data_ptr()
+
+        self.pack = abi.WeightPack(d, addr)
+        self._keep = store
+
+    # ---- workspaces ----------------------------------------------------------------------------------
+    def _workspace(self, tag, nbytes):
+        cur = self._ws.get(tag)
+        if cur is None or cur.numel() < nbytes:
+            self._ws[tag] = cur = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return cur
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- stages --------------------------------------------------------------------------------------
+    def vit(self, pixel_values: torch.Tensor, want_pooler: bool = False, max_frames_per_call: int = 136):
+        """(N, 3, T, H, W) fp32/bf16 -> (N, T*tokens, Dv) bf16 [ref:eilev/model/v2.py:24-103]."""
+        if pixel_values is None:
+            raise ValueError("You have to specify pixel_values")
+        d = self.dims
+        px = pixel_values.to(self.device)
+        if px.dtype not in (torch.float32, torch.bfloat16):
+            px = px.float()
+        px = px.contiguous()
+        N, ch, T, Hh, Ww = px.shape
+        if ch != 3 or Hh != d.image_size or Ww != d.image_size:
+            raise ValueError(f"pixel_values must be (N, 3, T, {d.image_size}, {d.image_size}), got {tuple(px.shape)}")
+        out = torch.empty((N, T * self.tokens_per_frame, d.v_hidden), dtype=torch.bfloat16, device=self.device)
+        pool = torch.empty((N, T, d.v_hidden), dtype=torch.bfloat16, device=self.device) if want_pooler else None
+        step = max(1, max_frames_per_call // T)
+        dt = abi_dtype(px)
+        for n0 in range(0, N, step):
+            n1 = min(N, n0 + step)
+            nb = self.lib.eilev_vit_workspace_bytes(C.byref(d), n1 - n0, T)
+            ws = self._workspace("vit", nb)
+            abi.check(self.lib.eilev_vit_forward(C.byref(d), C.byref(self.pack.vit), _ptr(px[n0:n1]), dt, n1 - n0, T,
+                                                 _ptr(out[n0:n1]), _ptr(pool[n0:n1]) if want_pooler else None,
+                                                 _ptr(ws), ws.numel(), self._stream()), "eilev_vit_forward")
+        return (out, pool) if want_pooler else out
+
+    def qformer(self, image_embeds: torch.Tensor):
+        d = self.dims
+        img = image_embeds.contiguous()
+        assert img.dtype == torch.bfloat16
+        N, kv = img.shape[:2]
+        out = torch.empty((N, d.num_query, d.q_hidden), dtype=torch.bfloat16, device=self.device)
+        nb = self.lib.eilev_qformer_workspace_bytes(C.byref(d), N, kv)
+        ws = self._workspace("qf", nb)
+        abi.check(self.lib.eilev_qformer_forward(C.byref(d), C.byref(self.pack.qf), _ptr(img), N, kv, _ptr(out), _ptr(ws),
+                                                 ws.numel(), self._stream()), "eilev_qformer_forward")
+        return out
+
+    def project(self, query_out: torch.Tensor):
+        d = self.dims
+        q = query_out.reshape(-1, d.q_hidden).contiguous()
+        out = torch.empty((q.shape[0], d.t_hidden), dtype=torch.bfloat16, device=self.device)
+        abi.check(self.lib.eilev_project_rows(C.byref(d), self.pack.proj_w, self.pack.proj_b, _ptr(q), q.shape[0], _ptr(out),
+                                              self._stream()), "eilev_project_rows")
+        return out
+
+    def encode_clips(self, pixel_values):
+        """pixels -> projected query tokens (N*num_query, Dt): ViT + Q-Former + language_projection."""
+        return self.project(self.qformer(self.vit(pixel_values)))
+
+    def embed_scatter(self, input_ids, video_mask, video_feats):
+        d = self.dims
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        B, L = ids.shape
+        vm = None
+        n_rows = 0
+        if video_mask is not None and video_feats is not None:
+            vm = (video_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+            n_rows = int(video_feats.shape[0])
+            n_set = int(vm.sum().item())
+            if n_set != n_rows:  # same contract as torch's boolean index_put (ref:eilev/model/v2.py:316)
+                raise RuntimeError(f"shape mismatch: video_input_mask selects {n_set} positions but there are {n_rows} video feature rows")
+            video_feats = video_feats.contiguous()
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= d.vocab):
+            raise IndexError("input_ids out of range")
+        out = torch.empty((B, L, d.t_hidden), dtype=torch.bfloat16, device=self.device)
+        abi.check(self.lib.eilev_embed_scatter(C.byref(d), self.pack.opt.embed_tokens, _ptr(ids), _ptr(vm),
+                                               _ptr(video_feats) if vm is not None else None, n_rows, B, L, _ptr(out),
+                                               self._stream()), "eilev_embed_scatter")
+        return out
+
+    def new_kv_cache(self, batch, capacity):
+        nb = self.lib.eilev_opt_kv_cache_bytes(C.byref(self.dims), batch, capacity)
+        return torch.zeros(int(nb), dtype=torch.uint8, device=self.device)
+
+    def prefill(self, inputs_embeds, attention_mask, kv_cache=None, kv_capacity=None, all_logits=False, last_logits=True):
+        d = self.dims
+        x = inputs_embeds.contiguous()
+        B, L, _ = x.shape
+        cap = int(kv_capacity or L)
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        if kv_cache is None:
+            kv_cache = self.new_kv_cache(B, cap)
+        last = torch.empty((B, d.vocab), dtype=torch.float32, device=self.device) if last_logits else None
+        alll = torch.empty((B, L, d.vocab), dtype=torch.float32, device=self.device) if all_logits else None
+        nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, L)
+        ws = self._workspace("opt", nb)
+        abi.check(self.lib.eilev_opt_prefill(C.byref(d), C.byref(self.pack.opt), _ptr(x), _ptr(am), B, L, _ptr(kv_cache), cap,
+                                             _ptr(last), _ptr(alll), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_prefill")
+        return last, alll, kv_cache
+
+    def greedy_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, use_graph=True,
+                      poll_every=8, return_step_logits=False):
+        """Prefill + KV-cached greedy decode [ref:eilev/model/v2.py:318-322 -> hf generation/utils.py:2783-2941].
+
+        Returns int64 (B, n_steps) of NEW tokens only (OPT path)."""
+        d = self.dims
+        B, L, _ = inputs_embeds.shape
+        if max_new_tokens <= 0:
+            return torch.empty((B, 0), dtype=torch.int64, device=self.device)
+        if B > 16:
+            raise NotImplementedError("decode batch > 16 per call is not supported yet; split the batch")
+        cap = L + max_new_tokens
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        last, _, kv = self.prefill(inputs_embeds, am, kv_capacity=cap)
+        state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        finished = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        tokens = torch.zeros(B, dtype=torch.int64, device=self.device)
+        out = torch.full((B, max_new_tokens), int(pad_id), dtype=torch.int64, device=self.device)
+        n_valid = am.sum(dim=1).to(torch.int32).contiguous()
+        logits = torch.empty((B, d.vocab), dtype=torch.float32, device=self.device)
+        step_logits = [last.clone()] if return_step_logits else None
+        abi.check(self.lib.eilev_greedy_select(_ptr(last), B, d.vocab, _ptr(state), _ptr(finished), eos_id, pad_id,
+                                               _ptr(tokens), _ptr(out), max_new_tokens, self._stream()), "eilev_greedy_select")
+        nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, 1)
+        ws = self._workspace("dec", nb)
+
+        def one_step():
+            abi.check(self.lib.eilev_opt_decode_step(
+                C.byref(d), C.byref(self.pack.opt), _ptr(tokens), _ptr(state), _ptr(am), _ptr(n_valid), B, L, _ptr(kv), cap,
+                _ptr(logits), _ptr(finished), eos_id, pad_id, _ptr(out), max_new_tokens, _ptr(ws), ws.numel(),
+                self._stream()), "eilev_opt_decode_step")
+
+        n_dec = max_new_tokens - 1
+        graph = None
+        if use_graph and n_dec > 1 and not return_step_logits:
+            # every per-step quantity is read from `state` on the device, so ONE captured step replays for all
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                snap = (state.clone(), finished.clone(), tokens.clone(), out.clone())
+                one_step()  # warm-up outside capture (lazy module loading), then restore the state it consumed
+                state.copy_(snap[0]); finished.copy_(snap[1]); tokens.copy_(snap[2]); out.copy_(snap[3])
+                # the warm-up wrote KV slot L (state said step 1): the captured replay rewrites the same slot
+                with torch.cuda.graph(graph, stream=side):
+                    one_step()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            # capture does not execute: nothing ran yet for step 1
+        done_steps = 0
+        while done_steps < n_dec:
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
+                if return_step_logits:
+                    step_logits.append(logits.clone())
+            done_steps += 1
+            if eos_id >= 0 and (done_steps % poll_every == 0) and int(state[1].item()) == 0:
+                break
+        ids = out
+        if eos_id >= 0:
+            # HF stops as soon as every row has emitted EOS: trim to that length
+            is_eos = ids == eos_id
+            first = torch.where(is_eos.any(dim=1), is_eos.float().argmax(dim=1) + 1,
+                                torch.full((B,), max_new_tokens, device=self.device))
+            n = int(first.max().item())
+            ids = ids[:, :n]
+        else:
+            ids = ids[:, : 1 + done_steps]
+        return (ids, step_logits) if return_step_logits else ids
+
+
+def abi_dtype(t: torch.Tensor) -> int:
+    return 0 if t.dtype == torch.float32 else 1

@@ -1,0 +1,151 @@
+"""-m gpu: unit parity of the HIP building blocks (through the C ABI) against the CPU oracle.
+
+Inputs are bf16-exact; the oracle computes in fp32.  Tolerances are bf16 output rounding (2^-9 relative)
+plus fp32 accumulation-order noise: |err| <= 1e-2 * max|ref| for GEMM/attention outputs stored in bf16,
+<= 2e-5 * K-scaled for fp32 logits-style outputs.  Every shape uses ASYMMETRIC random operands so a
+transposed fragment mapping cannot pass.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from eilev_amd import abi
+from eilev_amd.synth import det_normal, round_bf16
+from oracle import runner as orc
+
+from hip_utils import P, dev_bf16, host, stream_ptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return abi.load_hip()
+
+
+def _lin_case(hip, m, n, k, epi, bias, resid, out_f32=False, seed=0):
+    a = round_bf16(det_normal(f"A{m}x{k}", (m, k), seed))
+    w = round_bf16(det_normal(f"W{n}x{k}", (n, k), seed) / np.sqrt(k))
+    b = round_bf16(0.5 * det_normal("b", (n,), seed)) if bias else None
+    r = round_bf16(det_normal("r", (m, n), seed)) if resid else None
+    ref = np.empty((m, n), np.float32)
+    pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_linear(pp(a), pp(w), pp(b), pp(r), pp(ref), m, n, k, epi, 0, None) == 0
+    da, dw = dev_bf16(a), dev_bf16(w)
+    db = dev_bf16(b) if bias else None
+    dr = dev_bf16(r) if resid else None
+    out = torch.empty((m, n), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    rc = hip.eilev_linear(P(da), P(dw), P(db), P(dr), P(out), m, n, k, epi, int(out_f32), stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = host(out)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    tol = (2e-4 if out_f32 else 1e-2) * scale
+    assert err <= tol, (m, n, k, epi, err, tol)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (257, 528, 176), (300, 200, 72), (1000, 1408, 1408), (4112, 768, 3072),
+                                   (513, 4224, 1408), (2056, 6144, 640)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_linear_tiled(hip, m, n, k, epi):
+    _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 160, 160), (8, 2560, 2560), (8, 7680, 2560), (3, 320, 160), (16, 1000, 10240), (8, 50272, 2560)])
+def test_linear_skinny(hip, m, n, k):
+    _lin_case(hip, m, n, k, 0, bias=True, resid=True)
+    _lin_case(hip, m, n, k, 2, bias=True, resid=False)
+
+
+def test_linear_f32_logits(hip):
+    _lin_case(hip, 300, 1000, 160, 0, bias=False, resid=False, out_f32=True)
+    _lin_case(hip, 4, 50272, 2560, 0, bias=False, resid=False, out_f32=True)
+
+
+def test_linear_rejects_unaligned_k(hip):
+    a = torch.zeros((32, 20), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((32, 20), dtype=torch.bfloat16, device="cuda")
+    o = torch.zeros((32, 32), dtype=torch.bfloat16, device="cuda")
+    assert hip.eilev_linear(P(a), P(w), None, None, P(o), 32, 32, 20, 0, 0, stream_ptr()) == abi_unsupported()
+
+
+def abi_unsupported():
+    return -2
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 128), (1000, 1408), (33, 2560), (5, 176), (64, 768), (3, 4096)])
+def test_layernorm(hip, rows, cols):
+    x = round_bf16(2.0 * det_normal("lnx", (rows, cols)) + 0.5)
+    g = round_bf16(1.0 + 0.1 * det_normal("lng", (cols,)))
+    b = round_bf16(0.1 * det_normal("lnb", (cols,)))
+    ref = np.empty_like(x)
+    pp = lambda v: v.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_layernorm(pp(x), pp(g), pp(b), pp(ref), rows, cols, 1e-5, None) == 0
+    dx, dg, db = dev_bf16(x), dev_bf16(g), dev_bf16(b)
+    out = torch.empty((rows, cols), dtype=torch.bfloat16, device="cuda")
+    assert hip.eilev_layernorm(P(dx), P(dg), P(db), P(out), rows, cols, 1e-5, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert np.abs(host(out) - ref).max() <= 1e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("batch,heads,sq,skv,hd,causal,masked", [
+    (3, 2, 17, 17, 88, 0, False),      # ViT mid config
+    (2, 16, 257, 257, 88, 0, False),   # ViT-g frame
+    (2, 12, 32, 32, 64, 0, False),     # Q-Former self
+    (2, 12, 32, 2056, 64, 0, False),   # Q-Former cross over 8 frames
+    (2, 4, 100, 100, 80, 1, True),     # OPT prefill, left padding
+    (1, 32, 200, 200, 80, 1, False),   # OPT-2.7B heads
+    (2, 2, 70, 130, 128, 1, True),     # causal with offset (sq < skv), d=128
+])
+def test_attention(hip, batch, heads, sq, skv, hd, causal, masked):
+    D = heads * hd
+    q = round_bf16(det_normal("q", (batch, sq, D)))
+    k = round_bf16(det_normal("k", (batch, skv, D)))
+    v = round_bf16(det_normal("v", (batch, skv, D)))
+    scale = 1.0 / np.sqrt(hd)
+    km = None
+    if masked:
+        km = np.ones((batch, skv), np.int32)
+        km[0, :5] = 0  # left padding on row 0
+        if batch > 1:
+            km[1, :1] = 0
+    ref = np.empty((batch, sq, D), np.float32)
+    pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_attention(pp(q), pp(k), pp(v), pp(ref), batch, heads, sq, skv, hd, D, D, D, scale, causal, pp(km), None) == 0
+    dq, dk, dv = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    dkm = torch.from_numpy(km).cuda() if masked else None
+    out = torch.empty((batch, sq, D), dtype=torch.bfloat16, device="cuda")
+    rc = hip.eilev_attention(P(dq), P(dk), P(dv), P(out), batch, heads, sq, skv, hd, D, D, D, scale, causal, P(dkm), stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = host(out)
+    # rows whose every key is masked are undefined in the reference (HF) and never read downstream
+    valid = np.ones((batch, sq), bool)
+    if masked and causal:
+        for b in range(batch):
+            first = int(np.argmax(km[b] != 0))
+            for i in range(sq):
+                if i + (skv - sq) < first:
+                    valid[b, i] = False
+    err = np.abs(got - ref)[valid].max()
+    assert err <= 2e-2 * np.abs(ref).max(), err
+
+
+def test_attention_online_softmax_rescale_branch(hip):
+    """One late key dominates (score jump >> 8 between tiles): exercises the alpha rescale of O and l."""
+    batch, heads, sq, skv, hd = 1, 1, 16, 200, 64
+    q = round_bf16(det_normal("q2", (batch, sq, hd)))
+    k = round_bf16(0.1 * det_normal("k2", (batch, skv, hd)))
+    v = round_bf16(det_normal("v2", (batch, skv, hd)))
+    k[0, 150] = round_bf16(8.0 * q[0, 3])  # spike: q_3 . k_150 is huge, in the third tile
+    ref = np.empty((batch, sq, hd), np.float32)
+    pp = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_attention(pp(q), pp(k), pp(v), pp(ref), 1, 1, sq, skv, hd, hd, hd, hd, 1.0, 0, None, None) == 0
+    dq, dk, dv = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    out = torch.empty((batch, sq, hd), dtype=torch.bfloat16, device="cuda")
+    assert hip.eilev_attention(P(dq), P(dk), P(dv), P(out), 1, 1, sq, skv, hd, hd, hd, hd, 1.0, 0, None, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert np.abs(host(out) - ref).max() <= 2e-2 * np.abs(ref).max()
