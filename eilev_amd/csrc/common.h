@@ -91,6 +91,7 @@ struct GemmArgs {
     float scale;        // columns [0, scale_cols) are multiplied by scale after the bias
     int scale_cols;
     int patch_group;    // > 0: patch-embedding row remap (see gemm.hip)
+    int dbg;            // probe-only
     float *scratch;     // optional fp32 scratch for the skinny kernel's split-K partials
     size_t scratch_bytes;
 };

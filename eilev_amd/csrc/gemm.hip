@@ -15,18 +15,146 @@
 // range split over the 8 waves (and over gridDim.y when N is small) — HBM-bound weight streaming.
 #include "common.h"
 
+int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
+extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
+
 namespace {
 
 constexpr int BK = 64;  // bf16 elements per K-step = one 128-byte LDS row
 
+// LDS swizzle: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7).  With it the 16 lanes
+// that one ds_read_b128 services together (MI355X_MICROARCH.md §LDS) always hit 16 distinct 16-byte
+// slots of the 256-byte bank row, for the 32-row fragment pattern of the 32x32x16 MFMA.
+__device__ __forceinline__ int swz(int row, int c) { return (c ^ ((row >> 1) & 7)) << 4; }
+
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[WM / 32][WN / 32], char *smem, int m0, int n0,
+                                              int wm, int wn, int wid, int lane) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RS = WN * 2 + 8;  // staging row stride (bytes)
+    const int l31 = lane & 31, hi = lane >> 5;
+    // ---- epilogue -------------------------------------------------------------------------------------
+    // (Every index into acc[][] must be a compile-time constant or the array is demoted to scratch.)
+    const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
+    if (g.out_f32) {
+        // fp32 output (logits): a lane's 4 consecutive n are one 16-byte store
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wrow0 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = wcol0 + j * 32 + q * 8 + hi * 4;
+                    if (row < g.M && col < g.N && !((g.dbg & 1) && row > 0)) {
+                        float *dst = reinterpret_cast<float *>(g.C) + (int64_t)row * g.ldc + col;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][j][q * 4 + e];
+                            if (g.bias) v += (float)g.bias[col + e];
+                            if (col + e < g.scale_cols) v *= g.scale;
+                            if (EPI == 1) v = gelu_erf(v);
+                            else if (EPI == 2) v = fmaxf(v, 0.0f);
+                            if (g.resid) v += (float)g.resid[(int64_t)row * g.ldr + col + e];
+                            if (col + e < g.N) dst[e] = v;
+                        }
+                    }
+                }
+        }
+        return;
+    }
+    // bf16 output: each wave stages its WM x WN sub-tile in a private LDS region (the K-loop stages are
+    // dead after the last barrier) so that HBM sees whole 128-byte row segments, 16 bytes per lane —
+    // 2-byte scattered stores from the MFMA layout cost as much as the K-loop itself.
+    // (a) residual rows -> LDS (coalesced); (b) acc + bias, activation, + residual -> bf16 in place;
+    // (c) rows -> HBM.  Only this wave touches its region: no workgroup barrier needed.
+    char *reg = smem + wid * (WM * RS);
+    const int srow = lane >> 3, schunk = lane & 7;  // row-major phases: 8 lanes per 128-byte row segment
+    const bool patch = g.patch_group > 0;
+    if (g.resid) {
+#pragma unroll 4
+        for (int it = 0; it < WM / 8; ++it) {
+            const int lr = it * 8 + srow, row = wrow0 + lr, col = wcol0 + schunk * 8;
+            bf16x8 v = zero8();
+            if (row < g.M && col < g.N) {
+                const int64_t rrow = patch ? 1 + (row % g.patch_group) : row;
+                v = *reinterpret_cast<const bf16x8 *>(g.resid + rrow * g.ldr + col);
+            }
+            bf16x4 *d = reinterpret_cast<bf16x4 *>(reg + lr * RS + schunk * 16);
+            d[0] = (bf16x4){v[0], v[1], v[2], v[3]};
+            d[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lc = j * 32 + q * 8 + hi * 4, col = wcol0 + lc;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f};
+            if (col < g.N) {
+                if (g.bias) {
+                    const bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(g.bias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[e] = (col + e) < g.scale_cols ? g.scale : 1.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16x4 *cell = reinterpret_cast<bf16x4 *>(reg + (i * 32 + l31) * RS + lc * 2);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (acc[i][j][q * 4 + e] + bv[e]) * sc[e];
+                    if (EPI == 1) v[e] = gelu_erf(v[e]);
+                    else if (EPI == 2) v[e] = fmaxf(v[e], 0.0f);
+                }
+                if (g.resid) {
+                    const bf16x4 r4 = *cell;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                }
+                *cell = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            }
+        }
+    }
+#pragma unroll 4
+    for (int it = 0; it < WM / 8; ++it) {
+        const int lr = it * 8 + srow, row = wrow0 + lr, col = wcol0 + schunk * 8;
+        if (row < g.M && col < g.N && !((g.dbg & 1) && row > 0)) {
+            const bf16x4 *sp = reinterpret_cast<const bf16x4 *>(reg + lr * RS + schunk * 16);
+            const bf16x4 lo = sp[0], hi4 = sp[1];
+            int64_t orow = row;
+            if (patch) {
+                // patch-embedding mode: GEMM row m = frame * group + patch; the output has one extra (CLS)
+                // row in front of every frame (and `resid` above was the position table [1 + group, N]).
+                const int f = row / g.patch_group;
+                orow = row + f + 1;
+            }
+            bf16 *dst = reinterpret_cast<bf16 *>(g.C) + orow * g.ldc + col;
+            if (col + 8 <= g.N) {
+                *reinterpret_cast<bf16x8 *>(dst) = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e < g.N) dst[e] = lo[e];
+                    if (col + 4 + e < g.N) dst[4 + e] = hi4[e];
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int NWM, int NWN, int EPI>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs g) {
-    constexpr int NT = 64 * NWM * NWN;
+    constexpr int NW = NWM * NWN, NT = 64 * NW;
     constexpr int WM = BM / NWM, WN = BN / NWN;
-    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int TM = WM / 32, TN = WN / 32;              // 32x32 MFMA tiles per wave
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-byte chunks per thread per K-step
     constexpr int STAGE = (BM + BN) * 128;                 // bytes per LDS stage
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for the workgroup");
+    static_assert(WN == 64, "the epilogue stores 128-byte row segments per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -44,7 +172,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / NWN, wn = wid % NWN;
-    const int l15 = lane & 15, lg = lane >> 4;
+    const int l31 = lane & 31, hi = lane >> 5;
 
     bf16x8 ra[A_CH], rb[B_CH];
     const int nk = (g.K + BK - 1) / BK;
@@ -72,88 +200,313 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
-            *reinterpret_cast<bf16x8 *>(sa + row * 128 + ((c ^ (row & 7)) << 4)) = ra[i];
+            *reinterpret_cast<bf16x8 *>(sa + row * 128 + swz(row, c)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
-            *reinterpret_cast<bf16x8 *>(sb + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
+            *reinterpret_cast<bf16x8 *>(sb + row * 128 + swz(row, c)) = rb[i];
         }
     };
 
-    f32x4 acc[TM][TN];
+    // acc[i][j][reg] = C[m = i*32 + (lane & 31)][n = j*32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)]
+    // (operands are swapped — MFMA rows are weight rows — so a lane owns runs of 4 consecutive n)
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     gload(0);
     swrite(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < ((g.dbg & 2) ? 1 : nk); ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);  // in flight while the MFMAs below run
         const char *sa = smem + cur * STAGE + (wm * WM) * 128;
         const char *sb = smem + cur * STAGE + BM * 128 + (wn * WN) * 128;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {  // 4 x (k = 16) per 64-wide K-step
             bf16x8 bfr[TN];
-            const int kc = ks * 4 + lg;
+            const int kc = ks * 2 + hi;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = j * 16 + l15;
-                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + ((kc ^ (row & 7)) << 4));
+                const int row = j * 32 + l31;
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row = i * 16 + l15;
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ((kc ^ (row & 7)) << 4));
+                const int row = i * 32 + l31;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) swrite(cur ^ 1);  // the other stage was last read before the previous barrier
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    // (Every index into acc[][] must be a compile-time constant or the array is demoted to scratch.)
-    const int ecol0 = n0 + wn * WN + l15, erow0 = m0 + wm * WM + lg * 4;
+    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
+}
+
+// ---- fast path: direct-to-LDS staging (K % 64 == 0) -------------------------------------------------
+// Same tile geometry, but the K-step tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA): no
+// staging VGPRs and no ds_write pass.  The DMA writes LDS linearly (wave-uniform base + lane * 16), so
+// the XOR swizzle is applied to the per-lane SOURCE address instead (lane p of an 8-row x 128-byte piece
+// fetches chunk (p & 7) ^ f(row)); fragment reads use the same involution.  Rows past M / N are clamped
+// to the last valid row (their products are never stored).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW>
+__global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr int NW = NWM * NWN;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PC = BM / 8 / NW, B_PC = BN / 8 / NW;  // 1-KiB pieces (8 rows) per wave per K-step
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(A_PC >= 1 && B_PC >= 1 && WN == 64, "unsupported geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm_i = bid / tiles_n, tn_i = bid % tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nk = g.K / BK;
+
+    // per-lane source pointers of this wave's pieces (advance by 64 elements per K-step)
+    const bf16 *pa[A_PC], *pb[B_PC];
+    const int prow = lane >> 3, pslot = lane & 7;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = ecol0 + j * 16;
-        const bool cok = col < g.N;
-        const int ccol = cok ? col : 0;
-        const float bv = g.bias ? (float)g.bias[ccol] : 0.0f;
-        const float sc = ccol < g.scale_cols ? g.scale : 1.0f;
+    for (int i = 0; i < A_PC; ++i) {
+        const int row = (wid * A_PC + i) * 8 + prow;  // tile row of this lane's LDS slot
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < B_PC; ++i) {
+        const int row = (wid * B_PC + i) * 8 + prow;
+        int gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
+    auto stage_in = [&](int buf, int kt) {
+        char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
+        char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = erow0 + i * 16 + r;
-                const bool ok = cok && row < g.M;
-                float v = (acc[i][j][r] + bv) * sc;
-                if (EPI == 1) v = gelu_erf(v);
-                else if (EPI == 2) v = fmaxf(v, 0.0f);
-                if (ok) {
-                    int64_t orow = row;
-                    if (g.patch_group > 0) {
-                        // patch-embedding mode: GEMM row m = frame * group + patch; the output has one extra
-                        // (CLS) row in front of every frame and `resid` is the position table [1+group, N].
-                        const int f = row / g.patch_group, p = row - f * g.patch_group;
-                        orow = (int64_t)f * (g.patch_group + 1) + 1 + p;
-                        v += (float)g.resid[(int64_t)(1 + p) * g.ldr + col];
-                    } else if (g.resid) {
-                        v += (float)g.resid[(int64_t)row * g.ldr + col];
-                    }
-                    if (g.out_f32) reinterpret_cast<float *>(g.C)[orow * g.ldc + col] = v;
-                    else reinterpret_cast<bf16 *>(g.C)[orow * g.ldc + col] = (bf16)v;
-                }
+        for (int i = 0; i < A_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * BK), (lds_void *)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * BK), (lds_void *)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto compute = [&](int buf) {
+        const char *sa = smem + buf * STAGE + (wm * WM) * 128;
+        const char *sb = smem + buf * STAGE + BM * 128 + (wn * WN) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bfr[TN];
+            const int kc = ks * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
             }
         }
+    };
+    const int nkd = (g.dbg & 2) ? 1 : nk;
+    if (NSTAGE == 2) {
+        stage_in(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nkd; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage_in(cur ^ 1, kt + 1);  // DMA runs under the MFMAs below
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // single LDS stage (two workgroups per CU hide each other's load / epilogue phases)
+        for (int kt = 0; kt < nkd; ++kt) {
+            stage_in(0, kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
+
+    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
+}
+
+// ---- ping-pong schedule (8 waves, K % 64 == 0) ------------------------------------------------------
+// A CU has 4 SIMDs; waves w and w + 4 of a workgroup share one.  The K-step is cut into 4 intervals
+// (read fragments of half 0 | 16 MFMAs | read half 1 | 16 MFMAs) separated by raw s_barriers, and the upper
+// wave group enters the loop one barrier late, so in every interval one wave of each SIMD issues MFMAs
+// while its partner does LDS reads and the LDS-DMA issue for the next K-step: the matrix pipe sees a
+// continuous MFMA stream instead of both waves stalling and computing in lockstep.
+// Hazards: fragment reads complete (lgkmcnt(0)) before the barrier that ends their interval, so the DMA that
+// refills a stage (issued >= 1 barrier after its last read) never races a ds_read; every wave drains its own
+// DMAs (vmcnt(0)) before the barrier that precedes the first read of the refilled stage.
+template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
+__global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_pp_kernel(const GemmArgs g) {
+    constexpr int NW = NWM * NWN;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PC = BM / 8 / NW, B_PC = BN / 8 / NW;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(NW == 8 && A_PC >= 1 && B_PC >= 1 && WN == 64, "unsupported geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm_i = bid / tiles_n, tn_i = bid % tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nk = g.K / BK;
+    const bool late = wid >= NW / 2;  // the wave group that runs one interval behind
+
+    const bf16 *pa[A_PC], *pb[B_PC];
+    const int prow = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < A_PC; ++i) {
+        const int row = (wid * A_PC + i) * 8 + prow;
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PC; ++i) {
+        const int row = (wid * B_PC + i) * 8 + prow;
+        int gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
+    auto stage_in = [&](int buf, int kt) {
+        char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
+        char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
+#pragma unroll
+        for (int i = 0; i < A_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * BK), (lds_void *)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * BK), (lds_void *)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read_half = [&](int buf, int half) {
+        const char *sa = smem + buf * STAGE + (wm * WM) * 128;
+        const char *sb = smem + buf * STAGE + BM * 128 + (wn * WN) * 128;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kc = (half * 2 + k2) * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+            }
+        }
+    };
+    auto mma_half = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER()                          \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+    stage_in(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (late) PP_BARRIER();
+
+    const int nkd = (g.dbg & 2) ? 1 : nk;
+    for (int kt = 0; kt < nkd; ++kt) {
+        const int cur = kt & 1;
+        // interval R0: next K-step's DMA, fragments of the first half
+        if (kt + 1 < nk) stage_in(cur ^ 1, kt + 1);
+        read_half(cur, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        mma_half();  // interval M0
+        PP_BARRIER();
+        read_half(cur, 1);  // interval R1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        mma_half();  // interval M1
+        PP_BARRIER();
+    }
+    if (!late) PP_BARRIER();
+#undef PP_BARRIER
+
+    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
 }
 
 // ---- skinny GEMM (M <= 16): weight-streaming, one 16-row block of W per workgroup ----------------
@@ -234,35 +587,67 @@ __global__ void skinny_reduce_kernel(const SkinnyArgs a) {
     skinny_epilogue(g, row, col, v);
 }
 
-template <int BM, int BN, int NWM, int NWN, int EPI>
+template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW>
 int launch_tiled_e(const GemmArgs &g, hipStream_t s) {
     static bool attr_set = false;
-    constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = gemm_nt_kernel<BM, BN, NWM, NWN, EPI>;
+    constexpr int stages = NSTAGE * (BM + BN) * 128, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
+    constexpr int smem = stages > epi ? stages : epi;
+    constexpr int smem_nt = 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi;
+    const bool fast = (g.K % BK) == 0 && !(g.dbg & 4);
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_kernel<BM, BN, NWM, NWN, EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem_nt));
         attr_set = true;
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
+    if (fast) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NWM, NWN, EPI>), dim3(tiles), dim3(64 * NWM * NWN), smem_nt, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
 
-template <int BM, int BN, int NWM, int NWN>
+template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
+int launch_pp_e(const GemmArgs &g, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int stages = 2 * (BM + BN) * 128, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
+    constexpr int smem = stages > epi ? stages : epi;
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_kernel<BM, BN, NWM, NWN, EPI, MINW>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, NWM, NWN, EPI, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+template <int BM, int BN, int NWM, int NWN, int MINW>
+int launch_pp(const GemmArgs &g, hipStream_t s) {
+    if (g.epi == 1) return launch_pp_e<BM, BN, NWM, NWN, 1, MINW>(g, s);
+    if (g.epi == 2) return launch_pp_e<BM, BN, NWM, NWN, 2, MINW>(g, s);
+    return launch_pp_e<BM, BN, NWM, NWN, 0, MINW>(g, s);
+}
+
+template <int BM, int BN, int NWM, int NWN, int NSTAGE, int MINW>
 int launch_tiled(const GemmArgs &g, hipStream_t s) {
-    if (g.epi == 1) return launch_tiled_e<BM, BN, NWM, NWN, 1>(g, s);
-    if (g.epi == 2) return launch_tiled_e<BM, BN, NWM, NWN, 2>(g, s);
-    return launch_tiled_e<BM, BN, NWM, NWN, 0>(g, s);
+    if (g.epi == 1) return launch_tiled_e<BM, BN, NWM, NWN, 1, NSTAGE, MINW>(g, s);
+    if (g.epi == 2) return launch_tiled_e<BM, BN, NWM, NWN, 2, NSTAGE, MINW>(g, s);
+    return launch_tiled_e<BM, BN, NWM, NWN, 0, NSTAGE, MINW>(g, s);
 }
 
 }  // namespace
 
-int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
+int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
+    GemmArgs g = g_in;
+    g.dbg = g_gemm_debug;
     if (g.M <= 0) return EILEV_OK;
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
+    if (g.M > 16 && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
+                                   (g.bias && ((uintptr_t)g.bias & 7))))
+        return EILEV_E_UNSUPPORTED;
     int rc;
     if (g.M <= 16 && g.patch_group == 0) {
         SkinnyArgs a;
@@ -285,11 +670,20 @@ int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
     }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
-    const int64_t t256 = ceil_div64(g.M, 256) * ceil_div64(g.N, 256);
-    const bool n_fits_256 = (g.N % 256 == 0) || g.N >= 2048;
-    if (t256 >= 256 && n_fits_256) rc = launch_tiled<256, 256, 2, 4>(g, s);
-    else if (ceil_div64(g.M, 256) * ceil_div64(g.N, 128) >= 256) rc = launch_tiled<256, 128, 4, 2>(g, s);
-    else rc = launch_tiled<128, 128, 2, 2>(g, s);
+    const int force = (g.dbg >> 4) & 7;  // probe-only override of the tile choice
+    const int64_t tm256 = ceil_div64(g.M, 256);
+    int cfg;
+    if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;        // 256x256, 2 LDS stages, 1 WG/CU
+    else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;                   // 256x128, 1 stage, 2 WG/CU (N = 1408 / 1536)
+    else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
+    else cfg = 4;                                                            // 128x128
+    if (force) cfg = force;
+    if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
+    else if (cfg == 6 && g.K % BK == 0) rc = launch_pp<256, 128, 4, 2, 2>(g, s);
+    else if (cfg == 1 || cfg == 5) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
+    else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4>(g, s);
+    else if (cfg == 2 || cfg == 6) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
+    else rc = launch_tiled<128, 128, 2, 2, 2, 2>(g, s);
     if (prof_kind >= 0) prof_end(s);
     return rc;
 }

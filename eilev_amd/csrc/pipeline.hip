@@ -103,7 +103,7 @@ GemmArgs mk_gemm(const bf16 *A, int64_t lda, const void *W, int64_t ldw, const v
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = (const bf16 *)W; g.ldw = ldw; g.bias = (const bf16 *)bias; g.resid = resid; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.epi = epi; g.out_f32 = 0; g.scale = 1.0f; g.scale_cols = 0;
-    g.patch_group = 0; g.scratch = nullptr; g.scratch_bytes = 0;
+    g.patch_group = 0; g.scratch = nullptr; g.scratch_bytes = 0; g.dbg = 0;
     return g;
 }
 

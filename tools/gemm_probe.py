@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""GPU probe: time eilev_linear on the ViT/OPT GEMM shapes; variants interleaved, several rounds (min / median)."""
+import ctypes as C
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from eilev_amd import abi
+
+lib = abi.load_hip()
+raw = C.CDLL(abi.HIP_LIB_PATH)
+P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True), "qkv": (34952, 4224, 1408, 0, False),
+       "proj": (34952, 1408, 1408, 0, True), "opt_fc1": (7680, 10240, 2560, 2, False), "opt_qkv": (7680, 7680, 2560, 0, False),
+       "qf_kv": (34952, 1536, 1408, 0, False), "opt_fc2": (7680, 2560, 10240, 0, True)}
+flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
+names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for name in names:
+    m, n, k, epi, resid = ALL[name]
+    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda").to(torch.bfloat16)
+    r = torch.randn(m, n, device="cuda").to(torch.bfloat16) if resid else None
+    o = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+    raw.eilev_debug_gemm_flags(4)   # reference: register-staged kernel
+    ref = torch.empty_like(o)
+    lib.eilev_linear(P(a), P(w), P(b), P(r), P(ref), m, n, k, epi, 0, st())
+    for flags in flags_list:
+        if flags & 3:
+            continue
+        raw.eilev_debug_gemm_flags(flags)
+        o.zero_()
+        lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+        torch.cuda.synchronize()
+        d = (o.float() - ref.float()).abs().max().item()
+        if d != 0.0:
+            print(f"{name}: flags={flags} MISMATCH vs register-staged kernel: max abs diff {d}")
+    times = {f: [] for f in flags_list}
+    for rd in range(rounds + 1):
+        for flags in flags_list:
+            raw.eilev_debug_gemm_flags(flags)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+            e1.record(); torch.cuda.synchronize()
+            if rd:
+                times[flags].append(e0.elapsed_time(e1) / 5)
+    for flags in flags_list:
+        t = times[flags]
+        med, mn = statistics.median(t), min(t)
+        print(f"{name:8s} M={m} N={n} K={k} flags={flags:3d} med {med*1e3:7.1f} us {2*m*n*k/med/1e9:7.1f} TF/s | min {mn*1e3:7.1f} us {2*m*n*k/mn/1e9:7.1f} TF/s", flush=True)
+raw.eilev_debug_gemm_flags(0)
