@@ -111,6 +111,7 @@ struct AttnArgs {
     int causal;
     const int32_t *key_mask;         // (batch, mask_ld) or null
     int64_t mask_ld;
+    int dbg;                         // probe-only
 };
 int launch_attention(const AttnArgs &a, hipStream_t s);
 
