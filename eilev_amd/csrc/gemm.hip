@@ -510,9 +510,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_pp_kernel(const Gem
 }
 
 // ---- skinny GEMM (M <= 16): weight-streaming, one 16-row block of W per workgroup ----------------
-// grid = (ceil(N/16), KS).  Each of the 8 waves owns a contiguous slice of this workgroup's K range;
+// grid = (ceil(N/16), KS).  Each of the 4 waves owns a contiguous slice of this workgroup's K range;
 // per K-step of 32 a lane loads 16 B of W (row n0 + lane%16, k-group lane/16) and 16 B of A (batch row
-// lane%16, zero beyond M) and issues one 16x16x32 MFMA.  Wave partials are summed through LDS in a
+// lane%16, zero beyond M) and issues one 16x16x32 MFMA; loads are issued 8 deep.  Wave partials are summed through LDS in a
 // fixed order (deterministic).  KS == 1: epilogue applied here; KS > 1: fp32 partials to `part`
 // ([KS][16][N]) for skinny_reduce_kernel.
 struct SkinnyArgs {
@@ -531,9 +531,9 @@ __device__ __forceinline__ void skinny_epilogue(const GemmArgs &g, int row, int 
     else reinterpret_cast<bf16 *>(g.C)[(int64_t)row * g.ldc + col] = (bf16)v;
 }
 
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(const SkinnyArgs a) {
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
-    __shared__ float red[8][64][4];
+    __shared__ float red[4][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -543,15 +543,26 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const SkinnyArgs a) {
     const int ksteps = (g.K + 31) / 32;
     const int per_wg = (ksteps + a.ks - 1) / a.ks;
     const int wg_beg = blockIdx.y * per_wg, wg_end = min(ksteps, wg_beg + per_wg);
-    const int per_w = (max(wg_end - wg_beg, 0) + 7) / 8;
+    const int per_w = (max(wg_end - wg_beg, 0) + 3) / 4;
     const int beg = wg_beg + wid * per_w, end = min(wg_end, beg + per_w);
 
     const bf16 *wp = g.W + (int64_t)wrow * g.ldw + lg * 8;
     const bf16 *ap = g.A + (int64_t)(l15 < g.M ? l15 : 0) * g.lda + lg * 8;
     const bool arow = l15 < g.M;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = beg; s < end; ++s) {
+    int s = beg;
+    // 8 independent 16-byte weight loads in flight per lane (the K tail of the matrix never lands here:
+    // K % 256 == 0 for every decode shape; the remainder loop below handles the general case)
+    for (; s + 8 <= end && (s + 8) * 32 <= g.K; s += 8) {
+        bf16x8 wv[8], av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wp + (s + u) * 32));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = arow ? *reinterpret_cast<const bf16x8 *>(ap + (s + u) * 32) : zero8();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], wv[u], acc, 0, 0, 0);
+    }
+    for (; s < end; ++s) {
         const int k = s * 32;
         const bool kin = (k + lg * 8) < g.K;
         bf16x8 wv = kin ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wp + k)) : zero8();
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const SkinnyArgs a) {
         for (int r = 0; r < 4; ++r) {
             float v = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[w][lane][r];
+            for (int w = 0; w < 4; ++w) v += red[w][lane][r];
             const int row = lg * 4 + r;
             if (row < g.M && col < g.N) {
                 if (a.ks == 1) skinny_epilogue(g, row, col, v);
@@ -655,11 +666,11 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         const int nb = (g.N + 15) / 16;
         int ks = nb >= 512 ? 1 : (512 + nb - 1) / nb;
         const int ksteps = (g.K + 31) / 32;
-        if (ks > ksteps / 8) ks = ksteps / 8 > 0 ? ksteps / 8 : 1;
+        if (ks > ksteps / 32) ks = ksteps / 32 > 0 ? ksteps / 32 : 1;  // >= 8 K-steps of 32 per wave
         if (ks > 1 && (!g.scratch || (size_t)ks * 16 * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
         a.ks = ks;
         a.part = g.scratch;
-        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
         if (ks > 1) {
             const int total = g.M * g.N;

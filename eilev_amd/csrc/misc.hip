@@ -195,85 +195,85 @@ __global__ __launch_bounds__(256) void kv_write_kernel(const bf16 *__restrict__ 
 }
 
 // ---- single-query attention against the cache (decode step) ---------------------------------------------
-// grid (heads, batch).  kv_total = seq_len + state[0]; keys < seq_len obey attn_mask, newer ones are visible.
-// Phase 1: 16 lanes per key (one 16-byte chunk each) -> score; phase 2: workgroup max / sum; phase 3:
-// thread = (key subset, d chunk) accumulates p * v, reduced through LDS.
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ kc,
-                                                          const bf16 *__restrict__ vc, bf16 *__restrict__ out,
-                                                          const int32_t *__restrict__ attn_mask,
-                                                          const int32_t *__restrict__ state, int seq_len, int cap,
-                                                          int heads, int hd) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float *sc = dsm;                 // [cap]
-    float *red = dsm + cap;          // [nks][hd]
+// Flash-decoding split: grid (heads, batch, nsplit); each workgroup owns KEYS_PER_WG = 256 consecutive cache
+// slots of one (batch, head) and writes an un-normalised partial (max, sum, o[hd]) to `part`; a second tiny
+// kernel merges the splits.  kv_total = seq_len + state[0] is read on the device (hipGraph replay); keys
+// < seq_len obey attn_mask, newer ones are visible.  One key per thread for the scores (its whole K row:
+// hd/8 independent 16-byte loads in flight), thread = (key subset, d chunk) for p.V; HBM-bound.
+constexpr int DEC_KEYS = 256;
+
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ kc,
+                                                                const bf16 *__restrict__ vc, float *__restrict__ part,
+                                                                const int32_t *__restrict__ attn_mask,
+                                                                const int32_t *__restrict__ state, int seq_len, int cap,
+                                                                int heads, int hd) {
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ float sc[DEC_KEYS];
+    __shared__ float red[32 * 128];
     __shared__ float wred[4];
     __shared__ float bc[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
     const int d = heads * hd, nch = hd >> 3;
     const int kv_total = min(cap, seq_len + state[0]);
+    const int k0 = sp * DEC_KEYS, k1 = min(kv_total, k0 + DEC_KEYS);
+    float *po = part + (((int64_t)b * heads + h) * nsplit + sp) * (hd + 2);
+    if (k0 >= kv_total) {  // nothing in this split yet
+        if (tid == 0) {
+            po[0] = -1e30f;
+            po[1] = 0.0f;
+        }
+        return;
+    }
     const bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd;
     const bf16 *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * 3 * d + h * hd + tid];
+    __syncthreads();
 
-    // phase 1
-    const int l15 = lane & 15, sub = lane >> 4;
-    float qv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = 0.0f;
-    if (l15 < nch) unpack8(*reinterpret_cast<const bf16x8 *>(qkv + (int64_t)b * 3 * d + h * hd + l15 * 8), qv);
-    float lmax = -1e30f;
-    for (int j = wid * 4 + sub; j < kv_total; j += 16) {
-        float s = 0.0f;
-        if (l15 < nch) {
-            float kvv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>(kbase + (int64_t)j * hd + l15 * 8), kvv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += qv[e] * kvv[e];
+    // scores: thread t <-> key k0 + t
+    const int j = k0 + tid;
+    float s = -1e30f;
+    if (j < k1) {
+        const bf16x8 *kr = reinterpret_cast<const bf16x8 *>(kbase + (int64_t)j * hd);
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int c = 0; c < nch; ++c) {
+            float kv[8];
+            unpack8(kr[c], kv);
+            const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]);
+            const float4 q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+            acc += kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 8, 64);
         const bool vis = j >= seq_len || attn_mask[(int64_t)b * seq_len + j] != 0;
-        s = vis ? s : -1e30f;
-        if (l15 == 0) sc[j] = s;
-        lmax = fmaxf(lmax, s);
+        s = vis ? acc : -1e30f;
     }
-    lmax = wave_max(lmax);
-    if (lane == 0) wred[wid] = lmax;
+    float mxw = wave_max(s);
+    if (lane == 0) wred[wid] = mxw;
     __syncthreads();
-    if (tid == 0) bc[0] = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    const float mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    const float p = s > -1e29f ? __expf(s - mx) : 0.0f;
+    sc[tid] = (float)(bf16)p;  // P rounded to bf16 like the prefill kernel's MFMA operand
+    float sw = wave_sum(p);
     __syncthreads();
-    const float mx = bc[0];
-    // phase 2
-    float lsum = 0.0f;
-    for (int j = tid; j < kv_total; j += 256) {
-        const float s = sc[j];
-        const float p = s > -1e29f ? __expf(s - mx) : 0.0f;
-        sc[j] = p;
-        lsum += p;
-    }
-    lsum = wave_sum(lsum);
+    if (lane == 0) wred[wid] = sw;
     __syncthreads();
-    if (lane == 0) wred[wid] = lsum;
-    __syncthreads();
-    if (tid == 0) bc[1] = wred[0] + wred[1] + wred[2] + wred[3];
-    __syncthreads();
-    const float inv = bc[1] > 0.0f ? 1.0f / bc[1] : 0.0f;
-    // phase 3
+    const float lsum = wred[0] + wred[1] + wred[2] + wred[3];
+
+    // p.V: thread = (key subset ks, d chunk c)
     const int nks = 256 / nch;
     const int c = tid % nch, ks = tid / nch;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     if (ks < nks) {
-        for (int j = ks; j < kv_total; j += nks) {
-            // P is rounded to bf16 like the prefill kernel's MFMA operand
-            const float p = (float)(bf16)sc[j];
+        const int nkeys = k1 - k0;
+#pragma unroll 4
+        for (int jj = ks; jj < nkeys; jj += nks) {
             float vv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>(vbase + (int64_t)j * hd + c * 8), vv);
+            unpack8(*reinterpret_cast<const bf16x8 *>(vbase + (int64_t)(k0 + jj) * hd + c * 8), vv);
+            const float pj = sc[jj];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += p * vv[e];
+            for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[ks * hd + c * 8 + e] = acc[e];
@@ -282,8 +282,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16 *__restrict
     if (tid < hd) {
         float v = 0.0f;
         for (int k2 = 0; k2 < nks; ++k2) v += red[k2 * hd + tid];
-        out[(int64_t)b * d + h * hd + tid] = (bf16)(v * inv);
+        po[2 + tid] = v;
     }
+    if (tid == 0) {
+        po[0] = mx;
+        po[1] = lsum;
+    }
+}
+
+__global__ __launch_bounds__(128) void attn_decode_merge_kernel(const float *__restrict__ part, bf16 *__restrict__ out,
+                                                                int heads, int hd, int nsplit) {
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const float *pp = part + ((int64_t)b * heads + h) * nsplit * (hd + 2);
+    float mx = -1e30f;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, pp[s * (hd + 2)]);
+    float l = 0.0f, o = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float *ps = pp + s * (hd + 2);
+        const float w = ps[1] > 0.0f ? __expf(ps[0] - mx) : 0.0f;
+        l += w * ps[1];
+        if (t < hd && w > 0.0f) o += w * ps[2 + t];
+    }
+    if (t < hd) out[((int64_t)b * heads + h) * hd + t] = (bf16)(l > 0.0f ? o / l : 0.0f);
 }
 
 // ---- greedy selection (hf generation/utils.py:2894-2937) ------------------------------------------------
@@ -396,12 +416,19 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
+    const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
+    return sizeof(float) * (size_t)batch * heads * nsplit * (hd + 2);
+}
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
-                       int batch, int seq_len, int cap, int heads, int hd, hipStream_t s) {
-    const int nks = 256 / (hd >> 3);
-    const size_t smem = sizeof(float) * ((size_t)cap + (size_t)nks * hd);
-    if (smem > 60 * 1024) return EILEV_E_UNSUPPORTED;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(heads, batch), dim3(256), smem, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, hd);
+                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s) {
+    if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
+    const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
+    if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap)) return EILEV_E_WORKSPACE;
+    hipLaunchKernelGGL(attn_decode_split_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, kc, vc, scratch, attn_mask, state,
+                       seq_len, cap, heads, hd);
+    EILEV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, nsplit);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -18,7 +18,7 @@ int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *token
 int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
                     const int32_t *state, hipStream_t s);
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
-                       int batch, int seq_len, int cap, int heads, int hd, hipStream_t s);
+                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
 
@@ -50,11 +50,11 @@ void prof_begin(int kind, double flops, hipStream_t s) {
     }
     g_recs[g_used].kind = kind;
     g_recs[g_used].flops = flops;
-    hipEventRecord(g_recs[g_used].a, s);
+    (void)hipEventRecord(g_recs[g_used].a, s);
 }
 void prof_end(hipStream_t s) {
     if (!g_prof_on || g_used >= kMaxRecs || g_used >= g_recs.size()) return;
-    hipEventRecord(g_recs[g_used].b, s);
+    (void)hipEventRecord(g_recs[g_used].b, s);
     ++g_used;
 }
 
@@ -351,17 +351,17 @@ int opt_qkv(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_
                        (const bf16 *)L->k_b == (const bf16 *)L->q_b + D && (const bf16 *)L->v_b == (const bf16 *)L->q_b + 2 * D;
     if (fused) {
         GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
-        g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+        g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
         return launch_gemm(g, 5, s);
     }
     GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, D, D, 0);
-    g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->k_w, D, L->k_b, nullptr, 0, b.qkv + D, 3 * D, M, D, D, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->v_w, D, L->v_b, nullptr, 0, b.qkv + 2 * D, 3 * D, M, D, D, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     return launch_gemm(g, 5, s);
 }
 
@@ -369,14 +369,14 @@ int opt_qkv(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_
 int opt_tail(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_t M, hipStream_t s) {
     const int D = d->t_hidden, Ft = d->t_ffn;
     GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     RC(launch_layernorm(b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, b.x, D, M, D, d->t_eps, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     return launch_gemm(g, 5, s);
 }
 
@@ -423,7 +423,7 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         // last position of every row: a strided [batch, D] view of x
         GemmArgs g = mk_gemm(b.x + (seq_len - 1) * (int64_t)D, seq_len * (int64_t)D, w->embed_tokens, D, nullptr, nullptr, 0,
                              logits_last, d->vocab, batch, d->vocab, D, 0);
-        g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+        g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
         RC(launch_gemm(g, 5, s));
     }
     return EILEV_OK;
@@ -460,12 +460,13 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
         RC(opt_qkv(d, L, b, batch, s));
         RC(launch_kv_write(b.qkv, kc, vc, (int)batch, 1, H, hd, (int)kv_capacity, (int)seq_len, state, s));
-        RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd, s));
+        RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
+                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s));
         RC(opt_tail(d, L, b, batch, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, batch, D, d->t_eps, s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
-    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch;
+    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
 }
