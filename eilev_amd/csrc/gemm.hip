@@ -588,6 +588,85 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs a) {
     }
 }
 
+// Skinny kernel, DMA-staged variant (K % 256 == 0): the 16-row weight block is streamed through per-wave LDS
+// buffers with global_load_lds_dwordx4 so that every load instruction covers two whole 512-byte row segments
+// (fully coalesced; the direct MFMA-layout loads above touch 64 separate 16-byte pieces per instruction).
+// Each wave runs its own 2-deep pipeline on a private 2 x 8 KiB region: DMA(t+1) is issued before the
+// counted s_waitcnt vmcnt(8) that retires DMA(t); no workgroup barrier in the K loop.  16-byte chunk c of
+// row r is stored at chunk c ^ (r & 15) (swizzle applied on the source address) so the ds_read_b128 fragment
+// reads of 16 rows x 512-byte stride are bank-conflict-free.
+__global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a) {
+    const GemmArgs &g = a.g;
+    __shared__ __attribute__((aligned(16))) char wbuf[4][2][8192];
+    __shared__ float red[4][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    // K range of this workgroup / wave in units of 256 (= one 16 x 256 tile = 8 MFMA steps)
+    const int ktiles = g.K / 256;
+    const int per_wg = (ktiles + a.ks - 1) / a.ks;
+    const int wg_beg = blockIdx.y * per_wg, wg_end = min(ktiles, wg_beg + per_wg);
+    const int per_w = (max(wg_end - wg_beg, 0) + 3) / 4;
+    const int beg = wg_beg + wid * per_w, end = min(wg_end, beg + per_w);
+
+    // DMA source: piece i (rows 2i, 2i+1): lane p -> row 2i + p/32, LDS slot p%32 <- global chunk slot ^ (row & 15)
+    const int prow = lane >> 5, pslot = lane & 31;
+    const bf16 *src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 2 * i + prow;
+        int gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        src[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ (row & 15)) << 3);
+    }
+    auto stage_in = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(src[i] + t * 256), (lds_void *)(&wbuf[wid][buf][i * 1024]), 16, 0, 0);
+    };
+    const bf16 *ap = g.A + (int64_t)(l15 < g.M ? l15 : 0) * g.lda + lg * 8;
+    const bool arow = l15 < g.M;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (beg < end) stage_in(0, beg);
+    for (int t = beg; t < end; ++t) {
+        const int cur = (t - beg) & 1;
+        bf16x8 av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = arow ? *reinterpret_cast<const bf16x8 *>(ap + t * 256 + u * 32) : zero8();
+        if (t + 1 < end) {
+            stage_in(cur ^ 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile t (older than the 8 just issued)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char *wb = &wbuf[wid][cur][0] + l15 * 512;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], wv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wid][lane][r] = acc[r];
+    __syncthreads();
+    if (wid == 0) {
+        const int col = n0 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w][lane][r];
+            const int row = lg * 4 + r;
+            if (row < g.M && col < g.N) {
+                if (a.ks == 1) skinny_epilogue(g, row, col, v);
+                else a.part[((int64_t)blockIdx.y * 16 + row) * g.N + col] = v;
+            }
+        }
+    }
+}
+
 __global__ void skinny_reduce_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -670,7 +749,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         if (ks > 1 && (!g.scratch || (size_t)ks * 16 * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
         a.ks = ks;
         a.part = g.scratch;
-        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
+        if (g.K % 256 == 0 && !(g.dbg & 8)) hipLaunchKernelGGL(gemm_skinny_dma_kernel, dim3(nb, ks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
         if (ks > 1) {
             const int total = g.M * g.N;
