@@ -20,7 +20,7 @@ def _ptr(t):
 class HipEngine:
     """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
 
-    def __init__(self, config, named_tensors: dict, device=None):
+    def __init__(self, config, named_tensors: dict, device=None, parts=("vit", "qf", "opt")):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = abi.load_hip()
@@ -31,6 +31,7 @@ class HipEngine:
             raise RuntimeError(f"HipEngine weights must live on the GPU, got {self.device}")
         self._keep = {}
         self._ws = {}
+        self.parts = tuple(parts)
         self._load(named_tensors)
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
@@ -49,11 +50,18 @@ class HipEngine:
                 store[k] = flat[off: off + p.numel()].view(p.shape)
                 off += p.numel()
 
-        for i in range(d.t_layers):
+        def part_of(key):
+            if key.startswith("vision_model."):
+                return "vit"
+            if key.startswith("qformer.") or key == "query_tokens":
+                return "qf"
+            return "opt"
+
+        for i in range(d.t_layers if "opt" in self.parts else 0):
             p = abi.OPT_PREFIX.format(i) + "self_attn."
             pack([p + "q_proj.weight", p + "k_proj.weight", p + "v_proj.weight"])
             pack([p + "q_proj.bias", p + "k_proj.bias", p + "v_proj.bias"])
-        for i in range(d.q_layers):
+        for i in range(d.q_layers if "qf" in self.parts else 0):
             p = abi.QF_PREFIX.format(i)
             pack([p + f"attention.attention.{n}.weight" for n in ("query", "key", "value")])
             pack([p + f"attention.attention.{n}.bias" for n in ("query", "key", "value")])
@@ -62,6 +70,8 @@ class HipEngine:
                 pack([p + f"crossattention.attention.{n}.bias" for n in ("key", "value")])
 
         def addr(key):
+            if part_of(key) not in self.parts:
+                return None
             if key not in store:
                 store[key] = bf(named[key])
             return store[key].data_ptr()

@@ -1,0 +1,292 @@
+"""VideoBLIP / EILeV model API on the MI355X-native forward path.
+
+Keeps the class surface the reference's callers import (ref:eilev/model/v2.py:20-324): ``VideoBlipVisionModel`` and
+``VideoBlipForConditionalGeneration`` with ``forward`` / ``generate`` / ``from_pretrained`` / ``save_pretrained`` /
+``.config`` / ``.device`` / ``.dtype`` / ``.vision_model`` / ``.qformer`` / ``.language_model`` /
+``.language_projection`` / ``.query_tokens``.  The modules below are PARAMETER CONTAINERS with the checkpoint's
+state-dict names; none of them has arithmetic in its ``forward``.  All FLOPs run in
+``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
+``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
+
+Not built yet (raise ``NotImplementedError``): beam search / sampling, the Flan-T5 language model, ``classify``,
+``output_attentions`` / ``output_hidden_states``, and autograd through the HIP path (training).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from transformers import Blip2Config, PreTrainedModel
+from transformers.modeling_outputs import (
+    BaseModelOutputWithPooling,
+    BaseModelOutputWithPoolingAndCrossAttentions,
+    CausalLMOutputWithPast,
+)
+from transformers.models.blip_2.modeling_blip_2 import Blip2ForConditionalGenerationModelOutput
+
+
+# ---- parameter containers (names = checkpoint keys) -----------------------------------------------------
+def _bag(**children) -> nn.Module:
+    m = nn.Module()
+    for k, v in children.items():
+        if isinstance(v, nn.Parameter):
+            m.register_parameter(k, v)
+        else:
+            m.add_module(k, v)
+    return m
+
+
+def _vit_params(c) -> nn.Module:
+    d, f = c.hidden_size, c.intermediate_size
+    tok = (c.image_size // c.patch_size) ** 2 + 1
+    emb = _bag(class_embedding=nn.Parameter(torch.zeros(1, 1, d)), position_embedding=nn.Parameter(torch.zeros(1, tok, d)),
+               patch_embedding=nn.Conv2d(3, d, c.patch_size, c.patch_size))
+    layers = nn.ModuleList(
+        _bag(self_attn=_bag(qkv=nn.Linear(d, 3 * d), projection=nn.Linear(d, d)), layer_norm1=nn.LayerNorm(d, eps=c.layer_norm_eps),
+             mlp=_bag(fc1=nn.Linear(d, f), fc2=nn.Linear(f, d)), layer_norm2=nn.LayerNorm(d, eps=c.layer_norm_eps))
+        for _ in range(c.num_hidden_layers))
+    return emb, _bag(layers=layers), nn.LayerNorm(d, eps=c.layer_norm_eps)
+
+
+def _qformer_params(c) -> nn.Module:
+    d, f = c.hidden_size, c.intermediate_size
+
+    def attn(kv):
+        return _bag(attention=_bag(query=nn.Linear(d, d), key=nn.Linear(kv, d), value=nn.Linear(kv, d)),
+                    output=_bag(dense=nn.Linear(d, d), LayerNorm=nn.LayerNorm(d, eps=c.layer_norm_eps)))
+
+    blocks = []
+    for i in range(c.num_hidden_layers):
+        parts = dict(attention=attn(d))
+        if i % c.cross_attention_frequency == 0:
+            parts["crossattention"] = attn(c.encoder_hidden_size)
+        parts["intermediate_query"] = _bag(dense=nn.Linear(d, f))
+        parts["output_query"] = _bag(dense=nn.Linear(f, d), LayerNorm=nn.LayerNorm(d, eps=c.layer_norm_eps))
+        blocks.append(_bag(**parts))
+    return _bag(layernorm=nn.LayerNorm(d, eps=c.layer_norm_eps), encoder=_bag(layer=nn.ModuleList(blocks)))
+
+
+class _OptParams(nn.Module):
+    """OPTForCausalLM's parameter tree (hf modeling_opt.py:443-524) without its arithmetic."""
+
+    def __init__(self, c):
+        super().__init__()
+        d, f = c.hidden_size, c.ffn_dim
+        layers = nn.ModuleList(
+            _bag(self_attn=_bag(k_proj=nn.Linear(d, d), v_proj=nn.Linear(d, d), q_proj=nn.Linear(d, d), out_proj=nn.Linear(d, d)),
+                 self_attn_layer_norm=nn.LayerNorm(d), fc1=nn.Linear(d, f), fc2=nn.Linear(f, d), final_layer_norm=nn.LayerNorm(d))
+            for _ in range(c.num_hidden_layers))
+        dec = _bag(embed_tokens=nn.Embedding(c.vocab_size, d, c.pad_token_id),
+                   embed_positions=nn.Embedding(c.max_position_embeddings + 2, d), final_layer_norm=nn.LayerNorm(d), layers=layers)
+        self.model = _bag(decoder=dec)
+        self.lm_head = nn.Linear(d, c.vocab_size, bias=False)
+        self.lm_head.weight = dec.embed_tokens.weight  # tied (hf modeling_opt.py:444)
+        self.config = c
+
+    def get_input_embeddings(self):
+        return self.model.decoder.embed_tokens
+
+    def forward(self, *a, **k):
+        raise RuntimeError("language_model is a parameter container; call the parent VideoBlipForConditionalGeneration")
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{what}: the MI355X-native path has no CPU fallback — move the model to an AMD GPU (.to('cuda'))")
+
+
+class VideoBlipVisionModel(nn.Module):
+    """(num_videos, C, T, H, W) -> ViT-g over every frame -> (num_videos, T * tokens, D)  [ref:eilev/model/v2.py:20-103]."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings, self.encoder, self.post_layernorm = _vit_params(config)
+        self._engine_ref = None  # set by the parent model; a stand-alone vision model builds a ViT-only engine
+        self._own_engine = None
+
+    def _engine(self):
+        if self._engine_ref is not None:
+            return self._engine_ref()
+        key = _params_key(self)
+        if self._own_engine is None or self._own_engine[0] != key:
+            from ..engine import HipEngine
+            from transformers import Blip2Config as _C
+
+            named = {"vision_model." + k: v for k, v in self.state_dict().items()}
+            full = _C(vision_config=self.config.to_dict())
+            self._own_engine = (key, HipEngine(full, named, device=next(self.parameters()).device, parts=("vit",)))
+        return self._own_engine[1]
+
+    @torch.no_grad()
+    def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        if pixel_values is None:
+            raise ValueError("You have to specify pixel_values")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / per-layer hidden states are not exported by the fused HIP path")
+        _require_gpu(next(self.parameters()), "VideoBlipVisionModel.forward")
+        dtype = next(self.parameters()).dtype
+        last, pooled = self._engine().vit(pixel_values, want_pooler=True)
+        last, pooled = last.to(dtype), pooled.to(dtype)
+        if return_dict is False:
+            return (last, pooled, None, None)
+        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled, hidden_states=None, attentions=None)
+
+
+def _params_key(module: nn.Module):
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in module.parameters())
+
+
+class VideoBlipForConditionalGeneration(PreTrainedModel):
+    config_class = Blip2Config
+    config: Blip2Config
+    base_model_prefix = "blip"
+    main_input_name = "pixel_values"
+    _tied_weights_keys = {"language_model.lm_head.weight": "language_model.model.decoder.embed_tokens.weight"}
+    _supports_sdpa = False
+
+    def __init__(self, config: Blip2Config) -> None:
+        super().__init__(config)
+        if not config.use_decoder_only_language_model or config.text_config.model_type != "opt":
+            raise NotImplementedError("only the OPT (decoder-only) language model is built on the HIP path so far")
+        self.vision_model = VideoBlipVisionModel(config.vision_config)
+        self.query_tokens = nn.Parameter(torch.zeros(1, config.num_query_tokens, config.qformer_config.hidden_size))
+        self.qformer = _qformer_params(config.qformer_config)
+        self.language_projection = nn.Linear(config.qformer_config.hidden_size, config.text_config.hidden_size)
+        self.language_model = _OptParams(config.text_config)
+        self._hip = None
+        import weakref
+
+        me = weakref.ref(self)
+        self.vision_model._engine_ref = lambda: me().engine()
+        self.post_init()
+
+    # ---- HF plumbing -------------------------------------------------------------------------------------
+    def _init_weights(self, module):
+        std = getattr(self.config, "initializer_range", 0.02)
+        if isinstance(module, (nn.Linear, nn.Conv2d, nn.Embedding)):
+            nn.init.normal_(module.weight, mean=0.0, std=std)
+            if getattr(module, "bias", None) is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.ones_(module.weight)
+            nn.init.zeros_(module.bias)
+
+    def get_input_embeddings(self):
+        return self.language_model.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.language_model.model.decoder.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.language_model.lm_head
+
+    def tie_weights(self, *a, **k):
+        self.language_model.lm_head.weight = self.language_model.model.decoder.embed_tokens.weight
+
+    # ---- engine ------------------------------------------------------------------------------------------
+    def engine(self):
+        """bf16 device copy of the weights + the HIP library; rebuilt when a parameter changed (optimizer step,
+        load_state_dict, .to())."""
+        key = _params_key(self)
+        if self._hip is None or self._hip[0] != key:
+            from ..engine import HipEngine
+
+            _require_gpu(self.query_tokens, type(self).__name__)
+            self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device))
+        return self._hip[1]
+
+    def _encode(self, pixel_values, input_ids, video_input_mask):
+        eng = self.engine()
+        feats = None
+        vision = qf = None
+        if pixel_values is not None:
+            assert video_input_mask is not None
+            img, pooled = eng.vit(pixel_values, want_pooler=True)
+            q = eng.qformer(img)
+            feats = eng.project(q)
+            vision, qf = (img, pooled), q
+        emb = eng.embed_scatter(input_ids, video_input_mask if feats is not None else None, feats)
+        return emb, vision, qf
+
+    # ---- API ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask=None, pixel_values=None, video_input_mask=None, decoder_input_ids=None,
+                decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
+        """pixel_values: (num_videos, C, T, H, W); video_input_mask: (batch, seq_len)  [ref:eilev/model/v2.py:132-252].
+
+        NOTE: runs without autograd — training through the HIP path (Q-Former backward) is not built yet."""
+        if pixel_values is not None:
+            assert video_input_mask is not None
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / per-layer hidden states are not exported by the fused HIP path")
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        dtype = self.dtype
+        emb, vision, qf = self._encode(pixel_values, input_ids, video_input_mask)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        _, logits32, _ = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False)
+        loss = None
+        if labels is not None:
+            # HF causal-LM loss: shifted CE, ignore_index -100 (hf loss_utils.ForCausalLMLoss)
+            shift = logits32[:, :-1].reshape(-1, logits32.size(-1))
+            tgt = labels.to(logits32.device)[:, 1:].reshape(-1)
+            loss = nn.functional.cross_entropy(shift, tgt, ignore_index=-100).to(dtype)
+        logits = logits32.to(dtype)
+        vis_out = qf_out = None
+        if vision is not None:
+            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype))
+            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
+        lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
+        if not return_dict:
+            out = (logits, vis_out, qf_out, lm_out)
+            return ((loss,) + out) if loss is not None else out
+        return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=logits, vision_outputs=vis_out, qformer_outputs=qf_out,
+                                                        language_model_outputs=lm_out)
+
+    @torch.no_grad()
+    def generate(self, input_ids, pixel_values=None, video_input_mask=None, attention_mask=None, **generate_kwargs):
+        """Greedy decoding on the HIP path; returns only the NEW tokens like the reference does for OPT
+        (ref:eilev/model/v2.py:254-324 drives the LM with inputs_embeds)."""
+        assert not (input_ids is None and pixel_values is None)
+        if pixel_values is not None:
+            assert video_input_mask is not None
+        kw = dict(generate_kwargs)
+        num_beams = kw.pop("num_beams", 1)
+        do_sample = kw.pop("do_sample", False)
+        kw.pop("length_penalty", None)  # only affects beam search
+        if num_beams not in (None, 1) or do_sample:
+            raise NotImplementedError("only greedy decoding (num_beams=1, do_sample=False) is built on the HIP path so far")
+        max_new = kw.pop("max_new_tokens", None)
+        if max_new is None:
+            max_len = kw.pop("max_length", None)
+            if max_len is None:
+                max_new = 20  # HF GenerationConfig default max_length
+            else:
+                max_new = int(max_len) - input_ids.shape[1]
+        min_new = kw.pop("min_new_tokens", 0) or 0
+        gen_cfg = getattr(self, "generation_config", None)
+        eos = kw.pop("eos_token_id", getattr(gen_cfg, "eos_token_id", None) if gen_cfg is not None else None)
+        if eos is None:
+            eos = self.config.text_config.eos_token_id
+        if isinstance(eos, (list, tuple)):
+            if len(eos) != 1:
+                raise NotImplementedError("several eos_token_id values")
+            eos = eos[0]
+        pad = kw.pop("pad_token_id", None)
+        if pad is None:
+            pad = self.config.text_config.pad_token_id if self.config.text_config.pad_token_id is not None else eos
+        if min_new >= max_new:
+            eos = -1  # EOS can never fire before the budget is exhausted
+        elif min_new > 0:
+            raise NotImplementedError("0 < min_new_tokens < max_new_tokens")
+        for k in ("use_cache", "return_dict_in_generate", "output_scores"):
+            kw.pop(k, None)
+        if kw:
+            raise NotImplementedError(f"unsupported generate() arguments on the HIP path: {sorted(kw)}")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        emb, _, _ = self._encode(pixel_values, input_ids, video_input_mask)
+        return self.engine().greedy_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad))
+
+    def classify(self, *args, **kwargs):
+        raise NotImplementedError("classify() (KV-cache fan-out log-likelihood, ref:eilev/model/v2.py:326-501) is a next-row item")

@@ -1,0 +1,80 @@
+"""-m gpu: the drop-in class surface (forward / generate / vision model) on the HIP path vs the reference's goldens."""
+import numpy as np
+import pytest
+import torch
+
+from eilev_amd.configs import blip2_config
+from hip_utils import host, load_case, rel_rms
+from oracle.runner import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg_name, dtype):
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+
+    cfg = blip2_config(cfg_name)
+    m = VideoBlipForConditionalGeneration(cfg).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}
+    sd["language_model.lm_head.weight"] = sd["language_model.model.decoder.embed_tokens.weight"]
+    m.load_state_dict(sd)
+    return m.to(dtype).to("cuda")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["mid_b1", "mid_b2"])
+def test_forward_and_generate_like_the_reference(golden_dir, name, dtype):
+    g, meta, px = load_case(golden_dir, name)
+    m = build(meta["config"], dtype)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+            video_input_mask=t(g["video_input_mask"]), labels=t(g["labels"]), return_dict=True)
+    assert out.logits.dtype == dtype and out.logits.shape == g["fp32_logits"].shape
+    valid = g["attention_mask"] == 1
+    assert rel_rms(host(out.logits)[valid], g["fp32_logits"][valid]) <= 1.2e-2
+    assert abs(float(out.loss) - float(g["fp32_loss"])) <= 2e-2 * abs(float(g["fp32_loss"]))
+    assert out.vision_outputs.last_hidden_state.shape == g["fp32_vit"].shape
+    assert out.vision_outputs.pooler_output.shape == g["fp32_pooler"].shape
+    assert out.qformer_outputs.last_hidden_state.shape == g["fp32_qformer"].shape
+    tup = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+            video_input_mask=t(g["video_input_mask"]), return_dict=False)
+    assert torch.equal(tup[0], out.logits)
+    n = meta["new_tokens"]
+    ids = m.generate(input_ids=t(g["input_ids"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]),
+                     attention_mask=t(g["attention_mask"]), max_new_tokens=n, num_beams=1, do_sample=False,
+                     eos_token_id=int(g["fp32_eos_id"]))
+    assert np.array_equal(ids.cpu().numpy(), g["fp32_greedy_eos"])
+    ids = m.generate(input_ids=t(g["input_ids"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]),
+                     attention_mask=t(g["attention_mask"]), max_new_tokens=n, min_new_tokens=n)
+    assert np.array_equal(ids.cpu().numpy(), g["fp32_greedy_free"])
+
+
+def test_vision_model_standalone_and_text_only(golden_dir):
+    from eilev_amd.model.v2 import VideoBlipVisionModel
+
+    g, meta, px = load_case(golden_dir, "mid_b1")
+    cfg = blip2_config("mid")
+    vm = VideoBlipVisionModel(cfg.vision_config)
+    sd = {k[len("vision_model."):]: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items() if k.startswith("vision_model.")}
+    vm.load_state_dict(sd)
+    vm = vm.cuda()
+    o = vm(torch.from_numpy(px).cuda(), return_dict=True)
+    assert rel_rms(host(o.last_hidden_state), g["fp32_vit"]) <= 1e-2
+    assert rel_rms(host(o.pooler_output), g["fp32_pooler"]) <= 1e-2
+    with pytest.raises(ValueError):
+        vm(None)
+    # text-only call (no pixel_values): plain OPT forward
+    m = build("mid", torch.float32)
+    ids = torch.randint(4, 500, (2, 9)).cuda()
+    out = m(input_ids=ids)
+    assert out.logits.shape == (2, 9, cfg.text_config.vocab_size) and out.vision_outputs is None
+
+
+def test_engine_tracks_parameter_updates():
+    m = build("mid", torch.float32)
+    ids = torch.randint(4, 500, (1, 6)).cuda()
+    a = m(input_ids=ids).logits
+    with torch.no_grad():
+        m.language_model.model.decoder.final_layer_norm.bias.add_(0.5)
+    b = m(input_ids=ids).logits
+    assert not torch.equal(a, b)
