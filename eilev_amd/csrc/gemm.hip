@@ -27,6 +27,27 @@ constexpr int BK = 64;  // bf16 elements per K-step = one 128-byte LDS row
 // slots of the 256-byte bank row, for the 32-row fragment pattern of the 32x32x16 MFMA.
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ ((row >> 1) & 7)) << 4; }
 
+// Workgroup -> tile map.  (1) XCD-aware: block b runs on XCD b % 8, so each XCD (private 4 MiB L2) gets a
+// contiguous range of the tile order.  (2) Grouped order: consecutive tiles walk down GROUP_M tile rows before
+// moving to the next tile column, so the ~32-64 tiles an XCD runs concurrently form a compact 2-D block and
+// share A row-panels and W column-panels through its L2 (the K-slices they stream are in step).
+__device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int tiles_n, int &tm, int &tn) {
+    const int nwg = tiles_m * tiles_n;
+    int t = blockIdx.x;
+    const int xcd = t & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    if (g.dbg & 256) {  // probe: plain row-major order
+        tm = t / tiles_n;
+        tn = t % tiles_n;
+        return;
+    }
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * tiles_n, group = t / width, first = group * GROUP_M;
+    const int gsz = min(tiles_m - first, GROUP_M), in = t - group * width;
+    tm = first + in % gsz;
+    tn = in / gsz;
+}
+
 template <int WM, int WN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[WM / 32][WN / 32], char *smem, int m0, int n0,
                                               int wm, int wn, int wid, int lane) {
@@ -158,16 +179,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // ---- tile id: XCD-aware remap (block b runs on XCD b % 8; give each XCD a contiguous tile range)
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    // n fastest: consecutive workgroups of one XCD share the A row-panel, W streams through L2/MALL
-    const int tm_i = bid / tiles_n, tn_i = bid % tiles_n;
+    int tm_i, tn_i;
+    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
     const int m0 = tm_i * BM, n0 = tn_i * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW>
+template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW, int PRIO>
 __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int NW = NWM * NWN;
     constexpr int WM = BM / NWM, WN = BN / NWN;
@@ -273,14 +286,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm_i = bid / tiles_n, tn_i = bid % tiles_n;
+    int tm_i, tn_i;
+    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
     const int m0 = tm_i * BM, n0 = tn_i * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     auto compute = [&](int buf) {
         const char *sa = smem + buf * STAGE + (wm * WM) * 128;
         const char *sb = smem + buf * STAGE + BM * 128 + (wn * WN) * 128;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 bfr[TN];
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
             }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     const int nkd = (g.dbg & 2) ? 1 : nk;
     if (NSTAGE == 2) {
@@ -373,6 +382,123 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
 }
 
+// ---- BK = 32 variant: two 24 KiB stages so that TWO 256x128 workgroups fit one CU -----------------------
+// (the second workgroup's MFMAs fill the first one's barrier stalls and its store-bound epilogue).  LDS rows
+// are 64 bytes (32 bf16 = 4 chunks); chunk c of row r is stored at c ^ ((r >> 2) & 3), which keeps the 16
+// lanes of every ds_read_b128 service group on 16 distinct 16-byte slots for the 32-row fragment pattern.
+__device__ __forceinline__ int swz32(int row, int c) { return (c ^ ((row >> 2) & 3)) << 4; }
+
+template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
+__global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds32_kernel(const GemmArgs g) {
+    constexpr int NW = NWM * NWN, KB = 32;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PC = BM / 16 / NW, B_PC = BN / 16 / NW;  // 1-KiB pieces (16 rows x 64 B) per wave per K-step
+    constexpr int STAGE = (BM + BN) * 64;
+    static_assert(A_PC >= 1 && B_PC >= 1 && WN == 64, "unsupported geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    int tm_i, tn_i;
+    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nk = g.K / KB;
+
+    const bf16 *pa[A_PC], *pb[B_PC];
+    const int prow = lane >> 2, pslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < A_PC; ++i) {
+        const int row = (wid * A_PC + i) * 16 + prow;
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 2) & 3)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PC; ++i) {
+        const int row = (wid * B_PC + i) * 16 + prow;
+        int gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 2) & 3)) << 3);
+    }
+    auto stage_in = [&](int buf, int kt) {
+        char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
+        char *sb = smem + buf * STAGE + BM * 64 + (wid * B_PC) * 1024;
+#pragma unroll
+        for (int i = 0; i < A_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * KB), (lds_void *)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * KB), (lds_void *)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_in(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nkd = (g.dbg & 2) ? 1 : nk;
+    for (int kt = 0; kt < nkd; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage_in(cur ^ 1, kt + 1);
+        const char *sa = smem + cur * STAGE + (wm * WM) * 64;
+        const char *sb = smem + cur * STAGE + BM * 64 + (wn * WN) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[TN];
+            const int kc = ks * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
+}
+
+template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
+int launch_glds32_e(const GemmArgs &g, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int stages = 2 * (BM + BN) * 64, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
+    constexpr int smem = stages > epi ? stages : epi;
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds32_kernel<BM, BN, NWM, NWN, EPI, MINW>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_glds32_kernel<BM, BN, NWM, NWN, EPI, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+template <int BM, int BN, int NWM, int NWN, int MINW>
+int launch_glds32(const GemmArgs &g, hipStream_t s) {
+    if (g.epi == 1) return launch_glds32_e<BM, BN, NWM, NWN, 1, MINW>(g, s);
+    if (g.epi == 2) return launch_glds32_e<BM, BN, NWM, NWN, 2, MINW>(g, s);
+    return launch_glds32_e<BM, BN, NWM, NWN, 0, MINW>(g, s);
+}
+
 // ---- ping-pong schedule (8 waves, K % 64 == 0) ------------------------------------------------------
 // A CU has 4 SIMDs; waves w and w + 4 of a workgroup share one.  The K-step is cut into 4 intervals
 // (read fragments of half 0 | 16 MFMAs | read half 1 | 16 MFMAs) separated by raw s_barriers, and the upper
@@ -393,14 +519,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_pp_kernel(const Gem
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm_i = bid / tiles_n, tn_i = bid % tiles_n;
+    int tm_i, tn_i;
+    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
     const int m0 = tm_i * BM, n0 = tn_i * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -677,7 +797,7 @@ __global__ void skinny_reduce_kernel(const SkinnyArgs a) {
     skinny_epilogue(g, row, col, v);
 }
 
-template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW>
+template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW, int PRIO = 0>
 int launch_tiled_e(const GemmArgs &g, hipStream_t s) {
     static bool attr_set = false;
     constexpr int stages = NSTAGE * (BM + BN) * 128, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
@@ -685,14 +805,14 @@ int launch_tiled_e(const GemmArgs &g, hipStream_t s) {
     constexpr int smem_nt = 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi;
     const bool fast = (g.K % BK) == 0 && !(g.dbg & 4);
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW>),
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW, PRIO>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_kernel<BM, BN, NWM, NWN, EPI>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem_nt));
         attr_set = true;
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    if (fast) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
+    if (fast) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW, PRIO>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NWM, NWN, EPI>), dim3(tiles), dim3(64 * NWM * NWN), smem_nt, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
@@ -720,11 +840,11 @@ int launch_pp(const GemmArgs &g, hipStream_t s) {
     return launch_pp_e<BM, BN, NWM, NWN, 0, MINW>(g, s);
 }
 
-template <int BM, int BN, int NWM, int NWN, int NSTAGE, int MINW>
+template <int BM, int BN, int NWM, int NWN, int NSTAGE, int MINW, int PRIO = 0>
 int launch_tiled(const GemmArgs &g, hipStream_t s) {
-    if (g.epi == 1) return launch_tiled_e<BM, BN, NWM, NWN, 1, NSTAGE, MINW>(g, s);
-    if (g.epi == 2) return launch_tiled_e<BM, BN, NWM, NWN, 2, NSTAGE, MINW>(g, s);
-    return launch_tiled_e<BM, BN, NWM, NWN, 0, NSTAGE, MINW>(g, s);
+    if (g.epi == 1) return launch_tiled_e<BM, BN, NWM, NWN, 1, NSTAGE, MINW, PRIO>(g, s);
+    if (g.epi == 2) return launch_tiled_e<BM, BN, NWM, NWN, 2, NSTAGE, MINW, PRIO>(g, s);
+    return launch_tiled_e<BM, BN, NWM, NWN, 0, NSTAGE, MINW, PRIO>(g, s);
 }
 
 }  // namespace
@@ -764,15 +884,18 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     const int force = (g.dbg >> 4) & 7;  // probe-only override of the tile choice
     const int64_t tm256 = ceil_div64(g.M, 256);
     int cfg;
-    if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;        // 256x256, 2 LDS stages, 1 WG/CU
-    else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;                   // 256x128, 1 stage, 2 WG/CU (N = 1408 / 1536)
+    if (g.M >= 16384 && tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;       // 256x128, 1 LDS stage, 2 WG/CU: every ViT GEMM
+    else if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;   // 256x256, 2 LDS stages, 1 WG/CU: OPT prefill
+    else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;
     else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
     else cfg = 4;                                                            // 128x128
     if (force) cfg = force;
-    if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
+    if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
+    else if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
     else if (cfg == 6 && g.K % BK == 0) rc = launch_pp<256, 128, 4, 2, 2>(g, s);
     else if (cfg == 1 || cfg == 5) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
-    else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4>(g, s);
+    else if (cfg == 3 && (g.dbg & 512)) rc = launch_tiled<256, 128, 4, 2, 1, 4, 0>(g, s);
+    else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
     else if (cfg == 2 || cfg == 6) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
     else rc = launch_tiled<128, 128, 2, 2, 2, 2>(g, s);
     if (prof_kind >= 0) prof_end(s);
