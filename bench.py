@@ -192,10 +192,13 @@ def main():
              3: "gemm_nt ViT qkv (+bias) [34952x4224x1408]", 4: "gemm_nt ViT proj (+bias+residual) [34952x1408x1408]"}
     best = None
     tot_ms = 0.0
+    per_kind = {}
     for kd, nm in kinds.items():
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         eng.lib.eilev_prof_collect(kd, C.byref(n), C.byref(ms), C.byref(fl))
         tot_ms += ms.value
+        if n.value:
+            per_kind[nm.split(" [")[0].replace("gemm_nt ViT ", "")] = [round(1e3 * ms.value / n.value, 1), round(fl.value / ms.value / 1e9, 1)]
         if n.value and (best is None or ms.value > best[2]):
             best = (nm, n.value, ms.value, fl.value)
     eng.lib.eilev_prof_enable(0)
@@ -220,7 +223,8 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                                "launches": int(n), "avg_launch_ms": round(ms / n, 4),
-                               "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2)}
+                               "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
+                               "vit_gemm_us_and_tflops": per_kind}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

@@ -884,9 +884,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     const int force = (g.dbg >> 4) & 7;  // probe-only override of the tile choice
     const int64_t tm256 = ceil_div64(g.M, 256);
     int cfg;
-    if (g.M >= 16384 && tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;       // 256x128, 1 LDS stage, 2 WG/CU: every ViT GEMM
-    else if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;   // 256x256, 2 LDS stages, 1 WG/CU: OPT prefill
-    else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;
+    if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;        // 256x256, 2 LDS stages, 1 WG/CU
+    else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;                   // 256x128, 1 stage, 2 WG/CU (N = 1408 / 1536)
     else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
     else cfg = 4;                                                            // 128x128
     if (force) cfg = force;
