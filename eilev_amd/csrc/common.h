@@ -56,19 +56,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far
-// below the bf16 rounding of the stored activation): 1 rcp + 1 exp + 5 fma instead of libm's erff,
-// which keeps the 128-accumulator GEMM epilogue in registers.
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below
+// the bf16 rounding of the stored activation), rearranged as max(x, 0) - |x| * t * P(t) * exp(-x^2 / 2)
+// with t = 1 / (1 + p |x| / sqrt 2): 2 transcendentals + 10 VALU ops, no libm call (libm's erff in a
+// 128-accumulator epilogue spills to scratch).
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = 0.5f * 1.061405429f;
+    p = fmaf(p, t, -0.5f * 1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, -0.5f * 0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2 / 2)
+    return fmaf(-(p * t), ax * e, fmaxf(x, 0.0f));
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

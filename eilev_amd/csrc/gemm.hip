@@ -31,9 +31,8 @@ __device__ __forceinline__ int swz(int row, int c) { return (c ^ ((row >> 1) & 7
 // contiguous range of the tile order.  (2) Grouped order: consecutive tiles walk down GROUP_M tile rows before
 // moving to the next tile column, so the ~32-64 tiles an XCD runs concurrently form a compact 2-D block and
 // share A row-panels and W column-panels through its L2 (the K-slices they stream are in step).
-__device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int tiles_n, int &tm, int &tn) {
+__device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int tiles_n, int &tm, int &tn, int t = blockIdx.x) {
     const int nwg = tiles_m * tiles_n;
-    int t = blockIdx.x;
     const int xcd = t & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
     if (g.dbg & 256) {  // probe: plain row-major order
@@ -48,19 +47,24 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
     tn = in / gsz;
 }
 
-template <int WM, int WN, int EPI>
+// Epilogue shared by every tiled kernel.  acc[i][j][reg] = C[m = i*32 + (lane & 31)][n = j*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)].
+// bf16 output: each wave stages its rows [IBEG*32, IEND*32) x WN in a private LDS region so that HBM sees whole
+// 128-byte row segments, 16 bytes per lane (2-byte stores straight from the MFMA layout cost as much as the K
+// loop): (a) residual rows -> LDS (coalesced); (b) acc + bias, activation, + residual -> bf16 in place;
+// (c) rows -> HBM.  Only the owning wave touches its region: no workgroup barrier.  The rare variants (fp32
+// logits, q pre-scaling, patch-embedding row remap, tile tails) are wave-uniform branches around the hot path.
+template <int WM, int WN, int EPI, int IBEG = 0, int IEND = WM / 32>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[WM / 32][WN / 32], char *smem, int m0, int n0,
                                               int wm, int wn, int wid, int lane) {
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TN = WN / 32;
     constexpr int RS = WN * 2 + 8;  // staging row stride (bytes)
+    constexpr int ROWS = (IEND - IBEG) * 32;
     const int l31 = lane & 31, hi = lane >> 5;
-    // ---- epilogue -------------------------------------------------------------------------------------
-    // (Every index into acc[][] must be a compile-time constant or the array is demoted to scratch.)
     const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
     if (g.out_f32) {
         // fp32 output (logits): a lane's 4 consecutive n are one 16-byte store
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = IBEG; i < IEND; ++i) {
             const int row = wrow0 + i * 32 + l31;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -84,54 +88,81 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
         }
         return;
     }
-    // bf16 output: each wave stages its WM x WN sub-tile in a private LDS region (the K-loop stages are
-    // dead after the last barrier) so that HBM sees whole 128-byte row segments, 16 bytes per lane —
-    // 2-byte scattered stores from the MFMA layout cost as much as the K-loop itself.
-    // (a) residual rows -> LDS (coalesced); (b) acc + bias, activation, + residual -> bf16 in place;
-    // (c) rows -> HBM.  Only this wave touches its region: no workgroup barrier needed.
-    char *reg = smem + wid * (WM * RS);
+    if (g.dbg & 1024) {  // probe: no epilogue at all (keep acc alive)
+        float keep = 0.0f;
+#pragma unroll
+        for (int i = IBEG; i < IEND; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keep += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+        if (keep == 123.456f) reinterpret_cast<float *>(g.C)[0] = keep;
+        return;
+    }
+    char *reg = smem + wid * (ROWS * RS);
+    const int wrow1 = wrow0 + IBEG * 32;            // first global row of this pass
     const int srow = lane >> 3, schunk = lane & 7;  // row-major phases: 8 lanes per 128-byte row segment
     const bool patch = g.patch_group > 0;
-    if (g.resid) {
+    const bool interior = wrow1 + ROWS <= g.M && wcol0 + WN <= g.N && !patch && !(g.dbg & 1);
+    const bool has_res = g.resid != nullptr;
+    const bool has_scale = g.scale_cols > 0;
+    // (a) residual rows -> LDS
+    if (has_res) {
+        if (interior) {
+            const bf16 *rp = g.resid + (int64_t)(wrow1 + srow) * g.ldr + wcol0 + schunk * 8;
+            char *dp = reg + srow * RS + schunk * 16;
 #pragma unroll 4
-        for (int it = 0; it < WM / 8; ++it) {
-            const int lr = it * 8 + srow, row = wrow0 + lr, col = wcol0 + schunk * 8;
-            bf16x8 v = zero8();
-            if (row < g.M && col < g.N) {
-                const int64_t rrow = patch ? 1 + (row % g.patch_group) : row;
-                v = *reinterpret_cast<const bf16x8 *>(g.resid + rrow * g.ldr + col);
+            for (int it = 0; it < ROWS / 8; ++it) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(rp);
+                bf16x4 *d = reinterpret_cast<bf16x4 *>(dp);
+                d[0] = (bf16x4){v[0], v[1], v[2], v[3]};
+                d[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+                rp += 8 * g.ldr;
+                dp += 8 * RS;
             }
-            bf16x4 *d = reinterpret_cast<bf16x4 *>(reg + lr * RS + schunk * 16);
-            d[0] = (bf16x4){v[0], v[1], v[2], v[3]};
-            d[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll 2
+            for (int it = 0; it < ROWS / 8; ++it) {
+                const int lr = it * 8 + srow, row = wrow1 + lr, col = wcol0 + schunk * 8;
+                bf16x8 v = zero8();
+                if (row < g.M && col < g.N) {
+                    const int64_t rrow = patch ? 1 + (row % g.patch_group) : row;
+                    v = *reinterpret_cast<const bf16x8 *>(g.resid + rrow * g.ldr + col);
+                }
+                bf16x4 *d = reinterpret_cast<bf16x4 *>(reg + lr * RS + schunk * 16);
+                d[0] = (bf16x4){v[0], v[1], v[2], v[3]};
+                d[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+            }
         }
     }
+    // (b) acc -> bf16 (+ bias, activation, residual) at [row][col] of the staging region
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int lc = j * 32 + q * 8 + hi * 4, col = wcol0 + lc;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f};
-            if (col < g.N) {
-                if (g.bias) {
-                    const bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(g.bias + col);
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias && col < g.N) {
+                const bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(g.bias + col);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
-                }
+                for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
+            }
+            float sc[4] = {1.f, 1.f, 1.f, 1.f};
+            if (has_scale) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sc[e] = (col + e) < g.scale_cols ? g.scale : 1.0f;
             }
+            char *cp = reg + l31 * RS + lc * 2;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                bf16x4 *cell = reinterpret_cast<bf16x4 *>(reg + (i * 32 + l31) * RS + lc * 2);
+            for (int i = IBEG; i < IEND; ++i) {
+                bf16x4 *cell = reinterpret_cast<bf16x4 *>(cp + (i - IBEG) * 32 * RS);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = (acc[i][j][q * 4 + e] + bv[e]) * sc[e];
+                    v[e] = acc[i][j][q * 4 + e] + bv[e];
+                    if (has_scale) v[e] *= sc[e];
                     if (EPI == 1) v[e] = gelu_erf(v[e]);
                     else if (EPI == 2) v[e] = fmaxf(v[e], 0.0f);
                 }
-                if (g.resid) {
+                if (has_res) {
                     const bf16x4 r4 = *cell;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
@@ -140,9 +171,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
             }
         }
     }
+    if (g.dbg & 2048) return;  // probe: no store phase
+    // (c) rows -> HBM
+    if (interior) {
+        bf16 *dp = reinterpret_cast<bf16 *>(g.C) + (int64_t)(wrow1 + srow) * g.ldc + wcol0 + schunk * 8;
+        const char *sp0 = reg + srow * RS + schunk * 16;
 #pragma unroll 4
-    for (int it = 0; it < WM / 8; ++it) {
-        const int lr = it * 8 + srow, row = wrow0 + lr, col = wcol0 + schunk * 8;
+        for (int it = 0; it < ROWS / 8; ++it) {
+            const bf16x4 *sp = reinterpret_cast<const bf16x4 *>(sp0);
+            const bf16x4 lo = sp[0], hi4 = sp[1];
+            *reinterpret_cast<bf16x8 *>(dp) = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            dp += 8 * g.ldc;
+            sp0 += 8 * RS;
+        }
+        return;
+    }
+#pragma unroll 2
+    for (int it = 0; it < ROWS / 8; ++it) {
+        const int lr = it * 8 + srow, row = wrow1 + lr, col = wcol0 + schunk * 8;
         if (row < g.M && col < g.N && !((g.dbg & 1) && row > 0)) {
             const bf16x4 *sp = reinterpret_cast<const bf16x4 *>(reg + lr * RS + schunk * 16);
             const bf16x4 lo = sp[0], hi4 = sp[1];
@@ -275,6 +321,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
+// One 1-KiB LDS-DMA piece through a buffer descriptor: lane i fetches 16 bytes at base + voff + soff and the wave
+// writes 64 x 16 bytes linearly at `dst` (wave-uniform).  Non-template helper on purpose: with ROCm 7.2 the host
+// pass silently drops the stub of a kernel TEMPLATE that calls this builtin in a dependent context.
+__device__ __forceinline__ void lds_dma16(const void *base, char *dst, unsigned voff, int soff) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 16, voff, soff, 0, 0);
+}
+
 template <int BM, int BN, int NWM, int NWN, int EPI, int NSTAGE, int MINW, int PRIO>
 __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int NW = NWM * NWN;
@@ -296,32 +350,33 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = g.K / BK;
 
-    // per-lane source pointers of this wave's pieces (advance by 64 elements per K-step)
-    const bf16 *pa[A_PC], *pb[B_PC];
+    // per-lane byte offsets of this wave's pieces; the LDS-DMA goes through buffer descriptors (one s_mov m0 +
+    // one buffer_load ... lds per piece, K advance in the scalar offset: no 64-bit VALU address arithmetic)
+    unsigned pa[A_PC], pb[B_PC];
     const int prow = lane >> 3, pslot = lane & 7;
 #pragma unroll
     for (int i = 0; i < A_PC; ++i) {
         const int row = (wid * A_PC + i) * 8 + prow;  // tile row of this lane's LDS slot
         int gr = m0 + row;
         gr = gr < g.M ? gr : g.M - 1;
-        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 1) & 7)) << 3);
+        pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PC; ++i) {
         const int row = (wid * B_PC + i) * 8 + prow;
         int gr = n0 + row;
         gr = gr < g.N ? gr : g.N - 1;
-        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 1) & 7)) << 3);
+        pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
     }
     auto stage_in = [&](int buf, int kt) {
         char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
         char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
 #pragma unroll
         for (int i = 0; i < A_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * BK), (lds_void *)(sa + i * 1024), 16, 0, 0);
+            lds_dma16(g.A, sa + i * 1024, pa[i], kt * (BK * 2));
 #pragma unroll
         for (int i = 0; i < B_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * BK), (lds_void *)(sb + i * 1024), 16, 0, 0);
+            lds_dma16(g.W, sb + i * 1024, pb[i], kt * (BK * 2));
     };
 
     f32x16 acc[TM][TN];
@@ -629,6 +684,305 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_pp_kernel(const Gem
     gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
 }
 
+// ---- ping-pong schedule on HALF K-steps (256x256 tile, 8 waves, K % 64 == 0) -------------------------------
+// The K dimension is consumed in halves of 32 (H_0, H_1, ...), each living in one of FOUR 32-KiB LDS
+// half-buffers (A 256x32 + W 256x32, 64-byte rows, swz32).  Every wave alternates
+//     R#n : read the fragments of H_n (12 x ds_read_b128), issue its 4 LDS-DMA pieces of H_{n+2} (the buffer
+//           H_{n-2} vacated), lgkmcnt(0), vmcnt(4) (= the pieces it issued in R#(n-1), i.e. H_{n+1}, have
+//           landed), s_barrier
+//     M#n : 16 MFMAs on those fragments, s_barrier
+// and the upper four waves run one barrier late, so on every SIMD one wave is always in an M interval while its
+// partner is in an R interval: MFMA issue, LDS reads and DMA issue overlap instead of alternating.  Safety:
+// H_{n+2} overwrites the buffer of H_{n-2}, whose last reader finished >= 1 barrier earlier with lgkmcnt(0);
+// H_{n+1} is complete on every wave before the barrier that precedes its first reader (proof in DESIGN.md).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int HALF = (BM + BN) * 64;  // bytes per half-buffer
+    constexpr int PC = 2;                  // 1-KiB pieces (16 rows x 64 B) per wave per operand per half
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm_i, tn_i;
+    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nh = g.K / 32;  // number of halves (even)
+    const bool late = wid >= NW / 2;
+
+    const bf16 *pa[PC], *pb[PC];
+    const int prow = lane >> 2, pslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+        const int row = (wid * PC + i) * 16 + prow;
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 2) & 3)) << 3);
+        gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 2) & 3)) << 3);
+    }
+    auto stage_half = [&](int n) {  // DMA of H_n into half-buffer n % 4
+        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
+        char *sb = sa + BM * 64;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + n * 32), (lds_void *)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + n * 32), (lds_void *)(sb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read_half = [&](int n) {
+        const char *sa = smem + (n & 3) * HALF + (wm * WM) * 64;
+        const char *sb = smem + (n & 3) * HALF + BM * 64 + (wn * WN) * 64;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kc = k2 * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
+            }
+        }
+    };
+    auto mma_half = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER()                       \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    stage_half(0);
+    stage_half(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (late) PP_BARRIER();
+
+    const int nhd = (g.dbg & 2) ? 2 : nh;
+    for (int n = 0; n < nhd; ++n) {
+        // R#n
+        read_half(n);
+        if (n + 2 < nh) {
+            stage_half(n + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");  // reads done; H_{n+1} (issued in R#(n-1)) landed
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        // M#n
+        mma_half();
+        PP_BARRIER();
+    }
+    if (!late) PP_BARRIER();
+#undef PP_BARRIER
+
+    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
+}
+
+// ---- persistent form of the half-K-step ping-pong kernel --------------------------------------------------
+// One workgroup per CU walks tiles t = blockIdx.x, + gridDim.x, ...  What the per-tile launch form pays once
+// per tile — workgroup dispatch, the cold first DMA (~2 us of exposed latency), the store-bound tail of the
+// epilogue — is overlapped here: the first two halves of the NEXT tile are DMA'd into half-buffers 0/1 as soon
+// as the K loop ends, while the epilogue runs out of the other half of LDS (two passes of 64 rows per wave:
+// 69.6 KB at offset 64 KB), and the epilogue's global stores drain under the next tile's first K-steps.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int HALF = (BM + BN) * 64;
+    constexpr int PC = 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nh = g.K / 32;
+    const bool late = wid >= NW / 2;
+    const int prow = lane >> 2, pslot = lane & 3;
+
+    // LDS-DMA through buffer descriptors: one s_mov m0 + one buffer_load ... lds per 1-KiB piece, the K advance is
+    // a scalar offset — no per-piece 64-bit VALU address arithmetic (global_load_lds costs ~100+ issue cycles each)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
+    unsigned pa[PC], pb[PC];  // per-lane byte offsets of this wave's pieces (row * ld * 2 + swizzled chunk * 16)
+    auto set_tile = [&](int t, int &m0, int &n0) {
+        int tm_i, tn_i;
+        tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
+        m0 = tm_i * BM;
+        n0 = tn_i * BN;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int row = (wid * PC + i) * 16 + prow;
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
+            gr = n0 + row;
+            gr = gr < g.N ? gr : g.N - 1;
+            pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
+        }
+    };
+    auto stage_half = [&](int n) {
+        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
+        char *sb = sa + BM * 64;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + i * 1024), 16, pa[i], n * 64, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], n * 64, 0, 0);
+        }
+    };
+    f32x16 acc[TM][TN];
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read_half = [&](int n) {
+        const char *sa = smem + (n & 3) * HALF + (wm * WM) * 64;
+        const char *sb = smem + (n & 3) * HALF + BM * 64 + (wn * WN) * 64;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kc = k2 * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
+            }
+        }
+    };
+    auto mma_half = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER()                       \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    int t = blockIdx.x, m0, n0;
+    if (t >= ntiles) return;
+    set_tile(t, m0, n0);
+    stage_half(0);
+    stage_half(1);
+    for (; t < ntiles; t += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // H_0 / H_1 of this tile were issued by the prologue above or by the previous tile's tail; the wait also
+        // covers the previous epilogue's stores, and the barrier its LDS staging reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        if (late) PP_BARRIER();
+        const int nhd = (g.dbg & 2) ? 2 : nh;
+        for (int n = 0; n < nhd; ++n) {
+            if (!(g.dbg & 16384) || n == 0) read_half(n);
+            if (n + 2 < nh) {
+                if (!(g.dbg & 32768)) stage_half(n + 2);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_BARRIER();
+            mma_half();
+            PP_BARRIER();
+        }
+        if (!late) PP_BARRIER();
+        // every wave has finished reading every half-buffer: start the next tile's first two halves, then store
+        const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
+        if (tn < ntiles) {
+            set_tile(tn, m0, n0);
+            stage_half(0);
+            stage_half(1);
+        }
+        gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + 2 * HALF, cm0, cn0, wm, wn, wid, lane);
+        gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + 2 * HALF, cm0, cn0, wm, wn, wid, lane);
+    }
+#undef PP_BARRIER
+}
+
+int launch_pp3(const GemmArgs &g, hipStream_t s) {
+    static bool attr_set = false;
+    static int num_cu = 0;
+    constexpr int smem = 2 * 32768 + 8 * 64 * (64 * 2 + 8);  // half-buffers 0/1 + epilogue staging (which overlays 2/3)
+    static_assert(smem >= 4 * 32768, "staging must cover half-buffers 2 and 3");
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int dev = 0;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp3_kernel<1>, dim3(grid), dim3(512), smem, s, g);
+    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp3_kernel<2>, dim3(grid), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL(gemm_pp3_kernel<0>, dim3(grid), dim3(512), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
+int launch_pp2(const GemmArgs &g, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int smem = 8 * 128 * (64 * 2 + 8);  // 4 half-buffers = 128 KiB < epilogue staging 139264 B
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp2_kernel<1>, dim3(tiles), dim3(512), smem, s, g);
+    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp2_kernel<2>, dim3(tiles), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL(gemm_pp2_kernel<0>, dim3(tiles), dim3(512), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 // ---- skinny GEMM (M <= 16): weight-streaming, one 16-row block of W per workgroup ----------------
 // grid = (ceil(N/16), KS).  Each of the 4 waves owns a contiguous slice of this workgroup's K range;
 // per K-step of 32 a lane loads 16 B of W (row n0 + lane%16, k-group lane/16) and 16 B of A (batch row
@@ -803,7 +1157,7 @@ int launch_tiled_e(const GemmArgs &g, hipStream_t s) {
     constexpr int stages = NSTAGE * (BM + BN) * 128, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
     constexpr int smem = stages > epi ? stages : epi;
     constexpr int smem_nt = 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi;
-    const bool fast = (g.K % BK) == 0 && !(g.dbg & 4);
+    const bool fast = (g.K % BK) == 0 && !(g.dbg & 4) && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll;
     if (!attr_set) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds_kernel<BM, BN, NWM, NWN, EPI, NSTAGE, MINW, PRIO>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -852,6 +1206,8 @@ int launch_tiled(const GemmArgs &g, hipStream_t s) {
 int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     GemmArgs g = g_in;
     g.dbg = g_gemm_debug;
+    if (g.dbg & 4096) g.lda = 0;   // probe: every A row aliases row 0 (cache-resident operand)
+    if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
     if (g.M <= 0) return EILEV_OK;
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
@@ -881,7 +1237,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
-    const int force = (g.dbg >> 4) & 7;  // probe-only override of the tile choice
+    const int force = (g.dbg >> 4) & 15;  // probe-only override of the tile choice
     const int64_t tm256 = ceil_div64(g.M, 256);
     int cfg;
     if (tm256 * ceil_div64(g.N, 256) >= 256 && g.N >= 2048) cfg = 1;        // 256x256, 2 LDS stages, 1 WG/CU
@@ -889,9 +1245,15 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
     else cfg = 4;                                                            // 128x128
     if (force) cfg = force;
-    if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
+    if (cfg == 0 && false) rc = 0;
+    else if ((g.dbg >> 4) == 8 && g.K % 64 == 0) rc = launch_pp2(g, s);
+    else if ((g.dbg >> 4) == 9 && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+        rc = launch_pp3(g, s);
+    else if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
     else if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
     else if (cfg == 6 && g.K % BK == 0) rc = launch_pp<256, 128, 4, 2, 2>(g, s);
+    else if (cfg == 1 && !force && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+        rc = launch_pp3(g, s);  // persistent half-K-step ping-pong kernel
     else if (cfg == 1 || cfg == 5) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3 && (g.dbg & 512)) rc = launch_tiled<256, 128, 4, 2, 1, 4, 0>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
