@@ -1246,8 +1246,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else cfg = 4;                                                            // 128x128
     if (force) cfg = force;
     if (cfg == 0 && false) rc = 0;
-    else if ((g.dbg >> 4) == 8 && g.K % 64 == 0) rc = launch_pp2(g, s);
-    else if ((g.dbg >> 4) == 9 && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+    else if (((g.dbg >> 4) & 15) == 8 && g.K % 64 == 0) rc = launch_pp2(g, s);
+    else if (((g.dbg >> 4) & 15) == 9 && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp3(g, s);
     else if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
     else if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
