@@ -464,31 +464,31 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds32_kernel(const
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = g.K / KB;
 
-    const bf16 *pa[A_PC], *pb[B_PC];
+    unsigned pa[A_PC], pb[B_PC];
     const int prow = lane >> 2, pslot = lane & 3;
 #pragma unroll
     for (int i = 0; i < A_PC; ++i) {
         const int row = (wid * A_PC + i) * 16 + prow;
         int gr = m0 + row;
         gr = gr < g.M ? gr : g.M - 1;
-        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 2) & 3)) << 3);
+        pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PC; ++i) {
         const int row = (wid * B_PC + i) * 16 + prow;
         int gr = n0 + row;
         gr = gr < g.N ? gr : g.N - 1;
-        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 2) & 3)) << 3);
+        pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
     }
     auto stage_in = [&](int buf, int kt) {
         char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
         char *sb = smem + buf * STAGE + BM * 64 + (wid * B_PC) * 1024;
 #pragma unroll
         for (int i = 0; i < A_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * KB), (lds_void *)(sa + i * 1024), 16, 0, 0);
+            lds_dma16(g.A, sa + i * 1024, pa[i], kt * (KB * 2));
 #pragma unroll
         for (int i = 0; i < B_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * KB), (lds_void *)(sb + i * 1024), 16, 0, 0);
+            lds_dma16(g.W, sb + i * 1024, pb[i], kt * (KB * 2));
     };
 
     f32x16 acc[TM][TN];
