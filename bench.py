@@ -4,8 +4,8 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP = one pass of the hot path over one batch of synthetic input per GPU: `--samples` (default 8)
-16-shot samples = 8 x 17 clips x 8 frames of 224x224 pixels (bf16, resident in HBM) through ViT-g/14 ->
+One STEP = one pass of the hot path over one batch of synthetic input per GPU: `--samples` (default 16)
+16-shot samples = 16 x 17 clips x 8 frames of 224x224 pixels (bf16, resident in HBM) through ViT-g/14 ->
 Q-Former -> projection -> [all-gather of clip tokens when N > 1] -> embed+scatter -> OPT-2.7B prefill
 (L = 960) -> 32 greedy tokens (EOS disabled, decode under hipGraph).  Weak scaling: every rank gets its own
 `--samples` samples; clips of the global step are dealt round-robin over the ranks (eilev_amd/sharding.py).
@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=8, help="16-shot samples per GPU per step")
+    ap.add_argument("--samples", type=int, default=16, help="16-shot samples per GPU per step (<= 16: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
