@@ -220,8 +220,16 @@ def main():
         if best is not None:
             nm, n, ms, fl = best
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
+                with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
+                    tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
+                if tr:
+                    traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
+            except OSError:
+                pass
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "launches": int(n), "avg_launch_ms": round(ms / n, 4),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
