@@ -252,5 +252,51 @@ class HipEngine:
         return (ids, step_logits) if return_step_logits else ids
 
 
+    def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
+                    early_stopping=False, num_return_sequences=1):
+        """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
+
+        The prompt is prefilled ONCE per sample and its KV cache replicated to the beams; every step reorders the cache
+        rows by the surviving beams' parents (torch index_select: plumbing) and runs one HIP decode step on all rows."""
+        from .beam import beam_search
+
+        d = self.dims
+        B, L, _ = inputs_embeds.shape
+        R = B * num_beams
+        if R > 16:
+            raise NotImplementedError("batch * num_beams > 16 rows per decode call is not supported yet")
+        cap = L + max_new_tokens
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        last, _, kv_small = self.prefill(inputs_embeds, am, kv_capacity=cap)
+        planes = 2 * d.t_layers
+        kv = kv_small.view(planes, B, -1).repeat_interleave(num_beams, dim=1).contiguous()
+        del kv_small
+        am_r = am.repeat_interleave(num_beams, dim=0).contiguous()
+        n_valid = am_r.sum(dim=1).to(torch.int32).contiguous()
+        state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        finished = torch.zeros(R, dtype=torch.uint8, device=self.device)
+        tokens = torch.zeros(R, dtype=torch.int64, device=self.device)
+        scratch_out = torch.zeros((R, max_new_tokens), dtype=torch.int64, device=self.device)
+        logits = torch.empty((R, d.vocab), dtype=torch.float32, device=self.device)
+        nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), R, 1)
+        ws = self._workspace("dec", nb)
+        steps = [0]
+
+        def step(next_tokens, beam_src):
+            nonlocal kv
+            kv = kv.index_select(1, beam_src)  # row r continues the hypothesis that lived in row beam_src[r]
+            steps[0] += 1
+            state[0] = steps[0]               # tokens generated so far (the library reads it on the device)
+            tokens.copy_(next_tokens)
+            abi.check(self.lib.eilev_opt_decode_step(
+                C.byref(d), C.byref(self.pack.opt), _ptr(tokens), _ptr(state), _ptr(am_r), _ptr(n_valid), R, L, _ptr(kv), cap,
+                _ptr(logits), _ptr(finished), -1, pad_id, _ptr(scratch_out), max_new_tokens, _ptr(ws), ws.numel(),
+                self._stream()), "eilev_opt_decode_step")
+            return logits
+
+        return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
+                           num_return_sequences)
+
+
 def abi_dtype(t: torch.Tensor) -> int:
     return 0 if t.dtype == torch.float32 else 1

@@ -8,7 +8,7 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
-Not built yet (raise ``NotImplementedError``): beam search / sampling, the Flan-T5 language model, ``classify``,
+Not built yet (raise ``NotImplementedError``): sampling / contrastive decoding, the Flan-T5 language model, ``classify``,
 ``output_attentions`` / ``output_hidden_states``, and autograd through the HIP path (training).
 """
 from __future__ import annotations
@@ -253,9 +253,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         kw = dict(generate_kwargs)
         num_beams = kw.pop("num_beams", 1)
         do_sample = kw.pop("do_sample", False)
-        kw.pop("length_penalty", None)  # only affects beam search
-        if num_beams not in (None, 1) or do_sample:
-            raise NotImplementedError("only greedy decoding (num_beams=1, do_sample=False) is built on the HIP path so far")
+        length_penalty = kw.pop("length_penalty", 1.0)  # only affects beam search
+        early_stopping = kw.pop("early_stopping", False)
+        num_return = kw.pop("num_return_sequences", 1)
+        num_beams = 1 if num_beams is None else int(num_beams)
+        if do_sample or kw.get("penalty_alpha") or kw.get("num_beam_groups", 1) not in (None, 1):
+            raise NotImplementedError("sampling / contrastive / group-beam decoding is not built on the HIP path (greedy and beam search are)")
         max_new = kw.pop("max_new_tokens", None)
         if max_new is None:
             max_len = kw.pop("max_length", None)
@@ -286,6 +289,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         emb, _, _ = self._encode(pixel_values, input_ids, video_input_mask)
+        if num_beams > 1:
+            return self.engine().beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
+                                             eos_id=int(-1 if eos is None else eos), pad_id=int(pad), early_stopping=early_stopping,
+                                             num_return_sequences=int(num_return))
         return self.engine().greedy_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad))
 
     def classify(self, *args, **kwargs):

@@ -156,6 +156,46 @@ class OracleModel:
         return (ids, step_logits) if return_logits else ids
 
 
+    def generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1,
+                      pad_id=1, early_stopping=False):
+        """Beam search = reference generate(num_beams=k) with the oracle as the language model (eilev_amd.beam drives it)."""
+        import torch
+
+        from eilev_amd.beam import beam_search
+
+        d = self.dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        B, L, _ = emb.shape
+        R, cap = B * num_beams, L + max_new_tokens
+        am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        last, _, kv_small = self.prefill(emb, am, kv_capacity=cap, all_logits=False)
+        planes = 2 * d.t_layers
+        kv = [np.repeat(kv_small.reshape(planes, B, -1), num_beams, axis=1).copy()]
+        am_r = np.repeat(am, num_beams, axis=0).copy()
+        n_valid = am_r.sum(axis=1).astype(np.int32)
+        state = np.zeros(2, np.int32)
+        finished = np.zeros(R, np.uint8)
+        tokens = np.zeros(R, np.int64)
+        out = np.zeros((R, max_new_tokens), np.int64)
+        logits = np.empty((R, d.vocab), np.float32)
+        nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), R, 1)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        steps = [0]
+
+        def step(next_tokens, beam_src):
+            kv[0] = np.ascontiguousarray(kv[0][:, beam_src.numpy()])
+            steps[0] += 1
+            state[0] = steps[0]
+            tokens[:] = next_tokens.numpy()
+            abi.check(self.lib.eilev_opt_decode_step(C.byref(d), C.byref(self.pack.opt), _p(tokens), _p(state), _p(am_r), _p(n_valid),
+                                                     R, L, _p(kv[0]), cap, _p(logits), _p(finished), -1, pad_id, _p(out),
+                                                     max_new_tokens, _p(ws), nbytes, None), "oracle decode")
+            return torch.from_numpy(logits.copy())
+
+        ids = beam_search(step, torch.from_numpy(last.copy()), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping)
+        return ids.numpy()
+
+
 def abi_f32():
     return 0
 

@@ -98,3 +98,21 @@ def test_scatter_count_mismatch_is_an_error(models):
     vm = np.array([[0, 1, 1, 0, 0, 0]])
     with pytest.raises(RuntimeError):
         m.embed_scatter(ids, vm, np.zeros((3, m.dims.t_hidden), np.float32))
+
+
+BEAMS = [("beam5_lpm1", 5, -1.0), ("beam3_lp1", 3, 1.0)]
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tag,nb,lp", BEAMS)
+def test_beam_search_matches_reference(golden_dir, models, name, tag, nb, lp):
+    """eilev_amd.beam (host bookkeeping) + oracle LM == HF _beam_search through the reference's generate()."""
+    g, meta, cfg, px = load_case(golden_dir, name)
+    if f"fp32_{tag}" not in g.files:
+        pytest.skip("batch * beams > 16 rows")
+    m = models(meta["config"])
+    n = meta["new_tokens"]
+    ids = m.generate_beam(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, nb, lp, eos_id=int(g["fp32_eos_id"]))
+    assert np.array_equal(ids, g[f"fp32_{tag}"]), (ids, g[f"fp32_{tag}"])
+    free = m.generate_beam(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, nb, lp, eos_id=-1)
+    assert np.array_equal(free, g[f"fp32_{tag}_free"]), (free, g[f"fp32_{tag}_free"])

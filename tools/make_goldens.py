@@ -20,10 +20,18 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.append("/root/reference")  # reference package is named `eilev`; ours is `eilev_amd`
+
+import importlib.util  # noqa: E402
 
 import transformers  # noqa: E402
-from eilev.model.v2 import VideoBlipForConditionalGeneration as RefModel  # noqa: E402  (REFERENCE)
+
+# The REFERENCE class, loaded by file path (this repo also ships an `eilev` alias package, so a plain
+# `import eilev` would not reach /root/reference).
+_spec = importlib.util.spec_from_file_location("reference_eilev_model_v2", "/root/reference/eilev/model/v2.py")
+_ref = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_ref)
+RefModel = _ref.VideoBlipForConditionalGeneration
+assert RefModel.__module__ == "reference_eilev_model_v2"
 
 from eilev_amd.configs import CONFIGS, blip2_config  # noqa: E402
 from eilev_amd.synth import synth_interleaved_ids, synth_param, synth_pixels  # noqa: E402
@@ -111,6 +119,16 @@ def run_case(name):
                        do_sample=False, eos_token_id=eos)
         out[f"{tag}_greedy_eos"] = g.numpy().astype(np.int64)
         out[f"{tag}_eos_id"] = np.asarray(eos, dtype=np.int64)
+        # beam search as the sample script calls it (ref:samples/eilev_generate_action_narration.py:60-73), shorter budget
+        for nbm, lp, nm in ((5, -1.0, "beam5_lpm1"), (3, 1.0, "beam3_lp1")):
+            if len(rows) * nbm > 16:
+                continue
+            g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                           max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=eos)
+            out[f"{tag}_{nm}"] = g.numpy().astype(np.int64)
+            g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                           max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=never)
+            out[f"{tag}_{nm}_free"] = g.numpy().astype(np.int64)
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens,
                 weight_mode="fanin", torch=torch.__version__, transformers=transformers.__version__,
                 attn_implementation=str(getattr(cfg, "_attn_implementation", None)),
