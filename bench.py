@@ -188,8 +188,8 @@ def main():
         dt = float(t.item())
 
     # dominant kernel: the ViT GEMM family, timed with hipEvents on the launch stream during the timed region
-    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [34952x6144x1408]", 2: "gemm_nt ViT fc2 (+bias+residual) [34952x1408x6144]",
-             3: "gemm_nt ViT qkv (+bias) [34952x4224x1408]", 4: "gemm_nt ViT proj (+bias+residual) [34952x1408x1408]"}
+    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [M x 6144 x 1408, M = 257 tokens x 544 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
+             3: "gemm_nt ViT qkv (+bias) [M x 4224 x 1408]", 4: "gemm_nt ViT proj (+bias+residual) [M x 1408 x 1408]"}
     best = None
     tot_ms = 0.0
     per_kind = {}
@@ -224,8 +224,8 @@ def main():
             try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
                 with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
                     tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
-                if tr:
-                    traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
+                if tr:  # measured per 136-frame launch; the bench launches 544 frames at a time
+                    traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024 * 4)
             except OSError:
                 pass
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
