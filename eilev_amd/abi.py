@@ -165,7 +165,7 @@ class WeightPack:
 EXPORTS = [
     "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward",
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
-    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_greedy_select",
+    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect",
 ]
@@ -194,6 +194,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_opt_kv_cache_bytes.argtypes = [DP, i64, i64]
     lib.eilev_opt_prefill.restype = i32
     lib.eilev_opt_prefill.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.eilev_opt_extend.restype = i32
+    lib.eilev_opt_extend.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_greedy_select.restype = i32
     lib.eilev_greedy_select.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp, i64, vp]
     lib.eilev_opt_decode_step.restype = i32

@@ -141,9 +141,11 @@ __global__ __launch_bounds__(1024) void pos_ids_kernel(const int32_t *__restrict
 }
 
 __global__ __launch_bounds__(256) void add_pos_kernel(const bf16 *__restrict__ emb, const bf16 *__restrict__ pos,
-                                                      const int32_t *__restrict__ pid, bf16 *__restrict__ h, int d) {
-    const int64_t i = blockIdx.x;
-    const bf16 *e = emb + i * d, *p = pos + (int64_t)pid[i] * d;
+                                                      const int32_t *__restrict__ pid, bf16 *__restrict__ h, int d,
+                                                      int rows_per_b, int pid_ld, int pid_off) {
+    const int64_t i = blockIdx.x;  // row b * rows_per_b + r reads pid[b * pid_ld + pid_off + r]
+    const int64_t pb = i / rows_per_b, pr = i - pb * rows_per_b;
+    const bf16 *e = emb + i * d, *p = pos + (int64_t)pid[pb * pid_ld + pid_off + pr] * d;
     for (int c = threadIdx.x; c < (d >> 3); c += 256) {
         float x[8], y[8];
         unpack8(*reinterpret_cast<const bf16x8 *>(e + c * 8), x);
@@ -180,10 +182,10 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const bf16 *__restric
 // qkv: rows of 3*D (q | k | v).  Prefill: rows_per_b = L, slot0 = 0.  Decode: rows_per_b = 1, slot from state.
 __global__ __launch_bounds__(256) void kv_write_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc,
                                                        bf16 *__restrict__ vc, int rows_per_b, int heads, int hd, int cap,
-                                                       int seq_len, const int32_t *__restrict__ state) {
+                                                       int seq_len, const int32_t *__restrict__ state, int slot0) {
     const int64_t row = blockIdx.x;  // b * rows_per_b + r
     const int b = (int)(row / rows_per_b), r = (int)(row - (int64_t)b * rows_per_b);
-    const int slot = state ? (seq_len + state[0] - 1) : r;
+    const int slot = state ? (seq_len + state[0] - 1) : slot0 + r;
     const int d = heads * hd, ch = hd >> 3;
     const bf16 *src = qkv + row * 3 * (int64_t)d;
     for (int c = threadIdx.x; c < 2 * heads * ch; c += 256) {
@@ -397,10 +399,12 @@ int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *m
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
-int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s) {
+int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s,
+                     int past = 0) {
+    // mask / pid cover all L positions; the rows of emb / h are the last L - past positions of every sequence
     hipLaunchKernelGGL(pos_ids_kernel, dim3(batch), dim3(1024), 0, s, mask, pid, L);
     EILEV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(add_pos_kernel, dim3(batch * L), dim3(256), 0, s, emb, pos, pid, h, d);
+    hipLaunchKernelGGL(add_pos_kernel, dim3(batch * (L - past)), dim3(256), 0, s, emb, pos, pid, h, d, L - past, L, past);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
@@ -411,8 +415,8 @@ int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *token
     return EILEV_OK;
 }
 int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
-                    const int32_t *state, hipStream_t s) {
-    hipLaunchKernelGGL(kv_write_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, qkv, kc, vc, rows_per_b, heads, hd, cap, seq_len, state);
+                    const int32_t *state, hipStream_t s, int slot0 = 0) {
+    hipLaunchKernelGGL(kv_write_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, qkv, kc, vc, rows_per_b, heads, hd, cap, seq_len, state, slot0);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

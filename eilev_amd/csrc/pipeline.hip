@@ -12,11 +12,12 @@ int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_to
 int launch_broadcast_rows(const bf16 *src, bf16 *dst, int64_t copies, int64_t n, hipStream_t s);
 int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *mask, const bf16 *feats, int64_t n_rows,
                          int64_t total, int vocab, bf16 *out, int d, hipStream_t s);
-int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s);
+int launch_pos_embed(const bf16 *emb, const bf16 *pos, const int32_t *mask, int32_t *pid, bf16 *h, int batch, int L, int d, hipStream_t s,
+                     int past = 0);
 int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *tokens, const int32_t *n_valid, const int32_t *state,
                         int vocab, int max_pid, bf16 *h, int batch, int d, hipStream_t s);
 int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
-                    const int32_t *state, hipStream_t s);
+                    const int32_t *state, hipStream_t s, int slot0 = 0);
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
@@ -427,6 +428,47 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         RC(launch_gemm(g, 5, s));
     }
     return EILEV_OK;
+}
+
+extern "C" int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                                int64_t batch, int64_t new_len, int64_t past_len, void *kv_cache, int64_t kv_capacity,
+                                float *logits_all, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !inputs_embeds || !attn_mask || !kv_cache || !logits_all || !workspace || batch <= 0 || new_len <= 0 || past_len < 0)
+        return EILEV_E_BADARG;
+    const int64_t total = past_len + new_len;
+    if (total > kv_capacity || total > d->max_pos) return EILEV_E_BADARG;
+    if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_opt_workspace_bytes(d, batch, total)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->t_hidden, H = d->t_heads, hd = D / H;
+    const int64_t M = batch * new_len;
+    OptBufs b;
+    if (!carve_opt(d, batch * total, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    RC(launch_pos_embed((const bf16 *)inputs_embeds, (const bf16 *)w->embed_positions, attn_mask, b.pid, b.h, (int)batch, (int)total, D,
+                        s, (int)past_len));
+    const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    for (int l = 0; l < d->t_layers; ++l) {
+        const EilevOptLayer *L = &w->layers[l];
+        bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+        RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, M, D, d->t_eps, s));
+        RC(opt_qkv(d, L, b, M, s));
+        RC(launch_kv_write(b.qkv, kc, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)total, nullptr, s, (int)past_len));
+        // queries: the new rows (in the q|k|v buffer); keys / values: the cache, slots [0, total)
+        AttnArgs a;
+        a.q = b.qkv; a.k = kc; a.v = vc; a.o = b.att;
+        a.q_bs = new_len * 3 * (int64_t)D; a.o_bs = new_len * (int64_t)D;
+        a.k_bs = a.v_bs = (int64_t)H * kv_capacity * hd;
+        a.q_hs = a.o_hs = hd; a.k_hs = a.v_hs = kv_capacity * (int64_t)hd;
+        a.ldq = 3 * D; a.ldk = a.ldv = hd; a.ldo = D;
+        a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
+        a.key_mask = attn_mask; a.mask_ld = total; a.dbg = 0;
+        RC(launch_attention(a, s));
+        RC(opt_tail(d, L, b, M, s));
+    }
+    RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, M, D, d->t_eps, s));
+    GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits_all, d->vocab, M, d->vocab, D, 0);
+    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    return launch_gemm(g, 5, s);
 }
 
 extern "C" int eilev_greedy_select(const float *logits, int64_t batch, int64_t vocab, int32_t *state, uint8_t *finished,

@@ -53,7 +53,7 @@ class HipEngine:
         def part_of(key):
             if key.startswith("vision_model."):
                 return "vit"
-            if key.startswith("qformer.") or key == "query_tokens":
+            if key.startswith(("qformer.", "language_projection.")) or key == "query_tokens":
                 return "qf"
             return "opt"
 
@@ -179,6 +179,51 @@ class HipEngine:
         abi.check(self.lib.eilev_opt_prefill(C.byref(d), C.byref(self.pack.opt), _ptr(x), _ptr(am), B, L, _ptr(kv_cache), cap,
                                              _ptr(last), _ptr(alll), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_prefill")
         return last, alll, kv_cache
+
+    def extend(self, new_embeds, full_mask, past_len, kv_cache, kv_capacity):
+        """Run ``new_embeds`` (B, Ln, Dt) as positions past_len.. of sequences whose first ``past_len`` KV entries are in
+        ``kv_cache``; returns fp32 logits (B, Ln, vocab) [second LM call of classify(), ref:eilev/model/v2.py:461-466]."""
+        d = self.dims
+        x = new_embeds.contiguous()
+        B, Ln, _ = x.shape
+        am = full_mask.to(self.device, torch.int32).contiguous()
+        assert am.shape == (B, past_len + Ln)
+        out = torch.empty((B, Ln, d.vocab), dtype=torch.float32, device=self.device)
+        nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, past_len + Ln)
+        ws = self._workspace("opt", nb)
+        abi.check(self.lib.eilev_opt_extend(C.byref(d), C.byref(self.pack.opt), _ptr(x), _ptr(am), B, Ln, past_len, _ptr(kv_cache),
+                                            int(kv_capacity), _ptr(out), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_extend")
+        return out
+
+    def classify_loglik(self, prompt_embeds, prompt_mask, class_input_ids, class_attention_mask=None, class_batch_size=None):
+        """Mean log-likelihood of every class continuation after every prompt: (B, num_classes) fp32
+        [ref:eilev/model/v2.py:403-501].  The prompt is prefilled once; its KV cache is replicated per class chunk."""
+        d = self.dims
+        B, L, _ = prompt_embeds.shape
+        cls_ids = class_input_ids.to(self.device, torch.int64)
+        n_cls, Lc = cls_ids.shape
+        cls_mask = torch.ones_like(cls_ids) if class_attention_mask is None else class_attention_mask.to(self.device, torch.int64)
+        pm = prompt_mask.to(self.device, torch.int32).contiguous()
+        cap = L + Lc
+        last, _, kv = self.prefill(prompt_embeds, pm, kv_capacity=cap)
+        planes = 2 * d.t_layers
+        step = n_cls if class_batch_size is None else int(class_batch_size)
+        cols = []
+        for i in range(0, n_cls, step):
+            ids, msk = cls_ids[i:i + step], cls_mask[i:i + step]
+            nc = ids.shape[0]
+            rows_ids = ids.unsqueeze(0).expand(B, -1, -1).reshape(B * nc, Lc)
+            rows_msk = msk.unsqueeze(0).expand(B, -1, -1).reshape(B * nc, Lc)
+            full = torch.cat((pm.repeat_interleave(nc, dim=0), rows_msk.to(torch.int32)), dim=1)
+            kv_rows = kv.view(planes, B, -1).repeat_interleave(nc, dim=1).contiguous()
+            emb = self.embed_scatter(rows_ids, None, None)
+            logits = self.extend(emb, full, L, kv_rows, cap)
+            shift = torch.cat((last.repeat_interleave(nc, dim=0)[:, None], logits[:, :-1]), dim=1)
+            labels = torch.where(rows_msk != 0, rows_ids, torch.full_like(rows_ids, -100))
+            nll = torch.nn.functional.cross_entropy(shift.reshape(-1, d.vocab), labels.reshape(-1), reduction="none")
+            cols.append(-nll.view(B, nc, Lc).sum(-1) / msk.sum(-1).unsqueeze(0).to(torch.float32))
+            del kv_rows
+        return torch.cat(cols, dim=1)
 
     def greedy_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, use_graph=True,
                       poll_every=8, return_step_logits=False):

@@ -295,5 +295,16 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                              num_return_sequences=int(num_return))
         return self.engine().greedy_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad))
 
-    def classify(self, *args, **kwargs):
-        raise NotImplementedError("classify() (KV-cache fan-out log-likelihood, ref:eilev/model/v2.py:326-501) is a next-row item")
+    @torch.no_grad()
+    def classify(self, prompt_input_ids, class_input_ids, prompt_attention_mask=None, pixel_values=None,
+                 prompt_video_input_mask=None, class_attention_mask=None, class_batch_size=None):
+        """Mean log-likelihood of each class text after each (left-padded) prompt: (batch, num_classes)
+        [ref:eilev/model/v2.py:326-501].  Prompt prefilled once on the HIP path, class tokens continue its KV cache."""
+        assert self.config.use_decoder_only_language_model
+        if pixel_values is not None:
+            assert prompt_video_input_mask is not None
+        emb, _, _ = self._encode(pixel_values, prompt_input_ids, prompt_video_input_mask)
+        if prompt_attention_mask is None:
+            prompt_attention_mask = torch.ones_like(prompt_input_ids)
+        ll = self.engine().classify_loglik(emb, prompt_attention_mask, class_input_ids, class_attention_mask, class_batch_size)
+        return ll.to(self.dtype)

@@ -160,6 +160,16 @@ int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *
                       int64_t kv_capacity, float *logits_last, float *logits_all,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- stage 4b: continue a prefilled sequence (classify) ---------------------------------------------
+ * Runs `new_len` further positions per row against a KV cache that already holds `past_len` entries.
+ * Replaces the second language-model call of classify() (ref:eilev/model/v2.py:461-466:
+ * input_ids = class tokens, past_key_values = the prompt's cache repeated per class).
+ * inputs_embeds: (batch, new_len, Dt); attn_mask: (batch, past_len + new_len) int32;
+ * logits_all: (batch, new_len, vocab) f32.  Workspace: eilev_opt_workspace_bytes(d, batch, past_len + new_len). */
+int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                     int64_t batch, int64_t new_len, int64_t past_len, void *kv_cache, int64_t kv_capacity,
+                     float *logits_all, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stage 5: greedy decode ---------------------------------------------------------------
  * Replaces one iteration of GenerationMixin._sample with do_sample=False
  * (hf generation/utils.py:2876-2937): argmax of the fp32 last-row logits, pad-after-EOS,

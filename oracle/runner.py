@@ -156,6 +156,41 @@ class OracleModel:
         return (ids, step_logits) if return_logits else ids
 
 
+    def classify(self, pixels, input_ids, attn_mask, video_mask, class_ids, class_mask=None, class_batch_size=None):
+        """= reference classify(...) (ref:eilev/model/v2.py:326-501): (B, num_classes) mean class log-likelihoods."""
+        d = self.dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        B, L, _ = emb.shape
+        cls = np.asarray(class_ids, dtype=np.int64)
+        n_cls, Lc = cls.shape
+        cmask = np.ones_like(cls) if class_mask is None else np.asarray(class_mask, dtype=np.int64)
+        pm = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        cap = L + Lc
+        last, _, kv = self.prefill(emb, pm, kv_capacity=cap, all_logits=False)
+        planes = 2 * d.t_layers
+        step = n_cls if class_batch_size is None else int(class_batch_size)
+        cols = []
+        for i in range(0, n_cls, step):
+            ids, msk = cls[i:i + step], cmask[i:i + step]
+            nc = ids.shape[0]
+            R = B * nc
+            rows_ids = np.ascontiguousarray(np.broadcast_to(ids[None], (B, nc, Lc)).reshape(R, Lc))
+            rows_msk = np.broadcast_to(msk[None], (B, nc, Lc)).reshape(R, Lc)
+            full = np.ascontiguousarray(np.concatenate((np.repeat(pm, nc, axis=0), rows_msk.astype(np.int32)), axis=1))
+            kv_rows = np.ascontiguousarray(np.repeat(kv.reshape(planes, B, -1), nc, axis=1))
+            x = self.embed_scatter(rows_ids, None, None)
+            logits = np.empty((R, Lc, d.vocab), np.float32)
+            nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), R, cap)
+            ws = np.empty(nbytes // 4 + 1, np.float32)
+            abi.check(self.lib.eilev_opt_extend(C.byref(d), C.byref(self.pack.opt), _p(x), _p(full), R, Lc, L, _p(kv_rows), cap,
+                                                _p(logits), _p(ws), nbytes, None), "oracle extend")
+            shift = np.concatenate((np.repeat(last, nc, axis=0)[:, None], logits[:, :-1]), axis=1).astype(np.float64)
+            lse = np.log(np.exp(shift - shift.max(-1, keepdims=True)).sum(-1)) + shift.max(-1)
+            tok = np.take_along_axis(shift, rows_ids[..., None], axis=-1)[..., 0]
+            ll = np.where(rows_msk != 0, tok - lse, 0.0).reshape(B, nc, Lc).sum(-1)
+            cols.append(ll / msk.sum(-1)[None].astype(np.float64))
+        return np.concatenate(cols, axis=1).astype(np.float32)
+
     def generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1,
                       pad_id=1, early_stopping=False):
         """Beam search = reference generate(num_beams=k) with the oracle as the language model (eilev_amd.beam drives it)."""

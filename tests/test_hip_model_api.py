@@ -99,3 +99,24 @@ def test_beam_search_like_the_sample_script(golden_dir, name, tag, nb, lp):
 
 def meta_never(g):
     return 511
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["mid_b1", "mid_b2"])
+def test_classify_like_the_reference(golden_dir, name, dtype):
+    """classify() on the HIP path (prefill once, eilev_opt_extend per class chunk) vs the reference's own classify()."""
+    g, meta, px = load_case(golden_dir, name)
+    m = build(meta["config"], dtype)
+    t = lambda a: torch.from_numpy(a).cuda()
+    kw = dict(prompt_attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+              prompt_video_input_mask=t(g["video_input_mask"]), class_attention_mask=t(g["class_attention_mask"]))
+    ll = m.classify(t(g["input_ids"]), t(g["class_input_ids"]), **kw)
+    assert ll.dtype == dtype and ll.shape == g["fp32_classify"].shape
+    truth, ref_bf16 = g["fp32_classify"], g["bf16_classify"]
+    # judged like the logits: no further from the fp32 truth than 1.5x the reference's own bf16 run (+ slack)
+    budget = 1.5 * np.abs(ref_bf16 - truth).max() + 2e-2
+    assert np.abs(host(ll) - truth).max() <= budget, (host(ll), truth)
+    ll2 = m.classify(t(g["input_ids"]), t(g["class_input_ids"]), class_batch_size=2, **kw)
+    assert np.abs(host(ll2) - host(ll)).max() <= 2e-2  # chunking only changes GEMM shapes
+    if dtype == torch.float32:
+        assert np.array_equal(host(ll).argmax(-1), truth.argmax(-1)) or np.sort(truth, -1)[:, -1].min() - np.sort(truth, -1)[:, -2].max() < 5e-2

@@ -138,3 +138,58 @@ def test_clip_batch_invariance():
     a = eng.encode_clips(px[:2])
     b = eng.encode_clips(px[2:])
     assert torch.equal(all5, torch.cat([a, b]))
+
+
+@pytest.mark.parametrize("cfg_name,past,new", [("mid", 37, 5), ("mid", 64, 1), ("opt27_2l", 300, 7)])
+def test_extend_equals_full_prefill(cfg_name, past, new):
+    """Size-independent property of eilev_opt_extend (classify's second LM call): continuing a cache of `past`
+    entries with `new` positions gives the logits of one prefill over past+new positions, with left padding and
+    a padded tail; and the cache rows it appends equal the full prefill's."""
+    if cfg_name == "opt27_2l":  # the real OPT-2.7B widths (hd 80, 32 heads, vocab 50272), two layers
+        from eilev_amd.configs import blip2_config
+        from eilev_amd.engine import HipEngine
+        from eilev_amd.statedict import state_dict_shapes
+        from eilev_amd.synth import synth_param
+
+        cfg = blip2_config("opt27")
+        cfg.text_config.num_hidden_layers = 2
+        named = {k: torch.from_numpy(synth_param(k, shp, "fanin")).to(torch.bfloat16).cuda()
+                 for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
+        eng = HipEngine(cfg, named, device="cuda", parts=("opt",))
+    else:
+        cfg, oracle, eng = models(cfg_name)
+    torch.manual_seed(1)
+    B, D = 3, eng.dims.t_hidden
+    L = past + new
+    emb = (0.5 * torch.randn(B, L, D, device="cuda")).to(torch.bfloat16)
+    am = torch.ones(B, L, dtype=torch.int32, device="cuda")
+    am[1, :5] = 0          # left padding of the prompt
+    am[2, L - 2:] = 0      # right-padded class tail
+    _, full, kv_full = eng.prefill(emb, am, kv_capacity=L, all_logits=True, last_logits=False)
+    _, _, kv = eng.prefill(emb[:, :past].contiguous(), am[:, :past].contiguous(), kv_capacity=L, last_logits=False)
+    ext = eng.extend(emb[:, past:].contiguous(), am, past, kv, L)
+    torch.cuda.synchronize()
+    valid = host(am[:, past:]) == 1
+    assert rel_rms(host(ext)[valid], host(full[:, past:])[valid]) <= 3e-3
+    planes = 2 * eng.dims.t_layers
+    H, hd = eng.dims.t_heads, D // eng.dims.t_heads
+    a = kv.view(torch.bfloat16).view(planes, B, H, L, hd)[:, :, :, past:]
+    b = kv_full.view(torch.bfloat16).view(planes, B, H, L, hd)[:, :, :, past:]
+    vm = (am[:, past:] == 1)[None, :, None, :, None]
+    assert rel_rms(host((a * vm).float()), host((b * vm).float())) <= 3e-3
+
+
+@pytest.mark.parametrize("name", ["mid_b2"])
+def test_extend_vs_oracle(golden_dir, name):
+    """eilev_opt_extend on the HIP path vs the C oracle's, same inputs (class tokens after the golden prompt)."""
+    g, meta, px = load_case(golden_dir, name)
+    cfg, oracle, eng = models(meta["config"], emu=False)
+    emb_o = oracle.encode(px, g["input_ids"], g["video_input_mask"])
+    ll_o = oracle.classify(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["class_input_ids"],
+                           g["class_attention_mask"])
+    t = lambda a: torch.from_numpy(a).cuda()
+    feats = eng.encode_clips(t(px))
+    emb = eng.embed_scatter(t(g["input_ids"]), t(g["video_input_mask"]), feats)
+    assert rel_rms(host(emb), emb_o) <= 1e-2
+    ll = eng.classify_loglik(emb, t(g["attention_mask"]), t(g["class_input_ids"]), t(g["class_attention_mask"]))
+    assert np.abs(host(ll) - ll_o).max() <= 1.5 * np.abs(g["bf16_classify"] - g["fp32_classify"]).max() + 2e-2

@@ -122,10 +122,12 @@ def test_no_cpu_fallback():
         m.generate(torch.ones(1, 4, dtype=torch.long), max_new_tokens=2)
     with pytest.raises(ValueError):
         VideoBlipVisionModel(cfg.vision_config)(None)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         m.generate(torch.ones(1, 4, dtype=torch.long), num_beams=5)
+    with pytest.raises(RuntimeError):
+        m.classify(torch.ones(1, 4, dtype=torch.long), torch.ones(2, 3, dtype=torch.long))
     with pytest.raises(NotImplementedError):
-        m.classify()
+        m.generate(torch.ones(1, 4, dtype=torch.long), do_sample=True)
 
 
 def test_c_abi_library_exports_every_declared_symbol():

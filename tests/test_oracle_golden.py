@@ -116,3 +116,33 @@ def test_beam_search_matches_reference(golden_dir, models, name, tag, nb, lp):
     assert np.array_equal(ids, g[f"fp32_{tag}"]), (ids, g[f"fp32_{tag}"])
     free = m.generate_beam(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, nb, lp, eos_id=-1)
     assert np.array_equal(free, g[f"fp32_{tag}_free"]), (free, g[f"fp32_{tag}_free"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_classify_matches_reference(golden_dir, models, name):
+    """eilev_opt_extend + the class log-likelihood bookkeeping == reference classify() (ref:eilev/model/v2.py:326-501),
+    chunked or not; and the KV-cache continuation == one full forward over prompt + class tokens."""
+    g, meta, cfg, px = load_case(golden_dir, name)
+    m = models(meta["config"])
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["class_input_ids"], g["class_attention_mask"])
+    ll = m.classify(*args)
+    assert ll.shape == g["fp32_classify"].shape
+    assert np.abs(ll - g["fp32_classify"]).max() < 5e-4
+    ll2 = m.classify(*args, class_batch_size=2)
+    assert np.abs(ll2 - g["fp32_classify_cbs2"]).max() < 5e-4
+    assert np.abs(ll2 - ll).max() < 1e-5
+    # size-independent property: continuing the cache == re-running the whole sequence
+    emb = m.encode(px, g["input_ids"], g["video_input_mask"])
+    cls, cm = g["class_input_ids"], g["class_attention_mask"]
+    B = emb.shape[0]
+    for c in (0, 3):
+        ids = np.broadcast_to(cls[c][None], (B, cls.shape[1])).copy()
+        full_emb = np.concatenate((emb, m.embed_scatter(ids, None, None)), axis=1)
+        full_mask = np.concatenate((g["attention_mask"], np.broadcast_to(cm[c][None], ids.shape)), axis=1)
+        _, logits, _ = m.prefill(full_emb, full_mask)
+        L = emb.shape[1]
+        shift = logits[:, L - 1:-1].astype(np.float64)
+        lse = np.log(np.exp(shift - shift.max(-1, keepdims=True)).sum(-1)) + shift.max(-1)
+        tok = np.take_along_axis(shift, ids[..., None], axis=-1)[..., 0]
+        want = (np.where(cm[c][None] != 0, tok - lse, 0.0).sum(-1) / cm[c].sum())
+        assert np.abs(want - ll[:, c]).max() < 2e-4

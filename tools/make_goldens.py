@@ -82,6 +82,42 @@ def load_det_weights(model, mode="fanin"):
     model.load_state_dict(new)
 
 
+class _legacy_kv_compat:
+    """The reference's classify() was written against the tuple-of-(k, v) KV cache of the transformers release it pins
+    (ref:pyproject.toml); the installed release iterates a DynamicCache as (k, v, sliding_window) triples and only takes
+    Cache objects back.  While generating the classify goldens, present the old protocol to the reference code: iterate
+    as (k, v) pairs and rebuild a DynamicCache from the tuples it hands back.  Arithmetic is untouched."""
+
+    def __enter__(self):
+        from transformers.cache_utils import DynamicCache
+        from transformers.models.opt import modeling_opt
+
+        self.dc, self.opt = DynamicCache, modeling_opt.OPTForCausalLM
+        self.old_iter, self.old_fwd = DynamicCache.__iter__, modeling_opt.OPTForCausalLM.forward
+
+        def pairs(cache):
+            for layer in cache.layers:
+                yield layer.keys, layer.values
+
+        old_fwd = self.old_fwd
+
+        def fwd(lm, *a, past_key_values=None, **k):
+            if isinstance(past_key_values, tuple):
+                cache = DynamicCache(config=lm.config)
+                for i, (kk, vv) in enumerate(past_key_values):
+                    cache.update(kk, vv, i)
+                past_key_values = cache
+            return old_fwd(lm, *a, past_key_values=past_key_values, **k)
+
+        DynamicCache.__iter__ = pairs
+        modeling_opt.OPTForCausalLM.forward = fwd
+        return self
+
+    def __exit__(self, *exc):
+        self.dc.__iter__ = self.old_iter
+        self.opt.forward = self.old_fwd
+
+
 @torch.no_grad()
 def run_case(name):
     cfg_name, frames, rows, new_tokens = CASES[name]
@@ -129,6 +165,21 @@ def run_case(name):
             g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
                            max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=never)
             out[f"{tag}_{nm}_free"] = g.numpy().astype(np.int64)
+        # classify(): class log-likelihoods continued from the prompt's KV cache (ref:eilev/model/v2.py:326-501)
+        rng = np.random.default_rng(7)
+        n_cls, cls_len = 5, 4
+        cls_ids = rng.integers(4, vocab, size=(n_cls, cls_len)).astype(np.int64)
+        cls_mask = np.ones((n_cls, cls_len), dtype=np.int64)
+        cls_mask[1, 3:] = 0  # right-padded shorter classes
+        cls_mask[3, 2:] = 0
+        cls_ids[cls_mask == 0] = 1
+        for cbs, nm in ((None, "classify"), (2, "classify_cbs2")):
+            with _legacy_kv_compat():
+                ll = m.classify(t(input_ids), t(cls_ids), prompt_attention_mask=t(attn), pixel_values=px,
+                                prompt_video_input_mask=t(vmask), class_attention_mask=t(cls_mask), class_batch_size=cbs)
+            out[f"{tag}_{nm}"] = ll.float().numpy()
+        out["class_input_ids"] = cls_ids
+        out["class_attention_mask"] = cls_mask
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens,
                 weight_mode="fanin", torch=torch.__version__, transformers=transformers.__version__,
                 attn_implementation=str(getattr(cfg, "_attn_implementation", None)),
