@@ -1244,6 +1244,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (tm256 * ceil_div64(g.N, 128) >= 512) cfg = 3;                   // 256x128, 1 stage, 2 WG/CU (N = 1408 / 1536)
     else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
     else cfg = 4;                                                            // 128x128
+    bool wide_tiles = false;
+    if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force) cfg = force;
     if (cfg == 0 && false) rc = 0;
     else if (((g.dbg >> 4) & 15) == 8 && g.K % 64 == 0) rc = launch_pp2(g, s);
@@ -1252,7 +1254,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
     else if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
     else if (cfg == 6 && g.K % BK == 0) rc = launch_pp<256, 128, 4, 2, 2>(g, s);
-    else if (cfg == 1 && !force && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+    else if (cfg == 1 && !force && !wide_tiles && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp3(g, s);  // persistent half-K-step ping-pong kernel
     else if (cfg == 1 || cfg == 5) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3 && (g.dbg & 512)) rc = launch_tiled<256, 128, 4, 2, 1, 4, 0>(g, s);
