@@ -814,7 +814,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(const GemmArgs g) {
 // epilogue — is overlapped here: the first two halves of the NEXT tile are DMA'd into half-buffers 0/1 as soon
 // as the K loop ends, while the epilogue runs out of the other half of LDS (two passes of 64 rows per wave:
 // 69.6 KB at offset 64 KB), and the epilogue's global stores drain under the next tile's first K-steps.
-template <int EPI>
+// DM = 1: the LDS-DMA pieces of half n+3 are issued BETWEEN the MFMAs of M#n (one piece after every 4th MFMA) instead of
+// in R#n: the R phase (12 ds_read_b128 + 4 pieces ~ 680 cycles) was longer than the M phase it has to hide under (512).
+template <int EPI, int DM>
 __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
@@ -892,6 +894,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
+    auto mma_half_dma = [&](int n) {  // the same 16 MFMAs with the 4 pieces of half n interleaved
+        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
+        char *sb = sa + BM * 64;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+                if ((i & 1) == 0) {
+                    const int pc = i >> 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k2 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + pc * 1024), 16, pa[pc], n * 64, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + pc * 1024), 16, pb[pc], n * 64, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
 #define PP_BARRIER()                       \
     do {                                   \
         __builtin_amdgcn_sched_barrier(0); \
@@ -917,6 +940,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
         PP_BARRIER();
         if (late) PP_BARRIER();
         const int nhd = (g.dbg & 2) ? 2 : nh;
+        if (DM) {
+            // half-buffer 2 was the epilogue's staging area until the barrier above
+            if (2 < nh) stage_half(2);
+            // H_m is read by the early group after barrier 2m and by the late group after barrier 2m+1, so every wave's
+            // pieces of H_m must have landed before barrier 2m: early waves wait at the end of M#(m-1) (younger in flight:
+            // H_{m+1}, H_{m+2}), late waves — whose M#(m-1) comes after that barrier — at the end of R#(m-1) (younger: H_{m+1})
+            int n = 0;
+            for (; n + 3 < nh; ++n) {  // steady state
+                read_half(n);
+                if (late) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PP_BARRIER();
+                mma_half_dma(n + 3);
+                if (!late) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                PP_BARRIER();
+            }
+            for (; n < nh; ++n) {  // the last three halves: nothing left to issue
+                read_half(n);
+                if (late) {
+                    if (n + 2 < nh) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                PP_BARRIER();
+                mma_half();
+                if (!late) {
+                    if (n + 2 < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                PP_BARRIER();
+            }
+        } else
         for (int n = 0; n < nhd; ++n) {
             if (!(g.dbg & 16384) || n == 0) read_half(n);
             if (n + 2 < nh) {
@@ -949,9 +1005,12 @@ int launch_pp3(const GemmArgs &g, hipStream_t s) {
     constexpr int smem = 2 * 32768 + 8 * 64 * (64 * 2 + 8);  // half-buffers 0/1 + epilogue staging (which overlays 2/3)
     static_assert(smem >= 4 * 32768, "staging must cover half-buffers 2 and 3");
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         int dev = 0;
         EILEV_HIP_CHECK(hipGetDevice(&dev));
         EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -959,9 +1018,14 @@ int launch_pp3(const GemmArgs &g, hipStream_t s) {
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp3_kernel<1>, dim3(grid), dim3(512), smem, s, g);
-    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp3_kernel<2>, dim3(grid), dim3(512), smem, s, g);
-    else hipLaunchKernelGGL(gemm_pp3_kernel<0>, dim3(grid), dim3(512), smem, s, g);
+    const bool dm = (g.dbg & 65536) != 0;
+    if (dm) {
+        if (g.epi == 1) hipLaunchKernelGGL((gemm_pp3_kernel<1, 1>), dim3(grid), dim3(512), smem, s, g);
+        else if (g.epi == 2) hipLaunchKernelGGL((gemm_pp3_kernel<2, 1>), dim3(grid), dim3(512), smem, s, g);
+        else hipLaunchKernelGGL((gemm_pp3_kernel<0, 1>), dim3(grid), dim3(512), smem, s, g);
+    } else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp3_kernel<1, 0>), dim3(grid), dim3(512), smem, s, g);
+    else if (g.epi == 2) hipLaunchKernelGGL((gemm_pp3_kernel<2, 0>), dim3(grid), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL((gemm_pp3_kernel<0, 0>), dim3(grid), dim3(512), smem, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
                                                                 int heads, int hd) {
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float sc[DEC_KEYS];
-    __shared__ float red[32 * 128];
+    __shared__ float red[DEC_KEYS * 17];  // per-key chunk partials (stride 17), later the p.V partials (nks * hd <= 2048)
     __shared__ float wred[4];
     __shared__ float bc[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -232,20 +232,27 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * 3 * d + h * hd + tid];
     __syncthreads();
 
-    // scores: thread t <-> key k0 + t
+    // scores: thread = (key subset ks, d chunk c) so that consecutive lanes read consecutive 16-byte chunks (a K row is
+    // hd * 2 = 160 contiguous bytes); the nch partial dot products of a key meet in LDS, then thread t owns key k0 + t
+    const int nks = 256 / nch;
+    const int c = tid % nch, ks = tid / nch;
+    const int nkeys = k1 - k0;
+    if (ks < nks) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]);
+        const float4 q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+#pragma unroll 4
+        for (int jj = ks; jj < nkeys; jj += nks) {
+            float kv[8];
+            unpack8(*reinterpret_cast<const bf16x8 *>(kbase + (int64_t)(k0 + jj) * hd + c * 8), kv);
+            red[jj * 17 + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
+        }
+    }
+    __syncthreads();
     const int j = k0 + tid;
     float s = -1e30f;
     if (j < k1) {
-        const bf16x8 *kr = reinterpret_cast<const bf16x8 *>(kbase + (int64_t)j * hd);
         float acc = 0.0f;
-#pragma unroll 4
-        for (int c = 0; c < nch; ++c) {
-            float kv[8];
-            unpack8(kr[c], kv);
-            const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]);
-            const float4 q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
-            acc += kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
-        }
+        for (int cc = 0; cc < nch; ++cc) acc += red[tid * 17 + cc];
         const bool vis = j >= seq_len || attn_mask[(int64_t)b * seq_len + j] != 0;
         s = vis ? acc : -1e30f;
     }
@@ -261,14 +268,11 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     __syncthreads();
     const float lsum = wred[0] + wred[1] + wred[2] + wred[3];
 
-    // p.V: thread = (key subset ks, d chunk c)
-    const int nks = 256 / nch;
-    const int c = tid % nch, ks = tid / nch;
+    // p.V: same (ks, c) mapping
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     if (ks < nks) {
-        const int nkeys = k1 - k0;
 #pragma unroll 4
         for (int jj = ks; jj < nkeys; jj += nks) {
             float vv[8];
