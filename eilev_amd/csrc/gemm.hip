@@ -151,23 +151,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
                 for (int e = 0; e < 4; ++e) sc[e] = (col + e) < g.scale_cols ? g.scale : 1.0f;
             }
             char *cp = reg + l31 * RS + lc * 2;
+            constexpr int NI = IEND - IBEG;
+            float v[NI][4];
 #pragma unroll
-            for (int i = IBEG; i < IEND; ++i) {
-                bf16x4 *cell = reinterpret_cast<bf16x4 *>(cp + (i - IBEG) * 32 * RS);
-                float v[4];
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][q * 4 + e] + bv[e];
-                    if (has_scale) v[e] *= sc[e];
-                    if (EPI == 1) v[e] = gelu_erf(v[e]);
-                    else if (EPI == 2) v[e] = fmaxf(v[e], 0.0f);
+                    v[i][e] = acc[IBEG + i][j][q * 4 + e] + bv[e];
+                    if (has_scale) v[i][e] *= sc[e];
+                    if (EPI == 2) v[i][e] = fmaxf(v[i][e], 0.0f);
                 }
+            if (EPI == 1) {
+                f32x2 x[2 * NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    x[2 * i] = (f32x2){v[i][0], v[i][1]};
+                    x[2 * i + 1] = (f32x2){v[i][2], v[i][3]};
+                }
+                gelu_erf_pk<2 * NI>(x);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    v[i][0] = x[2 * i].x; v[i][1] = x[2 * i].y; v[i][2] = x[2 * i + 1].x; v[i][3] = x[2 * i + 1].y;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                bf16x4 *cell = reinterpret_cast<bf16x4 *>(cp + i * 32 * RS);
                 if (has_res) {
                     const bf16x4 r4 = *cell;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                    for (int e = 0; e < 4; ++e) v[i][e] += (float)r4[e];
                 }
-                *cell = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *cell = (bf16x4){(bf16)v[i][0], (bf16)v[i][1], (bf16)v[i][2], (bf16)v[i][3]};
             }
         }
     }
