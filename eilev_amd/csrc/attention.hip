@@ -408,6 +408,340 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Frame attention: the ViT case (hf Blip2Attention, S = 257 tokens per frame, hd = 88, no mask), persistent.
+//  * one workgroup (9 waves) per CU walks (frame, head) pairs; the whole K and V of a pair (257 x 176 B each)
+//    live in LDS: ring [K(even pairs) | K(odd pairs) | V]; K of the NEXT pair is DMA'd while the current pair
+//    computes, V of the current pair lands under the first S phase + softmax;
+//  * a wave owns 16-row query tiles (16x16x32 MFMA; tiles w and w + 9 of the 17): S^T = K Q^T for ALL keys of
+//    the row stays in registers (17 tiles x 4 = 68 fp32), so the softmax is exact single pass — no running
+//    max, no rescale of O, no barrier inside a tile — and P is already in the B-operand layout of O^T = V^T P^T;
+//  * k-slots of the S MFMA are a permutation of d chosen so that a K fragment is two ds_read_b64 that are
+//    bank-conflict free on 176-byte rows (slot (g, j) <-> d = 32 ks + 16 (j >> 2) + 4 g + (j & 3));
+//  * the 16 keys of a tile sit in the MFMA rows in the order 0 2 4 .. 14 1 3 .. 15: the V^T fragments come from
+//    ds_read_b64_tr_b16 (32 lanes per LDS cycle), and with that order the 8 key rows a half-wave transposes are all even
+//    (or all odd), which is what makes the 64 dwords it touches fall into 64 different banks on 176-byte rows;
+//  * O^T leaves the MFMA with 4 consecutive d per lane and tile; lane pairs (g, g ^ 1) swap halves so that a store
+//    is 16 bytes per lane and 64 contiguous bytes per query row, no LDS staging;
+//  * rows >= S of the LDS images are copies of the last key row (DMA source clamped): finite, and masked (K) or
+//    multiplied by P = 0 (V).
+__device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void_t *dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, 0, 0, 0);
+}
+
+__device__ unsigned long long g_attn_ts[9 * 8 * 16];  // probe: [wave][pair < 8][event < 16] s_memtime stamps of workgroup 0
+extern "C" int eilev_debug_attn_ts(void *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_ts), sizeof(g_attn_ts));
+}
+typedef __attribute__((address_space(3))) char lds_char_t;
+typedef __attribute__((address_space(3))) const bf16x4 lds_cbf16x4_t;
+
+template <int HD, int NT>
+__global__ __launch_bounds__(576) void attn_frame_kernel(const AttnArgs a) {
+    constexpr int NW = 9;
+    constexpr int CH = HD / 8, RS = HD * 2;
+    constexpr int NPIECE = (NT * 16 * CH + (12 - CH) + 63) / 64;  // 1-KiB pieces per K (or V) image, incl. the d >= HD overhang
+    constexpr int BUF = NPIECE * 1024;
+    constexpr int PPW = (NPIECE + NW - 1) / NW;
+    constexpr int KS = 3;               // k-steps of 32 over the padded head dim 96
+    constexpr int NKS = (NT + 1) / 2;   // k-steps of 32 keys in O^T = V^T P^T
+    constexpr int DT = 6;               // 16-row tiles of O^T
+    static_assert(NT > NW && NT <= 2 * NW && HD <= 96 && HD % 8 == 0 && NT * 16 * RS < 65536 - 512, "tile split / ds offset field");
+    static_assert(PPW == 6, "the counted s_waitcnt vmcnt(6) below assume 6 DMA pieces and 6 Q loads per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char_t *lds = (lds_char_t *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int S = a.sq;
+    const int npairs = a.batch * a.heads;
+    const float sl2 = a.scale * 1.44269504088896340736f;
+
+    // DMA: piece i covers 16-byte chunks 64 i + lane of an image, chunk p = (key p / CH, c = p % CH); wave w issues pieces
+    // w, w + 9, ... (surplus slots repeat the last piece: same bytes to the same place).  The geometry is recomputed per
+    // call (a handful of VALU ops) rather than kept in registers.
+    auto stage = [&](const bf16 *src, int buf) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+        const unsigned ld2 = (unsigned)(a.ldk * 2);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            int i = wid + NW * k;
+            i = i < NPIECE ? i : NPIECE - 1;
+            const int pch = i * 64 + lane;
+            int key = pch / CH;
+            const int c = pch - key * CH;
+            key = key < S ? key : S - 1;
+            attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), (unsigned)key * ld2 + c * 16);
+        }
+    };
+    // Q fragments of a tile (3 x 16 bytes per lane), fetched a pair ahead: [0] first tile (w), [1] second tile (w + 9)
+    bf16x8 qf[2][KS];
+    auto load_q = [&](int pair, int ti, bf16x8 (&dst)[KS]) {
+        const int b = pair / a.heads, h = pair - b * a.heads;
+        const int row = (wid + NW * ti) * 16 + l15;
+        const bf16 *rp = a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs + (int64_t)(row < S ? row : S - 1) * a.ldq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 32 + 4 * g, d1 = d0 + 16;
+            bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (row < S && d0 + 4 <= HD) lo = *reinterpret_cast<const bf16x4 *>(rp + d0);
+            if (row < S && d1 + 4 <= HD) hi = *reinterpret_cast<const bf16x4 *>(rp + d1);
+            dst[ks] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+#define FA_BARRIER()                       \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    // A row i of a key tile <-> key 16 t + pi(i), pi = (0 2 4 .. 14 1 3 .. 15): lanes 0-31 of the V^T transpose reads then
+    // touch even rows only, which makes them bank-conflict free on 176-byte rows
+    const int prow = l15 < 8 ? 2 * l15 : 2 * l15 - 15;
+    // K fragments are read with ds_read_b64 in inline asm: left to the compiler, pairs of them are fused into
+    // ds_read2_b64, which runs at half the rate with a 32-bank mapping that conflicts on these rows
+    const unsigned kbase = prow * RS + g * 8;
+    const int vi = 4 * g + (l15 >> 2);
+    const unsigned voff_t = 2 * BUF + (vi < 8 ? 2 * vi : 2 * vi - 15) * RS + (l15 & 3) * 8;
+    // ---- building blocks.  sc[t][r] = q_row . k_(16 t + pi(4 g + r)); two key tiles per call = two independent MFMA chains
+    // issue the 6 fragment reads of key tile t; kf[] is valid after the wait in s_mma
+    auto s_issue = [&](unsigned kaddr, bf16x4 (&kf)[2 * KS], int t) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(kf[ks * 2 + hf]) : "v"(kaddr), "i"(t * 16 * RS + ks * 64 + hf * 32));
+    };
+    // NAFTER = number of younger ds_read_b64 already issued (the next tile's fragments): wait for everything older
+    auto s_mma = [&](const bf16x8 (&q)[KS], bf16x4 (&kf)[2 * KS], auto &sc, int t, auto nafter) {
+        constexpr int NAFTER = decltype(nafter)::value;
+        // every fragment register is an in/out operand of the wait so that no MFMA can be scheduled above it
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]) : "n"(NAFTER));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x4 lo = kf[ks * 2], hi = kf[ks * 2 + 1];
+            const bf16x8 k0 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[ks], acc, 0, 0, 0);
+        }
+        sc[t] = acc;
+    };
+    // row maximum over all keys (4 lanes share a row: xor 16, xor 32) -> the exponent offset -max * scale * log2 e
+    auto row_offset = [&](auto &sc) -> float {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // keys of the last tile that do not exist (A row 4 g + r -> key)
+            const int ar = 4 * g + r;
+            if ((NT - 1) * 16 + (ar < 8 ? 2 * ar : 2 * ar - 15) >= S) sc[NT - 1][r] = -1e30f;
+        }
+        float m4[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+#pragma unroll
+        for (int t = 0; t < NT; t += 2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m4[r] = t + 1 < NT ? fmaxf(fmaxf(m4[r], sc[t][r]), sc[t + 1][r]) : fmaxf(m4[r], sc[t][r]);
+        float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        return -mx * sl2;
+    };
+    // p = exp2(s * scale * log2 e + offset) for key tiles t, t + 1: packed fp32 arguments and row sums, bf16 P
+    auto sm_tiles = [&](const auto &sc, bf16x4 (&pr)[NT], int t, float nm, f32x2 &la, f32x2 &lb) {
+#pragma unroll
+        for (int u = t; u < t + 2 && u < NT; ++u) {
+            const f32x2 x0 = (f32x2){sc[u][0], sc[u][1]} * sl2 + nm, x1 = (f32x2){sc[u][2], sc[u][3]} * sl2 + nm;
+            const f32x2 p0 = {__builtin_amdgcn_exp2f(x0.x), __builtin_amdgcn_exp2f(x0.y)};
+            const f32x2 p1 = {__builtin_amdgcn_exp2f(x1.x), __builtin_amdgcn_exp2f(x1.y)};
+            la += p0;
+            lb += p1;
+            pr[u] = (bf16x4){(bf16)p0.x, (bf16)p0.y, (bf16)p1.x, (bf16)p1.y};
+        }
+    };
+    auto row_sum = [&](f32x2 la, f32x2 lb) -> float {
+        float l = (la.x + la.y) + (lb.x + lb.y);
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        return l;
+    };
+    // O^T += V^T P^T for keys of tiles 2 k2, 2 k2 + 1: o[dt][r] = O[q_row][16 dt + 4 g + r].  The V^T fragments come from
+    // ds_read_b64_tr_b16 in inline asm with explicit lgkmcnt waits: a compiler-visible LDS read after an LDS-DMA makes
+    // hipcc drain vmcnt(0) first — i.e. wait for the K image of the NEXT pair that was issued a moment ago.
+    const unsigned vaddr = (unsigned)(uintptr_t)lds + voff_t;
+    auto pv_issue = [&](bf16x4 (&vf)[2 * DT], int k2) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vf[2 * dt]) : "v"(vaddr), "i"(2 * k2 * 16 * RS + dt * 32));
+            if (2 * k2 + 1 < NT)
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vf[2 * dt + 1]) : "v"(vaddr), "i"((2 * k2 + 1) * 16 * RS + dt * 32));
+        }
+    };
+    auto pv_mma = [&](f32x4 (&o)[DT], const bf16x4 (&pr)[NT], bf16x4 (&vf)[2 * DT], int k2, auto nafter) {
+        constexpr int NAFTER = decltype(nafter)::value;
+        constexpr bf16x4 z4 = {0, 0, 0, 0};
+        asm volatile("s_waitcnt lgkmcnt(%12)"
+                     : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vf[4]), "+v"(vf[5]), "+v"(vf[6]), "+v"(vf[7]), "+v"(vf[8]),
+                       "+v"(vf[9]), "+v"(vf[10]), "+v"(vf[11])
+                     : "n"(NAFTER));
+        const bool two = 2 * k2 + 1 < NT;
+        const bf16x4 p0 = pr[2 * k2], p1 = two ? pr[2 * k2 + 1 < NT ? 2 * k2 + 1 : 0] : z4;
+        const bf16x8 pb = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x4 lo = vf[2 * dt], hi = two ? vf[2 * dt + 1] : z4;
+            const bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, pb, o[dt], 0, 0, 0);
+        }
+    };
+    // O / l -> bf16.  Lane pairs (g, g ^ 1) swap halves so that every lane holds 8 consecutive d of one tile (even g:
+    // tile 2 m, odd g: tile 2 m + 1) -> 16-byte stores, 64 contiguous bytes per query row
+    auto store_o = [&](const f32x4 (&o)[DT], float l, bf16 *ob, int ti) {
+        const int row = (wid + NW * ti) * 16 + l15;
+        const float inv = 1.0f / l;
+        bf16 *op = ob + (int64_t)(row < S ? row : 0) * a.ldo + ((g & 1) * 16 + (g >> 1) * 8);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            union { bf16x4 v; int w[2]; } e, odd, give, got;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e.v[r] = (bf16)(o[2 * m][r] * inv);
+                odd.v[r] = (bf16)(o[2 * m + 1][r] * inv);
+            }
+            give.v = (g & 1) ? e.v : odd.v;  // what the partner lane stores
+            got.w[0] = __shfl_xor(give.w[0], 16, 64);
+            got.w[1] = __shfl_xor(give.w[1], 16, 64);
+            const bf16x4 mine = (g & 1) ? odd.v : e.v;
+            const bf16x4 lo = (g & 1) ? got.v : mine, hi = (g & 1) ? mine : got.v;
+            const int d0 = 32 * m + (g & 1) * 16 + (g >> 1) * 8;
+            if (row < S && d0 + 8 <= HD)
+                *reinterpret_cast<bf16x8 *>(op + 32 * m) = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+    {
+        const int b = pair / a.heads, h = pair - b * a.heads;
+        stage(a.k + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs, 0);
+    }
+    const bool two_tiles = wid + NW < NT;
+    load_q(pair, 0, qf[0]);
+    if (two_tiles) load_q(pair, 1, qf[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool ts_on = (a.dbg & 256) && blockIdx.x == 0 && lane == 0;
+#define FA_TS(ev)                                                                                  \
+    do {                                                                                           \
+        if (ts_on && it < 8) g_attn_ts[(wid * 8 + it) * 16 + (ev)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+    // one query tile: S^T (all keys, in registers) -> exact softmax -> O^T
+    auto s_phase = [&](unsigned kaddr, const bf16x8 (&q)[KS], f32x4 (&sc)[NT]) {
+        bf16x4 kf[2][2 * KS];  // double buffered: the reads of tile t + 1 are in flight under the MFMAs of tile t
+        s_issue(kaddr, kf[0], 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) {
+                s_issue(kaddr, kf[(t + 1) & 1], t + 1);
+                s_mma(q, kf[t & 1], sc, t, std::integral_constant<int, 2 * KS>{});
+            } else {
+                s_mma(q, kf[t & 1], sc, t, std::integral_constant<int, 0>{});
+            }
+        }
+    };
+    auto softmax = [&](f32x4 (&sc)[NT], bf16x4 (&pr)[NT]) -> float {
+        const float nm = row_offset(sc);
+        f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) sm_tiles(sc, pr, t, nm, la, lb);
+        return row_sum(la, lb);
+    };
+    auto pv_phase = [&](const bf16x4 (&pr)[NT], float l, bf16 *ob, int ti) {
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x4 vf[2 * DT];
+#pragma unroll
+        for (int k2 = 0; k2 < NKS; ++k2) {
+            pv_issue(vf, k2);
+            pv_mma(o, pr, vf, k2, std::integral_constant<int, 0>{});
+        }
+        store_o(o, l, ob, ti);
+    };
+    auto run = [&](auto two_tag) {
+        constexpr bool TWO = decltype(two_tag)::value;  // this wave owns query tiles (w, w + 9) or only w
+        for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
+            const int cur = it & 1;
+            const int b = pair / a.heads, h = pair - b * a.heads;
+            const int pn = pair + gridDim.x;
+            const bool more = pn < npairs;
+            FA_TS(0);
+            // My pieces of K(pair) were issued after the previous pair's second barrier.  Loads younger than them: the Q
+            // loads of the tiles I own (6 each), so "at most that many outstanding" implies the pieces have landed.
+            if (it > 0) {
+                if (TWO) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+            // past this barrier: K(pair) is complete in LDS, every wave is done with V(previous pair) and K(previous pair)
+            FA_BARRIER();
+            FA_TS(1);
+            stage(a.v + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs, 2);
+            const unsigned kaddr = (unsigned)(uintptr_t)lds + cur * BUF + kbase;  // LDS byte address of this lane's K row
+            bf16 *ob = a.o + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
+            f32x4 sc[NT];
+            bf16x4 pr[NT];
+            s_phase(kaddr, qf[0], sc);
+            FA_TS(2);
+            float l = softmax(sc, pr);
+            FA_TS(3);
+            // V(pair) must be complete in LDS for every wave (nothing younger than its pieces is in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FA_TS(4);
+            FA_BARRIER();
+            FA_TS(5);
+            // K of the next pair streams in under the rest of this pair (its buffer is free since the first barrier)
+            if (more) {
+                const int bn = pn / a.heads, hn = pn - bn * a.heads;
+                stage(a.k + (int64_t)bn * a.k_bs + (int64_t)hn * a.k_hs, cur ^ 1);
+            }
+            pv_phase(pr, l, ob, 0);
+            if (more) load_q(pn, 0, qf[0]);  // consumed a pair from now
+            FA_TS(6);
+            if constexpr (TWO) {
+                s_phase(kaddr, qf[1], sc);
+                FA_TS(7);
+                l = softmax(sc, pr);
+                FA_TS(8);
+                pv_phase(pr, l, ob, 1);
+                if (more) load_q(pn, 1, qf[1]);
+                FA_TS(9);
+            }
+        }
+    };
+    if (two_tiles) run(std::true_type{});
+    else run(std::false_type{});
+#undef FA_TS
+#undef FA_BARRIER
+}
+
+template <int HD, int NT>
+int launch_attn_frame(const AttnArgs &a, hipStream_t s) {
+    constexpr int CH = HD / 8;
+    constexpr int NPIECE = (NT * 16 * CH + (12 - CH) + 63) / 64;
+    constexpr int smem = 3 * NPIECE * 1024;
+    static bool attr_set = false;
+    static int num_cu = 0;
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_frame_kernel<HD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int dev = 0;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    const int npairs = a.batch * a.heads;
+    const int grid = npairs < num_cu ? npairs : num_cu;
+    hipLaunchKernelGGL((attn_frame_kernel<HD, NT>), dim3(grid), dim3(576), smem, s, a);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 template <int NWQ>
 int launch_attn_v2(const AttnArgs &a, hipStream_t s) {
     size_t smem = (size_t)4 * 64 * a.hd * 2 + 256 + (2 * 64 + 2) * sizeof(int);
@@ -428,6 +762,10 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
     if ((a.hd & 7) || a.hd > 128 || (a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 7) || ((uintptr_t)a.o & 15) || (a.q_hs & 7) ||
         (a.k_hs & 7) || (a.v_hs & 7) || (a.o_hs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.v_bs & 7) || (a.o_bs & 7))
         return EILEV_E_UNSUPPORTED;
+    // whole-frame ViT attention: S = 257 (17 tiles of 16), hd = 88, no mask, q / k / v rows of one fused buffer
+    if (!g_attn_force_v1 && !(a.dbg & 4) && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
+        a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll)
+        return launch_attn_frame<88, 17>(a, s);
     if (!g_attn_force_v1 && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
         const int qt = (a.sq + 31) / 32;
         if (qt == 9 || qt > 16) return (qt == 9) ? launch_attn_v2<9>(a, s) : launch_attn_v2<8>(a, s);

@@ -93,7 +93,9 @@ def test_layernorm(hip, rows, cols):
 
 @pytest.mark.parametrize("batch,heads,sq,skv,hd,causal,masked", [
     (3, 2, 17, 17, 88, 0, False),      # ViT mid config
-    (2, 16, 257, 257, 88, 0, False),   # ViT-g frame
+    (2, 16, 257, 257, 88, 0, False),   # ViT-g frame (persistent frame kernel, one pair per workgroup)
+    (40, 16, 257, 257, 88, 0, False),  # 640 (frame, head) pairs > 256 CUs: the frame kernel's K/V ring over several pairs
+    (3, 2, 270, 270, 88, 0, False),    # other S in (256, 272]: partially filled last key tile
     (2, 12, 32, 32, 64, 0, False),     # Q-Former self
     (2, 12, 32, 2056, 64, 0, False),   # Q-Former cross over 8 frames
     (2, 4, 100, 100, 80, 1, True),     # OPT prefill, left padding
