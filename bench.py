@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=16, help="16-shot samples per GPU per step (<= 16: one decode batch)")
+    ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -1072,6 +1072,7 @@ struct SkinnyArgs {
     GemmArgs g;
     float *part;
     int ks;
+    int mr;  // rows per split-K partial: 16 (M <= 16) or 32
 };
 
 __device__ __forceinline__ void skinny_epilogue(const GemmArgs &g, int row, int col, float v) {
@@ -1148,10 +1149,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs a) {
 // counted s_waitcnt vmcnt(8) that retires DMA(t); no workgroup barrier in the K loop.  16-byte chunk c of
 // row r is stored at chunk c ^ (r & 15) (swizzle applied on the source address) so the ds_read_b128 fragment
 // reads of 16 rows x 512-byte stride are bank-conflict-free.
+// MB = 1: M <= 16; MB = 2: M <= 32 (two 16-row activation tiles share every weight fragment: the weight stream, which
+// bounds the kernel, is read once for twice the rows)
+template <int MB>
 __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     __shared__ __attribute__((aligned(16))) char wbuf[4][2][8192];
-    __shared__ float red[4][64][4];
+    __shared__ float red[4][MB][64][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -1178,15 +1182,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_global_load_lds((glb_void *)(src[i] + t * 256), (lds_void *)(&wbuf[wid][buf][i * 1024]), 16, 0, 0);
     };
-    const bf16 *ap = g.A + (int64_t)(l15 < g.M ? l15 : 0) * g.lda + lg * 8;
-    const bool arow = l15 < g.M;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16 *ap[MB];
+    bool arow[MB];
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = mb * 16 + l15;
+        arow[mb] = r < g.M;
+        ap[mb] = g.A + (int64_t)(arow[mb] ? r : 0) * g.lda + lg * 8;
+        acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     if (beg < end) stage_in(0, beg);
     for (int t = beg; t < end; ++t) {
         const int cur = (t - beg) & 1;
-        bf16x8 av[8];
+        bf16x8 av[MB][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = arow ? *reinterpret_cast<const bf16x8 *>(ap + t * 256 + u * 32) : zero8();
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
         if (t + 1 < end) {
             stage_in(cur ^ 1, t + 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile t (older than the 8 just issued)
@@ -1198,23 +1211,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], wv, acc, 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wid][lane][r] = acc[r];
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wid][mb][lane][r] = acc[mb][r];
     __syncthreads();
-    if (wid == 0) {
+    if (wid < MB) {  // wave mb finishes row tile mb
         const int col = n0 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[w][lane][r];
-            const int row = lg * 4 + r;
+            for (int w = 0; w < 4; ++w) v += red[w][wid][lane][r];
+            const int row = wid * 16 + lg * 4 + r;
             if (row < g.M && col < g.N) {
                 if (a.ks == 1) skinny_epilogue(g, row, col, v);
-                else a.part[((int64_t)blockIdx.y * 16 + row) * g.N + col] = v;
+                else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
             }
         }
     }
@@ -1226,7 +1242,7 @@ __global__ void skinny_reduce_kernel(const SkinnyArgs a) {
     if (idx >= g.M * g.N) return;
     const int row = idx / g.N, col = idx - row * g.N;
     float v = 0.0f;
-    for (int s = 0; s < a.ks; ++s) v += a.part[((int64_t)s * 16 + row) * g.N + col];
+    for (int s = 0; s < a.ks; ++s) v += a.part[((int64_t)s * a.mr + row) * g.N + col];
     skinny_epilogue(g, row, col, v);
 }
 
@@ -1290,21 +1306,25 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (g.M <= 0) return EILEV_OK;
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
-    if (g.M > 16 && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
+    const bool dma_ok = g.K % 256 == 0 && !(g.dbg & 8);
+    const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0;
+    if (!skinny && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
                                    (g.bias && ((uintptr_t)g.bias & 7))))
         return EILEV_E_UNSUPPORTED;
     int rc;
-    if (g.M <= 16 && g.patch_group == 0) {
+    if (skinny) {
         SkinnyArgs a;
         a.g = g;
+        a.mr = g.M <= 16 ? 16 : 32;
         const int nb = (g.N + 15) / 16;
         int ks = nb >= 512 ? 1 : (512 + nb - 1) / nb;
         const int ksteps = (g.K + 31) / 32;
         if (ks > ksteps / 32) ks = ksteps / 32 > 0 ? ksteps / 32 : 1;  // >= 8 K-steps of 32 per wave
-        if (ks > 1 && (!g.scratch || (size_t)ks * 16 * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
+        if (ks > 1 && (!g.scratch || (size_t)ks * a.mr * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
         a.ks = ks;
         a.part = g.scratch;
-        if (g.K % 256 == 0 && !(g.dbg & 8)) hipLaunchKernelGGL(gemm_skinny_dma_kernel, dim3(nb, ks), dim3(256), 0, s, a);
+        if (dma_ok && g.M > 16) hipLaunchKernelGGL(gemm_skinny_dma_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
+        else if (dma_ok) hipLaunchKernelGGL(gemm_skinny_dma_kernel<1>, dim3(nb, ks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
         if (ks > 1) {

@@ -486,7 +486,7 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
                                      size_t workspace_bytes, void *stream) {
     if (!d || !w || !tokens || !state || !attn_mask || !n_valid || !kv_cache || !logits || !finished || !out_tokens || !workspace)
         return EILEV_E_BADARG;
-    if (batch <= 0 || batch > 16 || seq_len + max_new > kv_capacity + 1) return EILEV_E_BADARG;
+    if (batch <= 0 || seq_len + max_new > kv_capacity + 1) return EILEV_E_BADARG;
     if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
     if (workspace_bytes < eilev_opt_workspace_bytes(d, batch, 1)) return EILEV_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

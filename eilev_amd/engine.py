@@ -234,8 +234,8 @@ class HipEngine:
         B, L, _ = inputs_embeds.shape
         if max_new_tokens <= 0:
             return torch.empty((B, 0), dtype=torch.int64, device=self.device)
-        if B > 16:
-            raise NotImplementedError("decode batch > 16 per call is not supported yet; split the batch")
+        if B > 32:
+            raise NotImplementedError("decode batch > 32 per call is not supported yet; split the batch")
         cap = L + max_new_tokens
         am = attention_mask.to(self.device, torch.int32).contiguous()
         last, _, kv = self.prefill(inputs_embeds, am, kv_capacity=cap)
@@ -308,8 +308,8 @@ class HipEngine:
         d = self.dims
         B, L, _ = inputs_embeds.shape
         R = B * num_beams
-        if R > 16:
-            raise NotImplementedError("batch * num_beams > 16 rows per decode call is not supported yet")
+        if R > 32:
+            raise NotImplementedError("batch * num_beams > 32 rows per decode call is not supported yet")
         cap = L + max_new_tokens
         am = attention_mask.to(self.device, torch.int32).contiguous()
         last, _, kv_small = self.prefill(inputs_embeds, am, kv_capacity=cap)

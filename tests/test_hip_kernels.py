@@ -54,7 +54,8 @@ def test_linear_tiled(hip, m, n, k, epi):
     _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 160, 160), (8, 2560, 2560), (8, 7680, 2560), (3, 320, 160), (16, 1000, 10240), (8, 50272, 2560)])
+@pytest.mark.parametrize("m,n,k", [(1, 160, 160), (8, 2560, 2560), (8, 7680, 2560), (3, 320, 160), (16, 1000, 10240), (8, 50272, 2560),
+                                   (32, 2560, 2560), (17, 7680, 2560), (25, 2560, 10240), (20, 320, 160)])
 def test_linear_skinny(hip, m, n, k):
     _lin_case(hip, m, n, k, 0, bias=True, resid=True)
     _lin_case(hip, m, n, k, 2, bias=True, resid=False)
@@ -63,6 +64,7 @@ def test_linear_skinny(hip, m, n, k):
 def test_linear_f32_logits(hip):
     _lin_case(hip, 300, 1000, 160, 0, bias=False, resid=False, out_f32=True)
     _lin_case(hip, 4, 50272, 2560, 0, bias=False, resid=False, out_f32=True)
+    _lin_case(hip, 32, 50272, 2560, 0, bias=False, resid=False, out_f32=True)
 
 
 def test_linear_rejects_unaligned_k(hip):
