@@ -4,8 +4,8 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP = one pass of the hot path over one batch of synthetic input per GPU: `--samples` (default 16)
-16-shot samples = 16 x 17 clips x 8 frames of 224x224 pixels (bf16, resident in HBM) through ViT-g/14 ->
+One STEP = one pass of the hot path over one batch of synthetic input per GPU: `--samples` (default 32)
+16-shot samples, each 17 clips x 8 frames of 224x224 pixels (bf16, resident in HBM) through ViT-g/14 ->
 Q-Former -> projection -> [all-gather of clip tokens when N > 1] -> embed+scatter -> OPT-2.7B prefill
 (L = 960) -> 32 greedy tokens (EOS disabled, decode under hipGraph).  Weak scaling: every rank gets its own
 `--samples` samples; clips of the global step are dealt round-robin over the ranks (eilev_amd/sharding.py).
@@ -224,8 +224,8 @@ def main():
             try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
                 with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
                     tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
-                if tr:  # measured per 136-frame launch; the bench launches 544 frames at a time
-                    traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024 * 4)
+                if tr:  # measured on the bench's launch shape (544 frames x 257 tokens per launch)
+                    traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
             except OSError:
                 pass
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
