@@ -39,7 +39,10 @@ QF_LAYER_FIELDS = ["sq_w", "sq_b", "sk_w", "sk_b", "sv_w", "sv_b", "so_w", "so_b
 OPT_LAYER_FIELDS = ["ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",
                     "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
 
+T5_LAYER_FIELDS = ["ln_sa", "q_w", "k_w", "v_w", "o_w", "ln_ca", "cq_w", "ck_w", "cv_w", "co_w", "ln_ff", "wi0_w", "wi1_w", "wo_w"]
+
 VitLayer = _ptr_struct("VitLayer", VIT_LAYER_FIELDS)
+T5Layer = _ptr_struct("T5Layer", T5_LAYER_FIELDS)
 QfLayer = _ptr_struct("QfLayer", QF_LAYER_FIELDS)
 OptLayer = _ptr_struct("OptLayer", OPT_LAYER_FIELDS)
 
@@ -56,6 +59,18 @@ class QfWeights(C.Structure):
 class OptWeights(C.Structure):
     _fields_ = [("embed_tokens", vp), ("embed_positions", vp), ("final_ln_w", vp), ("final_ln_b", vp),
                 ("layers", C.POINTER(OptLayer))]
+
+
+class T5Dims(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("d_kv", C.c_int32), ("heads", C.c_int32), ("d_ff", C.c_int32),
+                ("enc_layers", C.c_int32), ("dec_layers", C.c_int32), ("vocab", C.c_int32),
+                ("rel_buckets", C.c_int32), ("rel_max_dist", C.c_int32), ("eps", C.c_float),
+                ("scale_decoder_outputs", C.c_int32), ("emulate_bf16", C.c_int32)]
+
+
+class T5Weights(C.Structure):
+    _fields_ = [("shared", vp), ("lm_head", vp), ("enc_rel_bias", vp), ("dec_rel_bias", vp), ("enc_final_ln", vp),
+                ("dec_final_ln", vp), ("enc_layers", C.POINTER(T5Layer)), ("dec_layers", C.POINTER(T5Layer))]
 
 
 # HF state-dict key suffixes for each struct field.
@@ -108,12 +123,43 @@ def opt_layer_keys(i):
     return {f: OPT_PREFIX.format(i) + s for f, s in _OPT_KEYS.items()}
 
 
+def t5_layer_keys(stack: str, i: int):
+    """struct field -> state-dict key of T5 block i of `stack` ("encoder" / "decoder")."""
+    p = f"language_model.{stack}.block.{i}.layer."
+    ff = 2 if stack == "decoder" else 1
+    k = {"ln_sa": p + "0.layer_norm.weight"}
+    for n in "qkvo":
+        k[f"{n}_w"] = p + f"0.SelfAttention.{n}.weight"
+    if stack == "decoder":
+        k["ln_ca"] = p + "1.layer_norm.weight"
+        for n in "qkvo":
+            k[f"c{n}_w"] = p + f"1.EncDecAttention.{n}.weight"
+    k["ln_ff"] = p + f"{ff}.layer_norm.weight"
+    for n, f in (("wi_0", "wi0_w"), ("wi_1", "wi1_w"), ("wo", "wo_w")):
+        k[f] = p + f"{ff}.DenseReluDense.{n}.weight"
+    return k
+
+
+def t5_dims_from_config(config, emulate_bf16: bool = False) -> T5Dims:
+    t = config.text_config
+    if t.feed_forward_proj != "gated-gelu":
+        raise NotImplementedError("only the gated-gelu (T5 v1.1 / flan-t5) feed-forward is built")
+    d = T5Dims()
+    d.d_model, d.d_kv, d.heads, d.d_ff = t.d_model, t.d_kv, t.num_heads, t.d_ff
+    d.enc_layers, d.dec_layers, d.vocab = t.num_layers, t.num_decoder_layers, t.vocab_size
+    d.rel_buckets, d.rel_max_dist, d.eps = t.relative_attention_num_buckets, t.relative_attention_max_distance, t.layer_norm_epsilon
+    d.scale_decoder_outputs = int(bool(getattr(t, "scale_decoder_outputs", getattr(t, "tie_word_embeddings", True))))
+    d.emulate_bf16 = int(emulate_bf16)
+    return d
+
+
 def dims_from_config(config, emulate_bf16: bool = False) -> Dims:
     """Fill EilevDims from a transformers Blip2Config (eps/sizes are read, never hard-coded)."""
     v, q, t = config.vision_config, config.qformer_config, config.text_config
-    if getattr(t, "model_type", "opt") != "opt":
-        raise NotImplementedError("only the decoder-only OPT language model is built on the HIP path so far")
-    if not getattr(t, "do_layer_norm_before", True) or getattr(t, "word_embed_proj_dim", t.hidden_size) != t.hidden_size:
+    mt = getattr(t, "model_type", "opt")
+    if mt not in ("opt", "t5"):
+        raise NotImplementedError(f"language model type {mt!r}: only OPT (decoder-only) and T5 (encoder-decoder) are built")
+    if mt == "opt" and (not getattr(t, "do_layer_norm_before", True) or getattr(t, "word_embed_proj_dim", t.hidden_size) != t.hidden_size):
         raise NotImplementedError("OPT variants with post-LN or projected embeddings (opt-350m) are not supported")
     d = Dims()
     d.image_size, d.patch_size = v.image_size, v.patch_size
@@ -121,8 +167,11 @@ def dims_from_config(config, emulate_bf16: bool = False) -> Dims:
     d.v_eps = v.layer_norm_eps
     d.q_hidden, d.q_inter, d.q_layers, d.q_heads = q.hidden_size, q.intermediate_size, q.num_hidden_layers, q.num_attention_heads
     d.q_cross_freq, d.num_query, d.q_eps = q.cross_attention_frequency, config.num_query_tokens, q.layer_norm_eps
-    d.t_hidden, d.t_ffn, d.t_layers, d.t_heads = t.hidden_size, t.ffn_dim, t.num_hidden_layers, t.num_attention_heads
-    d.vocab, d.max_pos, d.t_eps = t.vocab_size, t.max_position_embeddings, 1e-5  # nn.LayerNorm default (hf modeling_opt.py:215)
+    if mt == "t5":  # the OPT fields stay 0; projection / embedding only read t_hidden and vocab
+        d.t_hidden, d.vocab = t.d_model, t.vocab_size
+    else:
+        d.t_hidden, d.t_ffn, d.t_layers, d.t_heads = t.hidden_size, t.ffn_dim, t.num_hidden_layers, t.num_attention_heads
+        d.vocab, d.max_pos, d.t_eps = t.vocab_size, t.max_position_embeddings, 1e-5  # nn.LayerNorm default (hf modeling_opt.py:215)
     d.emulate_bf16 = int(emulate_bf16)
     return d
 
@@ -130,9 +179,10 @@ def dims_from_config(config, emulate_bf16: bool = False) -> Dims:
 class WeightPack:
     """The three weight structs plus the ctypes arrays they point to (kept alive here)."""
 
-    def __init__(self, dims: Dims, addr):
+    def __init__(self, dims: Dims, addr, t5dims: "T5Dims | None" = None):
         """``addr(key) -> int`` returns the address of the state-dict tensor ``key``."""
         self.dims = dims
+        self.t5dims = t5dims
         self._vit_layers = (VitLayer * dims.v_layers)()
         for i in range(dims.v_layers):
             for f, k in vit_layer_keys(i).items():
@@ -152,12 +202,34 @@ class WeightPack:
         for i in range(dims.t_layers):
             for f, k in opt_layer_keys(i).items():
                 setattr(self._opt_layers[i], f, addr(k))
-        self.opt = OptWeights(
-            addr("language_model.model.decoder.embed_tokens.weight"),
-            addr("language_model.model.decoder.embed_positions.weight"),
-            addr("language_model.model.decoder.final_layer_norm.weight"),
-            addr("language_model.model.decoder.final_layer_norm.bias"),
-            C.cast(self._opt_layers, C.POINTER(OptLayer)))
+        if t5dims is None:
+            self.opt = OptWeights(
+                addr("language_model.model.decoder.embed_tokens.weight"),
+                addr("language_model.model.decoder.embed_positions.weight"),
+                addr("language_model.model.decoder.final_layer_norm.weight"),
+                addr("language_model.model.decoder.final_layer_norm.bias"),
+                C.cast(self._opt_layers, C.POINTER(OptLayer)))
+            self.embed_tokens = self.opt.embed_tokens
+        else:
+            self._t5_layers = {}
+            for stack, n in (("encoder", t5dims.enc_layers), ("decoder", t5dims.dec_layers)):
+                arr = (T5Layer * n)()
+                for i in range(n):
+                    for f, k in t5_layer_keys(stack, i).items():
+                        setattr(arr[i], f, addr(k))
+                self._t5_layers[stack] = arr
+            rb = "language_model.{}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"
+            shared = addr("language_model.shared.weight")
+            try:  # untied head (original flan-t5 checkpoints); the installed transformers always ties it to `shared`
+                head = addr("language_model.lm_head.weight") or shared
+            except KeyError:
+                head = shared
+            self.t5 = T5Weights(shared, head, addr(rb.format("encoder")),
+                                addr(rb.format("decoder")), addr("language_model.encoder.final_layer_norm.weight"),
+                                addr("language_model.decoder.final_layer_norm.weight"),
+                                C.cast(self._t5_layers["encoder"], C.POINTER(T5Layer)),
+                                C.cast(self._t5_layers["decoder"], C.POINTER(T5Layer)))
+            self.embed_tokens = shared
         self.proj_w = addr("language_projection.weight")
         self.proj_b = addr("language_projection.bias")
 
@@ -167,7 +239,8 @@ EXPORTS = [
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
-    "eilev_prof_collect",
+    "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
+    "eilev_t5_self_kv_bytes", "eilev_t5_decode",
 ]
 
 
@@ -207,6 +280,19 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_layernorm.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.eilev_attention.restype = i32
     lib.eilev_attention.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
+    TP = C.POINTER(T5Dims)
+    lib.eilev_t5_workspace_bytes.restype = sz
+    lib.eilev_t5_workspace_bytes.argtypes = [TP, i64, i64, i64]
+    lib.eilev_t5_encode.restype = i32
+    lib.eilev_t5_encode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, vp, vp, sz, vp]
+    lib.eilev_t5_cross_kv_bytes.restype = sz
+    lib.eilev_t5_cross_kv_bytes.argtypes = [TP, i64, i64]
+    lib.eilev_t5_cross_kv.restype = i32
+    lib.eilev_t5_cross_kv.argtypes = [TP, C.POINTER(T5Weights), vp, i64, i64, vp, vp]
+    lib.eilev_t5_self_kv_bytes.restype = sz
+    lib.eilev_t5_self_kv_bytes.argtypes = [TP, i64, i64]
+    lib.eilev_t5_decode.restype = i32
+    lib.eilev_t5_decode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_prof_enable.restype = i32
     lib.eilev_prof_enable.argtypes = [i32]
     lib.eilev_prof_collect.restype = i32

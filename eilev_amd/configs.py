@@ -40,6 +40,34 @@ CONFIGS = {
                          word_embed_proj_dim=2560),
         num_query_tokens=32,
     ),
+    # encoder-decoder language model (flan-t5 family: gated-gelu FFN, RMSNorm, relative position bias, no biases)
+    "tiny_t5": dict(
+        vision_config=dict(hidden_size=16, intermediate_size=32, num_hidden_layers=2,
+                           num_attention_heads=2, patch_size=8, image_size=32),
+        qformer_config=dict(hidden_size=16, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=32, encoder_hidden_size=16),
+        text_config=dict(model_type="t5", d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, num_decoder_layers=2,
+                         vocab_size=128, feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0),
+        num_query_tokens=4,
+    ),
+    "mid_t5": dict(
+        vision_config=dict(hidden_size=176, intermediate_size=352, num_hidden_layers=2,
+                           num_attention_heads=2, patch_size=14, image_size=56),
+        qformer_config=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=256, encoder_hidden_size=176),
+        text_config=dict(model_type="t5", d_model=192, d_kv=64, num_heads=2, d_ff=320, num_layers=2, num_decoder_layers=2,
+                         vocab_size=512, feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0),
+        num_query_tokens=8,
+    ),
+    "t5xl": dict(  # eilev-blip2-flan-t5-xl
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                            intermediate_size=3072, encoder_hidden_size=1408),
+        text_config=dict(model_type="t5", d_model=2048, d_kv=64, num_heads=32, d_ff=5120, num_layers=24, num_decoder_layers=24,
+                         vocab_size=32128, feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0),
+        num_query_tokens=32,
+    ),
 }
 
 

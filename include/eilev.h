@@ -170,6 +170,57 @@ int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, const void *i
                      int64_t batch, int64_t new_len, int64_t past_len, void *kv_cache, int64_t kv_capacity,
                      float *logits_all, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- encoder-decoder language model: flan-t5 (BASELINE configs[3]) -----------------------
+ * Replaces T5ForConditionalGeneration as driven by ref:eilev/model/v2.py:228-238 (forward) and :318-322 (generate):
+ * hf models/t5/modeling_t5.py T5Stack :640-752, T5Block :435-510, T5Attention :176-370 (no 1/sqrt(d) scaling; relative
+ * position bias of block 0 shared by every block of the stack; :217-262 bucket function), T5LayerNorm :50-72 (RMS, no
+ * bias), T5DenseGatedActDense :97-124 (gelu_new(wi_0 x) * wi_1 x), lm_head :1030-1036.  No linear layer has a bias. */
+typedef struct EilevT5Dims {
+    int32_t d_model, d_kv, heads, d_ff, enc_layers, dec_layers, vocab;
+    int32_t rel_buckets, rel_max_dist;   /* relative_attention_num_buckets / _max_distance */
+    float eps;                           /* layer_norm_epsilon */
+    int32_t scale_decoder_outputs;       /* 1: sequence_output *= d_model^-0.5 before lm_head (T5 v1.0 configs) */
+    int32_t emulate_bf16;                /* oracle only */
+} EilevT5Dims;
+
+typedef struct EilevT5Layer {
+    const void *ln_sa;                          /* layer[0].layer_norm.weight [D] */
+    const void *q_w, *k_w, *v_w, *o_w;          /* SelfAttention q/k/v [H*dkv, D], o [D, H*dkv] */
+    const void *ln_ca;                          /* decoder: layer[1].layer_norm (NULL in the encoder) */
+    const void *cq_w, *ck_w, *cv_w, *co_w;      /* decoder: EncDecAttention (NULL in the encoder) */
+    const void *ln_ff;                          /* layer[-1].layer_norm */
+    const void *wi0_w, *wi1_w, *wo_w;           /* DenseReluDense wi_0/wi_1 [F, D], wo [D, F] */
+} EilevT5Layer;
+
+typedef struct EilevT5Weights {
+    const void *shared;                         /* [vocab, D] input embedding of encoder and decoder */
+    const void *lm_head;                        /* [vocab, D] (== shared when tied) */
+    const void *enc_rel_bias, *dec_rel_bias;    /* block[0].layer[0].SelfAttention.relative_attention_bias [buckets, H] */
+    const void *enc_final_ln, *dec_final_ln;    /* [D] */
+    const EilevT5Layer *enc_layers, *dec_layers;/* host arrays */
+} EilevT5Weights;
+
+/* rows = max tokens per sequence processed by one call (encoder length or decoder new_len), kv_len = max keys */
+size_t eilev_t5_workspace_bytes(const EilevT5Dims *d, int64_t batch, int64_t rows, int64_t kv_len);
+/* encoder stack on inputs_embeds (batch, enc_len, D) (= shared[input_ids] with the video rows scattered in,
+ * eilev_embed_scatter); attn_mask (batch, enc_len) int32; enc_out (batch, enc_len, D) = encoder last_hidden_state. */
+int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                    int64_t batch, int64_t enc_len, void *enc_out, void *workspace, size_t workspace_bytes, void *stream);
+/* cross-attention keys/values of every decoder block, computed once per encoder output:
+ * [dec_layer][k|v][batch][head][enc_len][d_kv] */
+size_t eilev_t5_cross_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t enc_len);
+int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, const void *enc_out, int64_t batch, int64_t enc_len,
+                      void *cross_kv, void *stream);
+/* decoder self-attention cache: [dec_layer][k|v][batch][head][capacity][d_kv] */
+size_t eilev_t5_self_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t kv_capacity);
+/* decoder over new_len positions past_len .. past_len + new_len - 1 of every sequence (teacher forcing: past_len = 0,
+ * new_len = target length; generation: new_len = 1).  dec_ids (batch, new_len) int64; enc_mask (batch, enc_len) int32;
+ * logits (batch, new_len, vocab) f32. */
+int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                    int64_t batch, int64_t new_len, int64_t past_len, void *self_kv, int64_t kv_capacity,
+                    const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
 /* ---- stage 5: greedy decode ---------------------------------------------------------------
  * Replaces one iteration of GenerationMixin._sample with do_sample=False
  * (hf generation/utils.py:2876-2937): argmax of the fp32 last-row logits, pad-after-EOS,

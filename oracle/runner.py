@@ -55,7 +55,9 @@ class OracleModel:
         self.config = config
         self.w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
         self.dims = abi.dims_from_config(config, emulate_bf16)
-        self.pack = abi.WeightPack(self.dims, lambda k: self.w[k].ctypes.data)
+        self.is_t5 = getattr(config.text_config, "model_type", "opt") == "t5"
+        self.t5dims = abi.t5_dims_from_config(config, emulate_bf16) if self.is_t5 else None
+        self.pack = abi.WeightPack(self.dims, lambda k: self.w[k].ctypes.data, self.t5dims)
         self.lib = lib()
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
@@ -96,7 +98,7 @@ class OracleModel:
         vm = None if video_mask is None else np.ascontiguousarray(video_mask != 0, dtype=np.uint8)
         vf = None if video_feats is None else np.ascontiguousarray(video_feats, dtype=np.float32)
         out = np.empty((B, L, self.dims.t_hidden), np.float32)
-        abi.check(self.lib.eilev_embed_scatter(C.byref(self.dims), self.pack.opt.embed_tokens, _p(ids), _p(vm), _p(vf),
+        abi.check(self.lib.eilev_embed_scatter(C.byref(self.dims), self.pack.embed_tokens, _p(ids), _p(vm), _p(vf),
                                                0 if vf is None else vf.shape[0], B, L, _p(out), None), "oracle embed_scatter")
         return out
 
@@ -190,6 +192,72 @@ class OracleModel:
             ll = np.where(rows_msk != 0, tok - lse, 0.0).reshape(B, nc, Lc).sum(-1)
             cols.append(ll / msk.sum(-1)[None].astype(np.float64))
         return np.concatenate(cols, axis=1).astype(np.float32)
+
+    # ---- encoder-decoder LM (flan-t5) ----------------------------------------------------------------------
+    def t5_encode(self, inputs_embeds, attn_mask):
+        d = self.t5dims
+        x = np.ascontiguousarray(inputs_embeds, dtype=np.float32)
+        B, L, _ = x.shape
+        am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        out = np.empty_like(x)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, L, L)
+        ws = np.empty(nb // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_t5_encode(C.byref(d), C.byref(self.pack.t5), _p(x), _p(am), B, L, _p(out), _p(ws), nb, None), "oracle t5 encode")
+        return out
+
+    def t5_cross_kv(self, enc_out):
+        d = self.t5dims
+        B, L, _ = enc_out.shape
+        kv = np.zeros(self.lib.eilev_t5_cross_kv_bytes(C.byref(d), B, L) // 4, np.float32)
+        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _p(np.ascontiguousarray(enc_out, np.float32)), B, L, _p(kv), None),
+                  "oracle t5 cross kv")
+        return kv
+
+    def t5_decode(self, dec_ids, enc_mask, past_len, self_kv, cap, cross_kv, enc_len):
+        d = self.t5dims
+        ids = np.ascontiguousarray(dec_ids, dtype=np.int64)
+        B, T = ids.shape
+        am = np.ascontiguousarray(enc_mask, dtype=np.int32)
+        logits = np.empty((B, T, d.vocab), np.float32)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, T, max(enc_len, past_len + T))
+        ws = np.empty(nb // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_t5_decode(C.byref(d), C.byref(self.pack.t5), _p(ids), _p(am), B, T, past_len, _p(self_kv), cap, _p(cross_kv),
+                                           enc_len, _p(logits), _p(ws), nb, None), "oracle t5 decode")
+        return logits
+
+    def t5_forward_logits(self, pixels, input_ids, attn_mask, video_mask, decoder_input_ids):
+        """= reference forward(..., decoder_input_ids / labels).logits for the encoder-decoder LM (ref:eilev/model/v2.py:228-238);
+        also returns the encoder's last hidden state."""
+        d = self.t5dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        enc = self.t5_encode(emb, attn_mask)
+        ckv = self.t5_cross_kv(enc)
+        B, T = np.asarray(decoder_input_ids).shape
+        skv = np.zeros(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T) // 4, np.float32)
+        return self.t5_decode(decoder_input_ids, attn_mask, 0, skv, T, ckv, enc.shape[1]), enc
+
+    def t5_generate(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0):
+        """Greedy = reference generate(num_beams=1, do_sample=False) for T5: returns decoder ids INCLUDING the start token."""
+        d = self.t5dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        enc = self.t5_encode(emb, attn_mask)
+        ckv = self.t5_cross_kv(enc)
+        B, L = enc.shape[:2]
+        cap = max_new_tokens + 1
+        skv = np.zeros(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, cap) // 4, np.float32)
+        cur = np.full((B, 1), start_id, np.int64)
+        out = [cur.copy()]
+        done = np.zeros(B, bool)
+        for t in range(max_new_tokens):
+            logits = self.t5_decode(cur, attn_mask, t, skv, cap, ckv, L)[:, 0]
+            nxt = logits.argmax(-1).astype(np.int64)
+            nxt = np.where(done, pad_id, nxt)
+            out.append(nxt[:, None])
+            done |= nxt == eos_id
+            cur = nxt[:, None]
+            if done.all():
+                break
+        return np.concatenate(out, axis=1)
 
     def generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1,
                       pad_id=1, early_stopping=False):

@@ -146,3 +146,38 @@ def test_classify_matches_reference(golden_dir, models, name):
         tok = np.take_along_axis(shift, ids[..., None], axis=-1)[..., 0]
         want = (np.where(cm[c][None] != 0, tok - lse, 0.0).sum(-1) / cm[c].sum())
         assert np.abs(want - ll[:, c]).max() < 2e-4
+
+
+T5_CASES = ["tiny_t5_b2", "mid_t5_b1", "mid_t5_b2"]
+
+
+@pytest.mark.parametrize("name", T5_CASES)
+def test_t5_path_matches_reference(golden_dir, models, name):
+    """Encoder-decoder LM (flan-t5 family, BASELINE configs[3]): oracle encoder output, teacher-forced logits, loss and greedy
+    ids vs the reference's own forward(labels=...) / generate() (right-padded encoder batch, padded targets)."""
+    path = os.path.join(golden_dir, f"{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g, meta, cfg, px = load_case(golden_dir, name)
+    m = models(meta["config"])
+    logits, enc = m.t5_forward_logits(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"])
+    valid = g["attention_mask"] == 1
+    assert np.abs(enc - g["fp32_enc"])[valid].max() < 2e-4
+    assert logits.shape == g["fp32_logits"].shape
+    assert np.abs(logits - g["fp32_logits"]).max() < 5e-4
+    assert abs(shifted_ce_loss_t5(logits, g["labels"]) - float(g["fp32_loss"])) < 1e-4
+    n = meta["new_tokens"]
+    ids = m.t5_generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, eos_id=-1)
+    assert np.array_equal(ids, g["fp32_greedy_free"])
+    ids = m.t5_generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, eos_id=int(g["fp32_eos_id"]))
+    ref = g["fp32_greedy_eos"]
+    assert np.array_equal(ids[:, : ref.shape[1]], ref) and ids.shape[1] == ref.shape[1]
+
+
+def shifted_ce_loss_t5(logits, labels):
+    """CrossEntropyLoss(ignore_index=-100) of logits (B, T, V) against labels (B, T) — no shift for encoder-decoder models."""
+    x = logits.astype(np.float64)
+    lse = np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1)) + x.max(-1)
+    keep = labels >= 0
+    tok = np.take_along_axis(x, np.where(keep, labels, 0)[..., None], axis=-1)[..., 0]
+    return float(((lse - tok) * keep).sum() / keep.sum())

@@ -71,15 +71,88 @@ def build_inputs(cfg_name, frames, rows):
     return pixels, input_ids, attn, vmask, labels
 
 
+T5_CASES = {
+    # name: (config, frames T, rows, target length, new_tokens)
+    "tiny_t5_b2": ("tiny_t5", 1, [([1, 1], [4, 6]), ([2], [3])], 5, 6),
+    "mid_t5_b1": ("mid_t5", 2, [([1, 1, 1], [5, 5, 4])], 6, 6),
+    "mid_t5_b2": ("mid_t5", 2, [([1, 1], [6, 7]), ([1, 1], [3, 3])], 6, 6),
+}
+
+
 def load_det_weights(model, mode="fanin"):
     sd = model.state_dict()
     new = {}
+    tied = {"language_model.lm_head.weight": None, "language_model.encoder.embed_tokens.weight": "language_model.shared.weight",
+            "language_model.decoder.embed_tokens.weight": "language_model.shared.weight"}
     for k, v in sd.items():
-        if k == "language_model.lm_head.weight":
+        if k in tied:
             continue
         new[k] = torch.from_numpy(synth_param(k, tuple(v.shape), mode)).to(v.dtype)
-    new["language_model.lm_head.weight"] = new["language_model.model.decoder.embed_tokens.weight"]
+    if "language_model.shared.weight" in new:  # T5: encoder/decoder embeddings and (installed transformers) lm_head = shared
+        for k in tied:
+            if k in sd:
+                new[k] = new["language_model.shared.weight"]
+    else:
+        new["language_model.lm_head.weight"] = new["language_model.model.decoder.embed_tokens.weight"]
     model.load_state_dict(new)
+
+
+@torch.no_grad()
+def run_t5_case(name):
+    """Encoder-decoder LM (flan-t5 family): teacher-forced forward with labels, greedy generate (ref:eilev/model/v2.py:228-238, 318-322)."""
+    cfg_name, frames, rows, tgt_len, new_tokens = T5_CASES[name]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, _ = build_inputs(cfg_name, frames, rows)
+    # T5 batches are RIGHT padded (encoder): move the padding of build_inputs to the right
+    B, L = input_ids.shape
+    for b in range(B):
+        n = int(attn[b].sum())
+        input_ids[b] = np.concatenate([input_ids[b, L - n:], np.zeros(L - n, np.int64)])
+        vmask[b] = np.concatenate([vmask[b, L - n:], np.zeros(L - n, np.int64)])
+        attn[b] = np.concatenate([np.ones(n, np.int64), np.zeros(L - n, np.int64)])
+    vocab = cfg.text_config.vocab_size
+    rng = np.random.default_rng(11)
+    labels = rng.integers(2, vocab, size=(B, tgt_len)).astype(np.int64)
+    if B > 1:
+        labels[1, tgt_len - 2:] = -100  # padded target
+    dec_in = np.concatenate([np.zeros((B, 1), np.int64), np.where(labels[:, :-1] < 0, 0, labels[:, :-1])], axis=1)  # _shift_right
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        px = t(pixels).to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=px, video_input_mask=t(vmask), labels=t(labels), return_dict=True)
+        out[f"{tag}_logits"] = o.logits.float().numpy()
+        out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
+        out[f"{tag}_enc"] = o.language_model_outputs.encoder_last_hidden_state.float().numpy()
+        o2 = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=px, video_input_mask=t(vmask), decoder_input_ids=t(dec_in),
+               return_dict=True)
+        assert torch.equal(o2.logits, o.logits)
+        free = None
+        for never in range(vocab - 1, 3, -1):
+            g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                           max_new_tokens=new_tokens, num_beams=1, do_sample=False, eos_token_id=never)
+            if not (g[:, 1:] == never).any():
+                free = g
+                break
+        assert free is not None and free.shape == (B, new_tokens + 1), free.shape
+        out[f"{tag}_greedy_free"] = free.numpy().astype(np.int64)
+        eos = int(free[0, 3])
+        g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                       max_new_tokens=new_tokens, num_beams=1, do_sample=False, eos_token_id=eos)
+        out[f"{tag}_greedy_eos"] = g.numpy().astype(np.int64)
+        out[f"{tag}_eos_id"] = np.asarray(eos, dtype=np.int64)
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="fanin",
+                torch=torch.__version__, transformers=transformers.__version__, generator="tools/make_goldens.py",
+                reference="/root/reference/eilev/model/v2.py", padding="right", scale_decoder_outputs=bool(cfg.text_config.scale_decoder_outputs))
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, labels=labels, decoder_input_ids=dec_in,
+               meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
 
 
 class _legacy_kv_compat:
@@ -196,5 +269,5 @@ def run_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or CASES):
-        run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES)):
+        (run_t5_case if n in T5_CASES else run_case)(n)
