@@ -106,7 +106,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
                 const int kl = ct * 16 + lg * 4 + r;
                 const bool ok = msk_[kl] != 0 && (!a.causal || (kv0 + kl) <= qrow + off);
                 okv[ct][r] = ok;
-                const float s = st[ct][r] * sl2;
+                float s = st[ct][r] * sl2;
+                if (a.rel_tab) {  // T5 relative position bias, a function of (key - query position) per head
+                    int ri = (kv0 + kl) - (qrow + off) + a.rel_off;
+                    ri = ri < 0 ? 0 : (ri >= a.rel_n ? a.rel_n - 1 : ri);
+                    s = fmaf(a.rel_tab[(int64_t)h * a.rel_hs + ri], 1.44269504088896340736f, s);
+                }
                 st[ct][r] = s;
                 if (ok) mx = fmaxf(mx, s);
             }
@@ -763,10 +768,10 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         (a.k_hs & 7) || (a.v_hs & 7) || (a.o_hs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.v_bs & 7) || (a.o_bs & 7))
         return EILEV_E_UNSUPPORTED;
     // whole-frame ViT attention: S = 257 (17 tiles of 16), hd = 88, no mask, q / k / v rows of one fused buffer
-    if (!g_attn_force_v1 && !(a.dbg & 4) && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
+    if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
         a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll)
         return launch_attn_frame<88, 17>(a, s);
-    if (!g_attn_force_v1 && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
+    if (!g_attn_force_v1 && !a.rel_tab && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
         const int qt = (a.sq + 31) / 32;
         if (qt == 9 || qt > 16) return (qt == 9) ? launch_attn_v2<9>(a, s) : launch_attn_v2<8>(a, s);
         if (qt >= 5) return launch_attn_v2<8>(a, s);

@@ -139,8 +139,14 @@ struct AttnArgs {
     const int32_t *key_mask;         // (batch, mask_ld) or null
     int64_t mask_ld;
     int dbg;                         // probe-only
+    // T5 relative position bias (additive, before the softmax): bias(h, i, j) = rel_tab[h * rel_hs + (j - i - (skv - sq)) +
+    // rel_off], a per-head table over the relative distance (built by launch_t5_rel_table); null = none
+    const float *rel_tab = nullptr;
+    int64_t rel_hs = 0;
+    int rel_off = 0, rel_n = 0;
 };
 int launch_attention(const AttnArgs &a, hipStream_t s);
+int launch_rmsnorm(const bf16 *x, int64_t ldx, const bf16 *g, bf16 *y, int64_t ldy, int64_t rows, int cols, float eps, hipStream_t s);
 
 void prof_begin(int kind, double flops, hipStream_t s);
 void prof_end(hipStream_t s);

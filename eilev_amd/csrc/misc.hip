@@ -371,6 +371,104 @@ __global__ void finalize_step_kernel(int32_t *__restrict__ state, const uint8_t 
 }  // namespace
 
 // ---- host launchers ------------------------------------------------------------------------------------
+// ---- T5 (flan-t5) glue -----------------------------------------------------------------------------------
+// Relative position bias table: tab[h][idx] = rel_w[bucket(idx - off)][h] (hf T5Attention.compute_bias :264-279).  The
+// bucket of a distance >= max_exact is max_exact + #{thresholds <= distance}; the thresholds are computed on the host with
+// the float32 formula of _relative_position_bucket :217-262 (same libm logf as the oracle), so the device needs no log.
+struct T5Buckets {
+    int bidirectional, nb, max_exact, nthr;
+    int thr[32];
+};
+__global__ void t5_rel_table_kernel(const bf16 *__restrict__ rel_w, float *__restrict__ tab, int n, int off, int heads, T5Buckets bk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int rel = idx - off;
+    int ret = 0, rp;
+    if (bk.bidirectional) {
+        if (rel > 0) ret += bk.nb;
+        rp = rel < 0 ? -rel : rel;
+    } else {
+        rp = rel < 0 ? -rel : 0;
+    }
+    int b = rp;
+    if (rp >= bk.max_exact) {
+        b = bk.max_exact;
+        for (int i = 0; i < bk.nthr; ++i) b += rp >= bk.thr[i];
+    }
+    for (int h = 0; h < heads; ++h) tab[(int64_t)h * n + idx] = (float)rel_w[(int64_t)(ret + b) * heads + h];
+}
+// gated activation: out = bf16(bf16(gelu_new(a)) * b), gelu_new = tanh form (hf activations NewGELUActivation);
+// a = cols [0, F), b = cols [F, 2F) of rows of ld elements
+__global__ __launch_bounds__(256) void gated_gelu_kernel(const bf16 *__restrict__ ab, int64_t ld, bf16 *__restrict__ out, int64_t rows, int F) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = F >> 3;
+    if (idx >= rows * ch) return;
+    const int64_t r = idx / ch;
+    const int c = (int)(idx - r * ch);
+    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ab + r * ld + c * 8);
+    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(ab + r * ld + F + c * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (float)a[e];
+        const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+        const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));  // tanh(u), finite for any u
+        const float g = 0.5f * x * (1.0f + t);
+        o[e] = (bf16)((float)(bf16)g * (float)b[e]);
+    }
+    *reinterpret_cast<bf16x8 *>(out + r * F + c * 8) = o;
+}
+// rows (b, t) of a projection [M, ld] (columns col0 .. col0 + heads*hd) -> cache plane [B][H][cap][hd] at slots slot0 + t
+__global__ __launch_bounds__(256) void rows_to_cache_kernel(const bf16 *__restrict__ src, int64_t ld, int col0, bf16 *__restrict__ plane,
+                                                            int rows_per_b, int heads, int hd, int cap, int slot0) {
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / rows_per_b), t = (int)(row - (int64_t)b * rows_per_b);
+    const int ch = hd >> 3;
+    for (int c = threadIdx.x; c < heads * ch; c += 256) {
+        const int hh = c / ch, cc = c - hh * ch;
+        *reinterpret_cast<bf16x8 *>(plane + (((int64_t)b * heads + hh) * cap + slot0 + t) * hd + cc * 8) =
+            *reinterpret_cast<const bf16x8 *>(src + row * ld + col0 + hh * hd + cc * 8);
+    }
+}
+
+int launch_t5_rel_table(const bf16 *rel_w, float *tab, int n, int off, int heads, int bidirectional, int num_buckets, int max_dist,
+                        hipStream_t s) {
+    T5Buckets bk;
+    int nb = num_buckets;
+    if (bidirectional) nb /= 2;
+    bk.bidirectional = bidirectional;
+    bk.nb = nb;
+    bk.max_exact = nb / 2;
+    bk.nthr = 0;
+    if (nb - bk.max_exact - 1 > 32) return EILEV_E_UNSUPPORTED;
+    // thresholds: smallest distance whose bucket reaches max_exact + i, i = 1 .. nb - max_exact - 1 (float32 formula of hf :247-256)
+    int prev = bk.max_exact;
+    for (int rp = bk.max_exact; rp <= 2 * max_dist && prev < nb - 1; ++rp) {
+        const float v = logf((float)rp / (float)bk.max_exact) / (float)log((double)max_dist / (double)bk.max_exact) * (float)(nb - bk.max_exact);
+        int big = bk.max_exact + (int)v;
+        if (big > nb - 1) big = nb - 1;
+        while (prev < big) {
+            bk.thr[bk.nthr++] = rp;
+            ++prev;
+        }
+    }
+    hipLaunchKernelGGL(t5_rel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rel_w, tab, n, off, heads, bk);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F, hipStream_t s) {
+    if (F & 7) return EILEV_E_UNSUPPORTED;
+    const int64_t total = rows * (F >> 3);
+    hipLaunchKernelGGL(gated_gelu_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, s, ab, ld, out, rows, F);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_rows_to_cache(const bf16 *src, int64_t ld, int col0, bf16 *plane, int batch, int rows_per_b, int heads, int hd, int cap,
+                         int slot0, hipStream_t s) {
+    hipLaunchKernelGGL(rows_to_cache_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, src, ld, col0, plane, rows_per_b, heads, hd, cap, slot0);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
 int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s) {
     const int64_t total = rows * (kp >> 3);
     const dim3 grid((unsigned)ceil_div64(total, 256)), block(256);

@@ -72,3 +72,58 @@ int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, b
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+
+// ---- T5LayerNorm (hf models/t5/modeling_t5.py:50-72): y = w * bf16(x * rsqrt(mean(x^2) + eps)), no mean subtraction, no bias.
+// One wave per row, the row stays in registers (cols <= 8 * 512).
+namespace {
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16 *__restrict__ x, int64_t ldx, const bf16 *__restrict__ g,
+                                                      bf16 *__restrict__ y, int64_t ldy, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int chunks = cols >> 3;
+    const bf16 *xr = x + row * ldx;
+    float v[MAXC][8];
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < chunks) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8 *>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (float)t[e];
+                ss += v[i][e] * v[i][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rs = rsqrtf(ss / (float)cols + eps);
+    bf16 *yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+        if (c < chunks) {
+            const bf16x8 gw = *reinterpret_cast<const bf16x8 *>(g + c * 8);
+            bf16x8 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (bf16)((float)gw[e] * (float)(bf16)(v[i][e] * rs));
+            *reinterpret_cast<bf16x8 *>(yr + c * 8) = out;
+        }
+    }
+}
+}  // namespace
+
+int launch_rmsnorm(const bf16 *x, int64_t ldx, const bf16 *g, bf16 *y, int64_t ldy, int64_t rows, int cols, float eps, hipStream_t s) {
+    if (rows <= 0) return EILEV_OK;
+    if (!x || !g || !y) return EILEV_E_BADARG;
+    if ((cols & 7) || (ldx & 7) || (ldy & 7) || cols > 8 * 512) return EILEV_E_UNSUPPORTED;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (cols <= 3 * 512) hipLaunchKernelGGL(rmsnorm_kernel<3>, grid, block, 0, s, x, ldx, g, y, ldy, rows, cols, eps);
+    else if (cols <= 5 * 512) hipLaunchKernelGGL(rmsnorm_kernel<5>, grid, block, 0, s, x, ldx, g, y, ldy, rows, cols, eps);
+    else hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, s, x, ldx, g, y, ldy, rows, cols, eps);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

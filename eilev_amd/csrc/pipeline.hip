@@ -23,6 +23,12 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
 
+int launch_t5_rel_table(const bf16 *rel_w, float *tab, int n, int off, int heads, int bidirectional, int num_buckets, int max_dist,
+                        hipStream_t s);
+int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F, hipStream_t s);
+int launch_rows_to_cache(const bf16 *src, int64_t ld, int col0, bf16 *plane, int batch, int rows_per_b, int heads, int hd, int cap,
+                         int slot0, hipStream_t s);
+
 #define RC(expr)                 \
     do {                         \
         int _rc = (expr);        \
@@ -541,4 +547,188 @@ extern "C" int eilev_attention(const void *q, const void *k, const void *v, void
     a.batch = (int)batch; a.heads = (int)heads; a.sq = (int)sq; a.skv = (int)skv; a.hd = (int)head_dim; a.scale = scale;
     a.causal = causal; a.key_mask = key_mask; a.mask_ld = skv;
     return launch_attention(a, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+// Encoder-decoder language model: flan-t5 (hf models/t5/modeling_t5.py; include/eilev.h "encoder-decoder")
+// =====================================================================================================
+namespace {
+bool dims_ok_t5(const EilevT5Dims *d) {
+    return d->d_model % 8 == 0 && d->d_kv % 8 == 0 && d->d_kv <= 128 && d->heads > 0 && d->d_ff % 8 == 0 && d->d_model <= 4096 &&
+           d->rel_buckets >= 4 && d->rel_max_dist > d->rel_buckets / 4;
+}
+struct T5Bufs {
+    bf16 *h, *x, *qkv, *att, *ff, *gate;
+    float *rel, *scratch;
+    int64_t rel_n;
+};
+bool carve_t5(const EilevT5Dims *d, int64_t M, int64_t rel_n, void *ws, size_t bytes, T5Bufs &b) {
+    const size_t I = (size_t)d->heads * d->d_kv;
+    Carver cv{(char *)ws, (char *)ws + bytes};
+    b.h = cv.take<bf16>((size_t)M * d->d_model);
+    b.x = cv.take<bf16>((size_t)M * d->d_model);
+    b.qkv = cv.take<bf16>((size_t)M * 3 * I);
+    b.att = cv.take<bf16>((size_t)M * I);
+    b.ff = cv.take<bf16>((size_t)M * 2 * d->d_ff);
+    b.gate = cv.take<bf16>((size_t)M * d->d_ff);
+    b.rel = cv.take<float>((size_t)d->heads * rel_n);
+    b.scratch = cv.take<float>(kSkinnyScratch / sizeof(float));
+    b.rel_n = rel_n;
+    return cv.ok();
+}
+GemmArgs t5_gemm(const T5Bufs &b, const bf16 *A, int64_t lda, const void *W, int64_t ldw, const bf16 *resid, int64_t ldr, void *Cp,
+                 int64_t ldc, int64_t M, int N, int K) {
+    GemmArgs g = mk_gemm(A, lda, W, ldw, nullptr, resid, ldr, Cp, ldc, M, N, K, 0);
+    g.scratch = b.scratch;
+    g.scratch_bytes = kSkinnyScratch;
+    return g;
+}
+// up to three projections of x with a shared input: one GEMM when the weights sit back to back in memory (the engine packs them)
+int t5_proj(const T5Bufs &b, const bf16 *x, int D, const void *w0, const void *w1, const void *w2, int n_each, bf16 *out, int64_t ldo,
+            int64_t M, hipStream_t s) {
+    const bf16 *p0 = (const bf16 *)w0, *p1 = (const bf16 *)w1, *p2 = (const bf16 *)w2;
+    const int cnt = 1 + (p1 != nullptr) + (p2 != nullptr);
+    const bool fused = (cnt < 2 || p1 == p0 + (size_t)n_each * D) && (cnt < 3 || p2 == p0 + 2 * (size_t)n_each * D);
+    if (fused) return launch_gemm(t5_gemm(b, x, D, w0, D, nullptr, 0, out, ldo, M, cnt * n_each, D), 5, s);
+    const bf16 *ws[3] = {p0, p1, p2};
+    for (int i = 0; i < cnt; ++i) RC(launch_gemm(t5_gemm(b, x, D, ws[i], D, nullptr, 0, out + (size_t)i * n_each, ldo, M, n_each, D), 5, s));
+    return EILEV_OK;
+}
+// h += wo(gelu_new(wi_0 x) * wi_1 x) with x = rmsnorm(h)   [T5LayerFF :126-141, T5DenseGatedActDense :97-124]
+int t5_ff(const EilevT5Dims *d, const EilevT5Layer *L, const T5Bufs &b, int64_t M, hipStream_t s) {
+    const int D = d->d_model, F = d->d_ff;
+    RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ff, b.x, D, M, D, d->eps, s));
+    RC(t5_proj(b, b.x, D, L->wi0_w, L->wi1_w, nullptr, F, b.ff, 2 * F, M, s));
+    RC(launch_gated_gelu(b.ff, 2 * F, b.gate, M, F, s));
+    return launch_gemm(t5_gemm(b, b.gate, F, L->wo_w, F, b.h, D, b.h, D, M, D, F), 5, s);
+}
+}  // namespace
+
+extern "C" size_t eilev_t5_workspace_bytes(const EilevT5Dims *d, int64_t batch, int64_t rows, int64_t kv_len) {
+    const size_t M = (size_t)batch * rows, I = (size_t)d->heads * d->d_kv;
+    const size_t rel_n = (size_t)(rows + kv_len + 1);
+    return (M * (2 * (size_t)d->d_model + 4 * I + 3 * (size_t)d->d_ff)) * sizeof(bf16) + d->heads * rel_n * sizeof(float) + kSkinnyScratch +
+           16 * 256;
+}
+
+extern "C" int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                               int64_t batch, int64_t enc_len, void *enc_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !inputs_embeds || !attn_mask || !enc_out || !workspace || batch <= 0 || enc_len <= 0) return EILEV_E_BADARG;
+    if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->d_model, H = d->heads, hd = d->d_kv, I = H * hd;
+    const int64_t M = batch * enc_len;
+    T5Bufs b;
+    if (!carve_t5(d, M, 2 * enc_len + 1, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    EILEV_HIP_CHECK(hipMemcpyAsync(b.h, inputs_embeds, (size_t)M * D * sizeof(bf16), hipMemcpyDeviceToDevice, s));
+    // bias(i, j) depends on j - i in [-(L-1), L-1]: table index (j - i) + L - 1
+    RC(launch_t5_rel_table((const bf16 *)w->enc_rel_bias, b.rel, (int)(2 * enc_len - 1), (int)enc_len - 1, H, 1, d->rel_buckets,
+                           d->rel_max_dist, s));
+    for (int l = 0; l < d->enc_layers; ++l) {
+        const EilevT5Layer *L = &w->enc_layers[l];
+        RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
+        RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
+        AttnArgs a;
+        a.q = b.qkv; a.k = b.qkv + I; a.v = b.qkv + 2 * I; a.o = b.att;
+        a.q_bs = a.k_bs = a.v_bs = enc_len * 3 * (int64_t)I; a.o_bs = enc_len * (int64_t)I;
+        a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+        a.ldq = a.ldk = a.ldv = 3 * I; a.ldo = I;
+        a.batch = (int)batch; a.heads = H; a.sq = a.skv = (int)enc_len; a.hd = hd; a.scale = 1.0f; a.causal = 0;
+        a.key_mask = attn_mask; a.mask_ld = enc_len; a.dbg = 0;
+        a.rel_tab = b.rel; a.rel_hs = 2 * enc_len - 1; a.rel_off = (int)enc_len - 1; a.rel_n = (int)(2 * enc_len - 1);
+        RC(launch_attention(a, s));
+        RC(launch_gemm(t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I), 5, s));
+        RC(t5_ff(d, L, b, M, s));
+    }
+    return launch_rmsnorm(b.h, D, (const bf16 *)w->enc_final_ln, (bf16 *)enc_out, D, M, D, d->eps, s);
+}
+
+extern "C" size_t eilev_t5_cross_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t enc_len) {
+    return sizeof(bf16) * (size_t)2 * d->dec_layers * batch * d->heads * enc_len * d->d_kv;
+}
+extern "C" size_t eilev_t5_self_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t kv_capacity) {
+    return sizeof(bf16) * (size_t)2 * d->dec_layers * batch * d->heads * kv_capacity * d->d_kv;
+}
+
+// The projections are written straight into the cache planes: plane = [batch][head][enc_len][d_kv] is the row-major
+// [M, H*d_kv] GEMM output re-tiled per head, done by one GEMM per (layer, k|v, head) column block with ldc = d_kv.
+extern "C" int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, const void *enc_out, int64_t batch, int64_t enc_len,
+                                 void *cross_kv, void *stream) {
+    if (!d || !w || !enc_out || !cross_kv || batch <= 0 || enc_len <= 0) return EILEV_E_BADARG;
+    if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->d_model, H = d->heads, hd = d->d_kv;
+    const size_t plane = (size_t)batch * H * enc_len * hd;
+    for (int l = 0; l < d->dec_layers; ++l) {
+        const EilevT5Layer *L = &w->dec_layers[l];
+        for (int which = 0; which < 2; ++which) {
+            bf16 *dst = (bf16 *)cross_kv + (2 * (size_t)l + which) * plane;
+            const bf16 *W = (const bf16 *)(which ? L->cv_w : L->ck_w);
+            for (int64_t bb = 0; bb < batch; ++bb)
+                for (int hh = 0; hh < H; ++hh) {
+                    GemmArgs g = mk_gemm((const bf16 *)enc_out + bb * enc_len * D, D, W + (size_t)hh * hd * D, D, nullptr, nullptr, 0,
+                                         dst + ((size_t)bb * H + hh) * enc_len * hd, hd, enc_len, hd, D, 0);
+                    RC(launch_gemm(g, 5, s));
+                }
+        }
+    }
+    return EILEV_OK;
+}
+
+extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                               int64_t batch, int64_t new_len, int64_t past_len, void *self_kv, int64_t kv_capacity,
+                               const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    if (!d || !w || !dec_ids || !enc_mask || !self_kv || !cross_kv || !logits || !workspace) return EILEV_E_BADARG;
+    if (batch <= 0 || new_len <= 0 || past_len < 0 || past_len + new_len > kv_capacity || enc_len <= 0) return EILEV_E_BADARG;
+    if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->d_model, H = d->heads, hd = d->d_kv, I = H * hd;
+    const int64_t M = batch * new_len, total = past_len + new_len;
+    T5Bufs b;
+    if (!carve_t5(d, M, total + 1, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    RC(launch_embed_scatter((const bf16 *)w->shared, dec_ids, nullptr, nullptr, 0, M, d->vocab, b.h, D, s));
+    // causal self-attention: key j of query at absolute position p: rel = j - p in [-(total-1), 0]: index rel + total - 1
+    RC(launch_t5_rel_table((const bf16 *)w->dec_rel_bias, b.rel, (int)total, (int)total - 1, H, 0, d->rel_buckets, d->rel_max_dist, s));
+    const size_t splane = (size_t)batch * H * kv_capacity * hd, cplane = (size_t)batch * H * enc_len * hd;
+    for (int l = 0; l < d->dec_layers; ++l) {
+        const EilevT5Layer *L = &w->dec_layers[l];
+        bf16 *kc = (bf16 *)self_kv + 2 * (size_t)l * splane, *vc = kc + splane;
+        const bf16 *ck = (const bf16 *)cross_kv + 2 * (size_t)l * cplane, *cv = ck + cplane;
+        // ---- self-attention against the cache (T5LayerSelfAttention :372-401)
+        RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
+        RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
+        RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
+        RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
+        AttnArgs a;
+        a.q = b.qkv; a.k = kc; a.v = vc; a.o = b.att;
+        a.q_bs = new_len * 3 * (int64_t)I; a.o_bs = new_len * (int64_t)I;
+        a.k_bs = a.v_bs = (int64_t)H * kv_capacity * hd;
+        a.q_hs = a.o_hs = hd; a.k_hs = a.v_hs = kv_capacity * (int64_t)hd;
+        a.ldq = 3 * I; a.ldk = a.ldv = hd; a.ldo = I;
+        a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
+        a.key_mask = nullptr; a.mask_ld = 0; a.dbg = 0;
+        a.rel_tab = b.rel; a.rel_hs = total; a.rel_off = (int)total - 1; a.rel_n = (int)total;
+        RC(launch_attention(a, s));
+        RC(launch_gemm(t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I), 5, s));
+        // ---- cross-attention over the encoder output (T5LayerCrossAttention :404-432): no position bias, padding mask
+        RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ca, b.x, D, M, D, d->eps, s));
+        RC(launch_gemm(t5_gemm(b, b.x, D, L->cq_w, D, nullptr, 0, b.qkv, I, M, I, D), 5, s));
+        AttnArgs c;
+        c.q = b.qkv; c.k = ck; c.v = cv; c.o = b.att;
+        c.q_bs = new_len * (int64_t)I; c.o_bs = new_len * (int64_t)I;
+        c.k_bs = c.v_bs = (int64_t)H * enc_len * hd;
+        c.q_hs = c.o_hs = hd; c.k_hs = c.v_hs = enc_len * (int64_t)hd;
+        c.ldq = I; c.ldk = c.ldv = hd; c.ldo = I;
+        c.batch = (int)batch; c.heads = H; c.sq = (int)new_len; c.skv = (int)enc_len; c.hd = hd; c.scale = 1.0f; c.causal = 0;
+        c.key_mask = enc_mask; c.mask_ld = enc_len; c.dbg = 0;
+        RC(launch_attention(c, s));
+        RC(launch_gemm(t5_gemm(b, b.att, I, L->co_w, I, b.h, D, b.h, D, M, D, I), 5, s));
+        RC(t5_ff(d, L, b, M, s));
+    }
+    RC(launch_rmsnorm(b.h, D, (const bf16 *)w->dec_final_ln, b.x, D, M, D, d->eps, s));
+    GemmArgs g = t5_gemm(b, b.x, D, w->lm_head, D, nullptr, 0, logits, d->vocab, M, d->vocab, D);
+    g.out_f32 = 1;
+    if (d->scale_decoder_outputs) { g.scale = 1.0f / sqrtf((float)D); g.scale_cols = d->vocab; }
+    return launch_gemm(g, 5, s);
 }

@@ -20,12 +20,16 @@ def _ptr(t):
 class HipEngine:
     """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
 
-    def __init__(self, config, named_tensors: dict, device=None, parts=("vit", "qf", "opt")):
+    def __init__(self, config, named_tensors: dict, device=None, parts=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = abi.load_hip()
         self.config = config
         self.dims = abi.dims_from_config(config)
+        self.is_t5 = getattr(config.text_config, "model_type", "opt") == "t5"
+        self.t5dims = abi.t5_dims_from_config(config) if self.is_t5 else None
+        if parts is None:
+            parts = ("vit", "qf", "t5" if self.is_t5 else "opt")
         self.device = torch.device(device) if device is not None else next(iter(named_tensors.values())).device
         if self.device.type != "cuda":
             raise RuntimeError(f"HipEngine weights must live on the GPU, got {self.device}")
@@ -55,7 +59,15 @@ class HipEngine:
                 return "vit"
             if key.startswith(("qformer.", "language_projection.")) or key == "query_tokens":
                 return "qf"
-            return "opt"
+            return "t5" if self.is_t5 else "opt"
+
+        if self.is_t5 and "t5" in self.parts:
+            t5 = self.t5dims
+            for stack, n in (("encoder", t5.enc_layers), ("decoder", t5.dec_layers)):
+                for i in range(n):
+                    k = abi.t5_layer_keys(stack, i)
+                    pack([k["q_w"], k["k_w"], k["v_w"]])       # one q|k|v GEMM
+                    pack([k["wi0_w"], k["wi1_w"]])             # one gate|up GEMM
 
         for i in range(d.t_layers if "opt" in self.parts else 0):
             p = abi.OPT_PREFIX.format(i) + "self_attn."
@@ -76,7 +88,13 @@ class HipEngine:
                 store[key] = bf(named[key])
             return store[key].data_ptr()
 
-        self.pack = abi.WeightPack(d, addr)
+        def addr_t5(key):
+            if key == "language_model.lm_head.weight" and key not in named:
+                raise KeyError(key)  # tied to `shared`
+            return addr(key)
+
+        t5d = self.t5dims if (self.is_t5 and "t5" in self.parts) else None
+        self.pack = abi.WeightPack(d, addr_t5 if t5d is not None else addr, t5d)
         self._keep = store
 
     # ---- workspaces ----------------------------------------------------------------------------------
@@ -155,7 +173,7 @@ class HipEngine:
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= d.vocab):
             raise IndexError("input_ids out of range")
         out = torch.empty((B, L, d.t_hidden), dtype=torch.bfloat16, device=self.device)
-        abi.check(self.lib.eilev_embed_scatter(C.byref(d), self.pack.opt.embed_tokens, _ptr(ids), _ptr(vm),
+        abi.check(self.lib.eilev_embed_scatter(C.byref(d), self.pack.embed_tokens, _ptr(ids), _ptr(vm),
                                                _ptr(video_feats) if vm is not None else None, n_rows, B, L, _ptr(out),
                                                self._stream()), "eilev_embed_scatter")
         return out
@@ -341,6 +359,77 @@ class HipEngine:
 
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
                            num_return_sequences)
+
+
+    # ---- encoder-decoder LM (flan-t5) ------------------------------------------------------------------------
+    def t5_encode(self, inputs_embeds, attention_mask):
+        """Encoder stack [hf T5Stack]: (B, L, D) bf16 -> encoder last_hidden_state (B, L, D)."""
+        d = self.t5dims
+        x = inputs_embeds.contiguous()
+        B, L, _ = x.shape
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        out = torch.empty_like(x)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, L, L)
+        ws = self._workspace("t5", nb)
+        abi.check(self.lib.eilev_t5_encode(C.byref(d), C.byref(self.pack.t5), _ptr(x), _ptr(am), B, L, _ptr(out), _ptr(ws), ws.numel(),
+                                           self._stream()), "eilev_t5_encode")
+        return out
+
+    def t5_cross_kv(self, enc_out):
+        d = self.t5dims
+        B, L, _ = enc_out.shape
+        kv = torch.empty(int(self.lib.eilev_t5_cross_kv_bytes(C.byref(d), B, L)), dtype=torch.uint8, device=self.device)
+        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _ptr(enc_out.contiguous()), B, L, _ptr(kv), self._stream()),
+                  "eilev_t5_cross_kv")
+        return kv
+
+    def t5_decode(self, dec_ids, enc_mask, past_len, self_kv, cap, cross_kv, enc_len):
+        """Decoder over dec_ids (B, T) at positions past_len..: fp32 logits (B, T, vocab)."""
+        d = self.t5dims
+        ids = dec_ids.to(self.device, torch.int64).contiguous()
+        B, T = ids.shape
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= d.vocab):
+            raise IndexError("decoder_input_ids out of range")
+        am = enc_mask.to(self.device, torch.int32).contiguous()
+        logits = torch.empty((B, T, d.vocab), dtype=torch.float32, device=self.device)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, T, max(enc_len, past_len + T))
+        ws = self._workspace("t5", nb)
+        abi.check(self.lib.eilev_t5_decode(C.byref(d), C.byref(self.pack.t5), _ptr(ids), _ptr(am), B, T, past_len, _ptr(self_kv), cap,
+                                           _ptr(cross_kv), enc_len, _ptr(logits), _ptr(ws), ws.numel(), self._stream()), "eilev_t5_decode")
+        return logits
+
+    def t5_forward(self, inputs_embeds, attention_mask, decoder_input_ids):
+        """Teacher-forced logits (B, T, vocab) fp32 + encoder output [ref:eilev/model/v2.py:228-238]."""
+        d = self.t5dims
+        enc = self.t5_encode(inputs_embeds, attention_mask)
+        ckv = self.t5_cross_kv(enc)
+        B, T = decoder_input_ids.shape
+        skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T)), dtype=torch.uint8, device=self.device)
+        return self.t5_decode(decoder_input_ids, attention_mask, 0, skv, T, ckv, enc.shape[1]), enc
+
+    def t5_greedy(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0):
+        """Greedy generation for the encoder-decoder LM [ref:eilev/model/v2.py:318-322 -> hf _sample]: returns decoder ids
+        (B, 1 + n) INCLUDING the start token, like HF does for encoder-decoder models."""
+        d = self.t5dims
+        enc = self.t5_encode(inputs_embeds, attention_mask)
+        ckv = self.t5_cross_kv(enc)
+        B, L, _ = enc.shape
+        cap = max_new_tokens + 1
+        skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, cap)), dtype=torch.uint8, device=self.device)
+        state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        finished = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        tokens = torch.full((B,), int(start_id), dtype=torch.int64, device=self.device)
+        out = torch.full((B, max_new_tokens), int(pad_id), dtype=torch.int64, device=self.device)
+        n = 0
+        for t in range(max_new_tokens):
+            logits = self.t5_decode(tokens.view(B, 1), attention_mask, t, skv, cap, ckv, L)
+            abi.check(self.lib.eilev_greedy_select(_ptr(logits), B, d.vocab, _ptr(state), _ptr(finished), eos_id, pad_id, _ptr(tokens),
+                                                   _ptr(out), max_new_tokens, self._stream()), "eilev_greedy_select")
+            n = t + 1
+            if eos_id >= 0 and int(state[1].item()) == 0:
+                break
+        start = torch.full((B, 1), int(start_id), dtype=torch.int64, device=self.device)
+        return torch.cat((start, out[:, :n]), dim=1)
 
 
 def abi_dtype(t: torch.Tensor) -> int:

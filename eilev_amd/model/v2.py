@@ -89,6 +89,57 @@ class _OptParams(nn.Module):
         raise RuntimeError("language_model is a parameter container; call the parent VideoBlipForConditionalGeneration")
 
 
+class _RmsW(nn.Module):
+    """T5LayerNorm's parameter (hf models/t5/modeling_t5.py:50-57): a weight, no bias."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+
+
+class _T5Params(nn.Module):
+    """T5ForConditionalGeneration's parameter tree (hf modeling_t5.py:898-937) without its arithmetic; `lm_head` and both
+    `embed_tokens` are tied to `shared` like the installed transformers does."""
+
+    def __init__(self, c):
+        super().__init__()
+        if c.feed_forward_proj != "gated-gelu":
+            raise NotImplementedError("only the gated-gelu (T5 v1.1 / flan-t5) feed-forward is built on the HIP path")
+        d, inner, f = c.d_model, c.num_heads * c.d_kv, c.d_ff
+        lin = lambda i, o: nn.Linear(i, o, bias=False)
+
+        def attn(rel):
+            parts = dict(q=lin(d, inner), k=lin(d, inner), v=lin(d, inner), o=lin(inner, d))
+            if rel:
+                parts["relative_attention_bias"] = nn.Embedding(c.relative_attention_num_buckets, c.num_heads)
+            return _bag(**parts)
+
+        def stack(n, decoder):
+            blocks = []
+            for i in range(n):
+                layers = [_bag(SelfAttention=attn(i == 0), layer_norm=_RmsW(d))]
+                if decoder:
+                    layers.append(_bag(EncDecAttention=attn(False), layer_norm=_RmsW(d)))
+                layers.append(_bag(DenseReluDense=_bag(wi_0=lin(d, f), wi_1=lin(d, f), wo=lin(f, d)), layer_norm=_RmsW(d)))
+                blocks.append(_bag(layer=nn.ModuleList(layers)))
+            return _bag(embed_tokens=nn.Embedding(c.vocab_size, d), block=nn.ModuleList(blocks), final_layer_norm=_RmsW(d))
+
+        self.shared = nn.Embedding(c.vocab_size, d)
+        self.encoder = stack(c.num_layers, False)
+        self.decoder = stack(c.num_decoder_layers, True)
+        self.lm_head = lin(d, c.vocab_size)
+        self.encoder.embed_tokens.weight = self.shared.weight
+        self.decoder.embed_tokens.weight = self.shared.weight
+        self.lm_head.weight = self.shared.weight
+        self.config = c
+
+    def get_input_embeddings(self):
+        return self.shared
+
+    def forward(self, *a, **k):
+        raise RuntimeError("language_model is a parameter container; call the parent VideoBlipForConditionalGeneration")
+
+
 def _require_gpu(t: torch.Tensor, what: str):
     if t.device.type != "cuda":
         raise RuntimeError(f"{what}: the MI355X-native path has no CPU fallback — move the model to an AMD GPU (.to('cuda'))")
@@ -146,13 +197,18 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
 
     def __init__(self, config: Blip2Config) -> None:
         super().__init__(config)
-        if not config.use_decoder_only_language_model or config.text_config.model_type != "opt":
-            raise NotImplementedError("only the OPT (decoder-only) language model is built on the HIP path so far")
+        mt = config.text_config.model_type
+        if (config.use_decoder_only_language_model and mt != "opt") or (not config.use_decoder_only_language_model and mt != "t5"):
+            raise NotImplementedError(f"language model {mt!r}: OPT (decoder-only) and T5 (encoder-decoder) are built on the HIP path")
+        self._is_t5 = mt == "t5"
+        if self._is_t5:
+            self._tied_weights_keys = {f"language_model.{k}": "language_model.shared.weight"
+                                       for k in ("lm_head.weight", "encoder.embed_tokens.weight", "decoder.embed_tokens.weight")}
         self.vision_model = VideoBlipVisionModel(config.vision_config)
         self.query_tokens = nn.Parameter(torch.zeros(1, config.num_query_tokens, config.qformer_config.hidden_size))
         self.qformer = _qformer_params(config.qformer_config)
         self.language_projection = nn.Linear(config.qformer_config.hidden_size, config.text_config.hidden_size)
-        self.language_model = _OptParams(config.text_config)
+        self.language_model = _T5Params(config.text_config) if self._is_t5 else _OptParams(config.text_config)
         self._hip = None
         import weakref
 
@@ -175,13 +231,20 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         return self.language_model.get_input_embeddings()
 
     def set_input_embeddings(self, value):
-        self.language_model.model.decoder.embed_tokens = value
+        if self._is_t5:
+            self.language_model.shared = value
+        else:
+            self.language_model.model.decoder.embed_tokens = value
 
     def get_output_embeddings(self):
         return self.language_model.lm_head
 
     def tie_weights(self, *a, **k):
-        self.language_model.lm_head.weight = self.language_model.model.decoder.embed_tokens.weight
+        lm = self.language_model
+        if self._is_t5:
+            lm.encoder.embed_tokens.weight = lm.decoder.embed_tokens.weight = lm.lm_head.weight = lm.shared.weight
+        else:
+            lm.lm_head.weight = lm.model.decoder.embed_tokens.weight
 
     # ---- engine ------------------------------------------------------------------------------------------
     def engine(self):
@@ -224,6 +287,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         emb, vision, qf = self._encode(pixel_values, input_ids, video_input_mask)
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
+        if self._is_t5:
+            return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict)
         _, logits32, _ = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False)
         loss = None
         if labels is not None:
@@ -237,6 +302,38 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype))
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
         lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
+        if not return_dict:
+            out = (logits, vis_out, qf_out, lm_out)
+            return ((loss,) + out) if loss is not None else out
+        return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=logits, vision_outputs=vis_out, qformer_outputs=qf_out,
+                                                        language_model_outputs=lm_out)
+
+    def _forward_t5(self, emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict):
+        """Encoder-decoder branch [ref:eilev/model/v2.py:228-238 -> hf T5ForConditionalGeneration.forward :939-1055]."""
+        from transformers.modeling_outputs import Seq2SeqLMOutput
+
+        if decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all()):
+            raise NotImplementedError("decoder_attention_mask with padding inside the target is not built on the HIP path")
+        t = self.config.text_config
+        if decoder_input_ids is None:
+            if labels is None:
+                raise ValueError("You have to specify either decoder_input_ids or labels")
+            # T5._shift_right: start token, labels shifted, -100 -> pad
+            start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
+            decoder_input_ids = torch.cat((torch.full_like(labels[:, :1], start), labels[:, :-1]), dim=1)
+            decoder_input_ids = decoder_input_ids.masked_fill(decoder_input_ids == -100, t.pad_token_id)
+        dtype = self.dtype
+        logits32, enc = self.engine().t5_forward(emb, attention_mask, decoder_input_ids)
+        loss = None
+        if labels is not None:
+            loss = nn.functional.cross_entropy(logits32.reshape(-1, logits32.size(-1)), labels.to(logits32.device).reshape(-1),
+                                               ignore_index=-100).to(dtype)
+        logits = logits32.to(dtype)
+        vis_out = qf_out = None
+        if vision is not None:
+            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype))
+            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
+        lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype))
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
             return ((loss,) + out) if loss is not None else out
@@ -263,7 +360,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if max_new is None:
             max_len = kw.pop("max_length", None)
             if max_len is None:
-                max_new = 20  # HF GenerationConfig default max_length
+                max_len = 20  # HF GenerationConfig default max_length
+                max_new = 19 if self._is_t5 else 20
+            elif self._is_t5:
+                max_new = int(max_len) - 1  # encoder-decoder: max_length counts the decoder tokens incl. the start token
             else:
                 max_new = int(max_len) - input_ids.shape[1]
         min_new = kw.pop("min_new_tokens", 0) or 0
@@ -289,6 +389,13 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         emb, _, _ = self._encode(pixel_values, input_ids, video_input_mask)
+        if self._is_t5:
+            if num_beams > 1:
+                raise NotImplementedError("beam search for the encoder-decoder LM is not built on the HIP path (greedy is)")
+            t = self.config.text_config
+            start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
+            return self.engine().t5_greedy(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
+                                           start_id=int(start))
         if num_beams > 1:
             return self.engine().beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
                                              eos_id=int(-1 if eos is None else eos), pad_id=int(pad), early_stopping=early_stopping,

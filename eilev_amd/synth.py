@@ -86,6 +86,10 @@ def synth_param(name: str, shape, mode: str = "fanin", seed: int = 0) -> np.ndar
     elif len(shape) >= 2 and name.endswith("weight") and "embed" not in low:
         fan_in = int(np.prod(shape[1:]))
         std = (1.0 / np.sqrt(fan_in)) if mode == "fanin" else 0.02
+        if mode == "fanin" and low.endswith("attention.q.weight"):
+            # T5 attention has no 1/sqrt(d_kv) factor (trained checkpoints carry it in q): without it the synthetic softmax
+            # saturates and the model amplifies bf16 noise chaotically
+            std *= 0.125
         out = std * n
     else:
         # embeddings, query_tokens, class/position embeddings
