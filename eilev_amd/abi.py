@@ -288,7 +288,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_t5_cross_kv_bytes.restype = sz
     lib.eilev_t5_cross_kv_bytes.argtypes = [TP, i64, i64]
     lib.eilev_t5_cross_kv.restype = i32
-    lib.eilev_t5_cross_kv.argtypes = [TP, C.POINTER(T5Weights), vp, i64, i64, vp, vp]
+    lib.eilev_t5_cross_kv.argtypes = [TP, C.POINTER(T5Weights), vp, i64, i64, vp, vp, sz, vp]
     lib.eilev_t5_self_kv_bytes.restype = sz
     lib.eilev_t5_self_kv_bytes.argtypes = [TP, i64, i64]
     lib.eilev_t5_decode.restype = i32

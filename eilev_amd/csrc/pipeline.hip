@@ -650,27 +650,24 @@ extern "C" size_t eilev_t5_self_kv_bytes(const EilevT5Dims *d, int64_t batch, in
     return sizeof(bf16) * (size_t)2 * d->dec_layers * batch * d->heads * kv_capacity * d->d_kv;
 }
 
-// The projections are written straight into the cache planes: plane = [batch][head][enc_len][d_kv] is the row-major
-// [M, H*d_kv] GEMM output re-tiled per head, done by one GEMM per (layer, k|v, head) column block with ldc = d_kv.
+// k|v of every decoder block from the encoder output: one GEMM per layer (two when the weights are not packed back to back)
+// into the workspace, then re-tiled per head into the cache planes.
 extern "C" int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, const void *enc_out, int64_t batch, int64_t enc_len,
-                                 void *cross_kv, void *stream) {
-    if (!d || !w || !enc_out || !cross_kv || batch <= 0 || enc_len <= 0) return EILEV_E_BADARG;
+                                 void *cross_kv, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !enc_out || !cross_kv || !workspace || batch <= 0 || enc_len <= 0) return EILEV_E_BADARG;
     if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int D = d->d_model, H = d->heads, hd = d->d_kv;
+    const int D = d->d_model, H = d->heads, hd = d->d_kv, I = H * hd;
+    const int64_t M = batch * enc_len;
+    T5Bufs b;
+    if (!carve_t5(d, M, 1, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
     const size_t plane = (size_t)batch * H * enc_len * hd;
     for (int l = 0; l < d->dec_layers; ++l) {
         const EilevT5Layer *L = &w->dec_layers[l];
-        for (int which = 0; which < 2; ++which) {
-            bf16 *dst = (bf16 *)cross_kv + (2 * (size_t)l + which) * plane;
-            const bf16 *W = (const bf16 *)(which ? L->cv_w : L->ck_w);
-            for (int64_t bb = 0; bb < batch; ++bb)
-                for (int hh = 0; hh < H; ++hh) {
-                    GemmArgs g = mk_gemm((const bf16 *)enc_out + bb * enc_len * D, D, W + (size_t)hh * hd * D, D, nullptr, nullptr, 0,
-                                         dst + ((size_t)bb * H + hh) * enc_len * hd, hd, enc_len, hd, D, 0);
-                    RC(launch_gemm(g, 5, s));
-                }
-        }
+        bf16 *kc = (bf16 *)cross_kv + 2 * (size_t)l * plane, *vc = kc + plane;
+        RC(t5_proj(b, (const bf16 *)enc_out, D, L->ck_w, L->cv_w, nullptr, I, b.qkv, 2 * I, M, s));
+        RC(launch_rows_to_cache(b.qkv, 2 * I, 0, kc, (int)batch, (int)enc_len, H, hd, (int)enc_len, 0, s));
+        RC(launch_rows_to_cache(b.qkv, 2 * I, I, vc, (int)batch, (int)enc_len, H, hd, (int)enc_len, 0, s));
     }
     return EILEV_OK;
 }

@@ -68,6 +68,8 @@ class HipEngine:
                     k = abi.t5_layer_keys(stack, i)
                     pack([k["q_w"], k["k_w"], k["v_w"]])       # one q|k|v GEMM
                     pack([k["wi0_w"], k["wi1_w"]])             # one gate|up GEMM
+                    if stack == "decoder":
+                        pack([k["ck_w"], k["cv_w"]])           # one cross k|v GEMM per layer
 
         for i in range(d.t_layers if "opt" in self.parts else 0):
             p = abi.OPT_PREFIX.format(i) + "self_attn."
@@ -379,8 +381,10 @@ class HipEngine:
         d = self.t5dims
         B, L, _ = enc_out.shape
         kv = torch.empty(int(self.lib.eilev_t5_cross_kv_bytes(C.byref(d), B, L)), dtype=torch.uint8, device=self.device)
-        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _ptr(enc_out.contiguous()), B, L, _ptr(kv), self._stream()),
-                  "eilev_t5_cross_kv")
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, L, L)
+        ws = self._workspace("t5", nb)
+        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _ptr(enc_out.contiguous()), B, L, _ptr(kv), _ptr(ws),
+                                             ws.numel(), self._stream()), "eilev_t5_cross_kv")
         return kv
 
     def t5_decode(self, dec_ids, enc_mask, past_len, self_kv, cap, cross_kv, enc_len):

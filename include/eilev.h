@@ -210,7 +210,7 @@ int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, const void *i
  * [dec_layer][k|v][batch][head][enc_len][d_kv] */
 size_t eilev_t5_cross_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t enc_len);
 int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, const void *enc_out, int64_t batch, int64_t enc_len,
-                      void *cross_kv, void *stream);
+                      void *cross_kv, void *workspace, size_t workspace_bytes, void *stream);
 /* decoder self-attention cache: [dec_layer][k|v][batch][head][capacity][d_kv] */
 size_t eilev_t5_self_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t kv_capacity);
 /* decoder over new_len positions past_len .. past_len + new_len - 1 of every sequence (teacher forcing: past_len = 0,

@@ -209,7 +209,7 @@ class OracleModel:
         d = self.t5dims
         B, L, _ = enc_out.shape
         kv = np.zeros(self.lib.eilev_t5_cross_kv_bytes(C.byref(d), B, L) // 4, np.float32)
-        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _p(np.ascontiguousarray(enc_out, np.float32)), B, L, _p(kv), None),
+        abi.check(self.lib.eilev_t5_cross_kv(C.byref(d), C.byref(self.pack.t5), _p(np.ascontiguousarray(enc_out, np.float32)), B, L, _p(kv), None, 0, None),
                   "oracle t5 cross kv")
         return kv
 

@@ -120,3 +120,39 @@ def test_t5_model_class_like_the_reference(golden_dir, dtype):
                      attention_mask=t(g["attention_mask"]), max_new_tokens=n, num_beams=1, do_sample=False, eos_token_id=int(g["fp32_eos_id"]))
     ref_ids = g["fp32_greedy_eos"]
     assert np.array_equal(ids.cpu().numpy()[:, : ref_ids.shape[1]], ref_ids)
+
+
+def test_t5_xl_widths_decode_equals_teacher_forcing():
+    """flan-t5-xl widths (d_model 2048, 32 heads x 64, d_ff 5120, vocab 32128; 2 + 2 layers), L = 300 with right padding:
+    size-independent properties — cached single-step decoding == teacher forcing, and padded encoder positions do not
+    influence the logits."""
+    import ctypes as C
+
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.engine import HipEngine
+    from eilev_amd.statedict import state_dict_shapes
+    from eilev_amd.synth import synth_param
+
+    cfg = blip2_config("t5xl")
+    cfg.text_config.num_layers = 2
+    cfg.text_config.num_decoder_layers = 2
+    named = {k: torch.from_numpy(synth_param(k, shp, "fanin")).to(torch.bfloat16).cuda()
+             for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
+    eng = HipEngine(cfg, named, device="cuda", parts=("t5",))
+    torch.manual_seed(3)
+    B, L, T, D = 3, 300, 5, 2048
+    emb = (0.5 * torch.randn(B, L, D, device="cuda")).to(torch.bfloat16)
+    am = torch.ones(B, L, dtype=torch.int32, device="cuda")
+    am[1, 250:] = 0
+    dec = torch.randint(2, 32128, (B, T), device="cuda")
+    dec[:, 0] = 0
+    full, enc = eng.t5_forward(emb, am, dec)
+    emb2 = emb.clone()
+    emb2[1, 250:] = 7.0  # garbage in the padded encoder positions
+    full2, _ = eng.t5_forward(emb2, am, dec)
+    assert torch.equal(full2[1], full[1])
+    ckv = eng.t5_cross_kv(enc)
+    skv = torch.zeros(int(eng.lib.eilev_t5_self_kv_bytes(C.byref(eng.t5dims), B, T)), dtype=torch.uint8, device="cuda")
+    for i in range(T):
+        step = eng.t5_decode(dec[:, i:i + 1], am, i, skv, T, ckv, L)
+        assert rel_rms(host(step[:, 0]), host(full[:, i])) <= 1e-2, i
