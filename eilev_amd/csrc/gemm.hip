@@ -452,376 +452,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
 }
 
-// ---- BK = 32 variant: two 24 KiB stages so that TWO 256x128 workgroups fit one CU -----------------------
-// (the second workgroup's MFMAs fill the first one's barrier stalls and its store-bound epilogue).  LDS rows
-// are 64 bytes (32 bf16 = 4 chunks); chunk c of row r is stored at c ^ ((r >> 2) & 3), which keeps the 16
-// lanes of every ds_read_b128 service group on 16 distinct 16-byte slots for the 32-row fragment pattern.
+// XOR swizzle of a 64-byte (32-element) K slice: 4 chunks per row
 __device__ __forceinline__ int swz32(int row, int c) { return (c ^ ((row >> 2) & 3)) << 4; }
-
-template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
-__global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds32_kernel(const GemmArgs g) {
-    constexpr int NW = NWM * NWN, KB = 32;
-    constexpr int WM = BM / NWM, WN = BN / NWN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_PC = BM / 16 / NW, B_PC = BN / 16 / NW;  // 1-KiB pieces (16 rows x 64 B) per wave per K-step
-    constexpr int STAGE = (BM + BN) * 64;
-    static_assert(A_PC >= 1 && B_PC >= 1 && WN == 64, "unsupported geometry");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    int tm_i, tn_i;
-    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / NWN, wn = wid % NWN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nk = g.K / KB;
-
-    unsigned pa[A_PC], pb[B_PC];
-    const int prow = lane >> 2, pslot = lane & 3;
-#pragma unroll
-    for (int i = 0; i < A_PC; ++i) {
-        const int row = (wid * A_PC + i) * 16 + prow;
-        int gr = m0 + row;
-        gr = gr < g.M ? gr : g.M - 1;
-        pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PC; ++i) {
-        const int row = (wid * B_PC + i) * 16 + prow;
-        int gr = n0 + row;
-        gr = gr < g.N ? gr : g.N - 1;
-        pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
-    }
-    auto stage_in = [&](int buf, int kt) {
-        char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
-        char *sb = smem + buf * STAGE + BM * 64 + (wid * B_PC) * 1024;
-#pragma unroll
-        for (int i = 0; i < A_PC; ++i)
-            lds_dma16(g.A, sa + i * 1024, pa[i], kt * (KB * 2));
-#pragma unroll
-        for (int i = 0; i < B_PC; ++i)
-            lds_dma16(g.W, sb + i * 1024, pb[i], kt * (KB * 2));
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    stage_in(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int nkd = (g.dbg & 2) ? 1 : nk;
-    for (int kt = 0; kt < nkd; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage_in(cur ^ 1, kt + 1);
-        const char *sa = smem + cur * STAGE + (wm * WM) * 64;
-        const char *sb = smem + cur * STAGE + BM * 64 + (wn * WN) * 64;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[TN];
-            const int kc = ks * 2 + hi;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = j * 32 + l31;
-                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = i * 32 + l31;
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
-}
-
-template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
-int launch_glds32_e(const GemmArgs &g, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr int stages = 2 * (BM + BN) * 64, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
-    constexpr int smem = stages > epi ? stages : epi;
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds32_kernel<BM, BN, NWM, NWN, EPI, MINW>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_glds32_kernel<BM, BN, NWM, NWN, EPI, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-template <int BM, int BN, int NWM, int NWN, int MINW>
-int launch_glds32(const GemmArgs &g, hipStream_t s) {
-    if (g.epi == 1) return launch_glds32_e<BM, BN, NWM, NWN, 1, MINW>(g, s);
-    if (g.epi == 2) return launch_glds32_e<BM, BN, NWM, NWN, 2, MINW>(g, s);
-    return launch_glds32_e<BM, BN, NWM, NWN, 0, MINW>(g, s);
-}
-
-// ---- ping-pong schedule (8 waves, K % 64 == 0) ------------------------------------------------------
-// A CU has 4 SIMDs; waves w and w + 4 of a workgroup share one.  The K-step is cut into 4 intervals
-// (read fragments of half 0 | 16 MFMAs | read half 1 | 16 MFMAs) separated by raw s_barriers, and the upper
-// wave group enters the loop one barrier late, so in every interval one wave of each SIMD issues MFMAs
-// while its partner does LDS reads and the LDS-DMA issue for the next K-step: the matrix pipe sees a
-// continuous MFMA stream instead of both waves stalling and computing in lockstep.
-// Hazards: fragment reads complete (lgkmcnt(0)) before the barrier that ends their interval, so the DMA that
-// refills a stage (issued >= 1 barrier after its last read) never races a ds_read; every wave drains its own
-// DMAs (vmcnt(0)) before the barrier that precedes the first read of the refilled stage.
-template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
-__global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_pp_kernel(const GemmArgs g) {
-    constexpr int NW = NWM * NWN;
-    constexpr int WM = BM / NWM, WN = BN / NWN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_PC = BM / 8 / NW, B_PC = BN / 8 / NW;
-    constexpr int STAGE = (BM + BN) * 128;
-    static_assert(NW == 8 && A_PC >= 1 && B_PC >= 1 && WN == 64, "unsupported geometry");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    int tm_i, tn_i;
-    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / NWN, wn = wid % NWN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nk = g.K / BK;
-    const bool late = wid >= NW / 2;  // the wave group that runs one interval behind
-
-    const bf16 *pa[A_PC], *pb[B_PC];
-    const int prow = lane >> 3, pslot = lane & 7;
-#pragma unroll
-    for (int i = 0; i < A_PC; ++i) {
-        const int row = (wid * A_PC + i) * 8 + prow;
-        int gr = m0 + row;
-        gr = gr < g.M ? gr : g.M - 1;
-        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 1) & 7)) << 3);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PC; ++i) {
-        const int row = (wid * B_PC + i) * 8 + prow;
-        int gr = n0 + row;
-        gr = gr < g.N ? gr : g.N - 1;
-        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 1) & 7)) << 3);
-    }
-    auto stage_in = [&](int buf, int kt) {
-        char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
-        char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
-#pragma unroll
-        for (int i = 0; i < A_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + kt * BK), (lds_void *)(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_PC; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + kt * BK), (lds_void *)(sb + i * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    bf16x8 af[2][TM], bfr[2][TN];
-    auto read_half = [&](int buf, int half) {
-        const char *sa = smem + buf * STAGE + (wm * WM) * 128;
-        const char *sb = smem + buf * STAGE + BM * 128 + (wn * WN) * 128;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int kc = (half * 2 + k2) * 2 + hi;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = j * 32 + l31;
-                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = i * 32 + l31;
-                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
-            }
-        }
-    };
-    auto mma_half = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define PP_BARRIER()                          \
-    do {                                      \
-        __builtin_amdgcn_sched_barrier(0);    \
-        __builtin_amdgcn_s_barrier();         \
-        __builtin_amdgcn_sched_barrier(0);    \
-    } while (0)
-
-    stage_in(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();
-    if (late) PP_BARRIER();
-
-    const int nkd = (g.dbg & 2) ? 1 : nk;
-    for (int kt = 0; kt < nkd; ++kt) {
-        const int cur = kt & 1;
-        // interval R0: next K-step's DMA, fragments of the first half
-        if (kt + 1 < nk) stage_in(cur ^ 1, kt + 1);
-        read_half(cur, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        mma_half();  // interval M0
-        PP_BARRIER();
-        read_half(cur, 1);  // interval R1
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        mma_half();  // interval M1
-        PP_BARRIER();
-    }
-    if (!late) PP_BARRIER();
-#undef PP_BARRIER
-
-    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
-}
-
-// ---- ping-pong schedule on HALF K-steps (256x256 tile, 8 waves, K % 64 == 0) -------------------------------
-// The K dimension is consumed in halves of 32 (H_0, H_1, ...), each living in one of FOUR 32-KiB LDS
-// half-buffers (A 256x32 + W 256x32, 64-byte rows, swz32).  Every wave alternates
-//     R#n : read the fragments of H_n (12 x ds_read_b128), issue its 4 LDS-DMA pieces of H_{n+2} (the buffer
-//           H_{n-2} vacated), lgkmcnt(0), vmcnt(4) (= the pieces it issued in R#(n-1), i.e. H_{n+1}, have
-//           landed), s_barrier
-//     M#n : 16 MFMAs on those fragments, s_barrier
-// and the upper four waves run one barrier late, so on every SIMD one wave is always in an M interval while its
-// partner is in an R interval: MFMA issue, LDS reads and DMA issue overlap instead of alternating.  Safety:
-// H_{n+2} overwrites the buffer of H_{n-2}, whose last reader finished >= 1 barrier earlier with lgkmcnt(0);
-// H_{n+1} is complete on every wave before the barrier that precedes its first reader (proof in DESIGN.md).
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
-    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
-    constexpr int HALF = (BM + BN) * 64;  // bytes per half-buffer
-    constexpr int PC = 2;                  // 1-KiB pieces (16 rows x 64 B) per wave per operand per half
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int tm_i, tn_i;
-    tile_coords(g, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, tm_i, tn_i);
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / NWN, wn = wid % NWN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nh = g.K / 32;  // number of halves (even)
-    const bool late = wid >= NW / 2;
-
-    const bf16 *pa[PC], *pb[PC];
-    const int prow = lane >> 2, pslot = lane & 3;
-#pragma unroll
-    for (int i = 0; i < PC; ++i) {
-        const int row = (wid * PC + i) * 16 + prow;
-        int gr = m0 + row;
-        gr = gr < g.M ? gr : g.M - 1;
-        pa[i] = g.A + (int64_t)gr * g.lda + ((pslot ^ ((row >> 2) & 3)) << 3);
-        gr = n0 + row;
-        gr = gr < g.N ? gr : g.N - 1;
-        pb[i] = g.W + (int64_t)gr * g.ldw + ((pslot ^ ((row >> 2) & 3)) << 3);
-    }
-    auto stage_half = [&](int n) {  // DMA of H_n into half-buffer n % 4
-        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
-        char *sb = sa + BM * 64;
-#pragma unroll
-        for (int i = 0; i < PC; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void *)(pa[i] + n * 32), (lds_void *)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void *)(pb[i] + n * 32), (lds_void *)(sb + i * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    bf16x8 af[2][TM], bfr[2][TN];
-    auto read_half = [&](int n) {
-        const char *sa = smem + (n & 3) * HALF + (wm * WM) * 64;
-        const char *sb = smem + (n & 3) * HALF + BM * 64 + (wn * WN) * 64;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int kc = k2 * 2 + hi;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = j * 32 + l31;
-                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = i * 32 + l31;
-                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
-            }
-        }
-    };
-    auto mma_half = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define PP_BARRIER()                       \
-    do {                                   \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-
-    stage_half(0);
-    stage_half(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();
-    if (late) PP_BARRIER();
-
-    const int nhd = (g.dbg & 2) ? 2 : nh;
-    for (int n = 0; n < nhd; ++n) {
-        // R#n
-        read_half(n);
-        if (n + 2 < nh) {
-            stage_half(n + 2);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");  // reads done; H_{n+1} (issued in R#(n-1)) landed
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-        }
-        PP_BARRIER();
-        // M#n
-        mma_half();
-        PP_BARRIER();
-    }
-    if (!late) PP_BARRIER();
-#undef PP_BARRIER
-
-    gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
-}
 
 // ---- persistent form of the half-K-step ping-pong kernel --------------------------------------------------
 // One workgroup per CU walks tiles t = blockIdx.x, + gridDim.x, ...  What the per-tile launch form pays once
@@ -829,9 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(const GemmArgs g) {
 // epilogue — is overlapped here: the first two halves of the NEXT tile are DMA'd into half-buffers 0/1 as soon
 // as the K loop ends, while the epilogue runs out of the other half of LDS (two passes of 64 rows per wave:
 // 69.6 KB at offset 64 KB), and the epilogue's global stores drain under the next tile's first K-steps.
-// DM = 1: the LDS-DMA pieces of half n+3 are issued BETWEEN the MFMAs of M#n (one piece after every 4th MFMA) instead of
-// in R#n: the R phase (12 ds_read_b128 + 4 pieces ~ 680 cycles) was longer than the M phase it has to hide under (512).
-template <int EPI, int DM>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
@@ -909,27 +539,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto mma_half_dma = [&](int n) {  // the same 16 MFMAs with the 4 pieces of half n interleaved
-        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
-        char *sb = sa + BM * 64;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
-                if ((i & 1) == 0) {
-                    const int pc = i >> 1;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (k2 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + pc * 1024), 16, pa[pc], n * 64, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + pc * 1024), 16, pb[pc], n * 64, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
 #define PP_BARRIER()                       \
     do {                                   \
         __builtin_amdgcn_sched_barrier(0); \
@@ -955,39 +564,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
         PP_BARRIER();
         if (late) PP_BARRIER();
         const int nhd = (g.dbg & 2) ? 2 : nh;
-        if (DM) {
-            // half-buffer 2 was the epilogue's staging area until the barrier above
-            if (2 < nh) stage_half(2);
-            // H_m is read by the early group after barrier 2m and by the late group after barrier 2m+1, so every wave's
-            // pieces of H_m must have landed before barrier 2m: early waves wait at the end of M#(m-1) (younger in flight:
-            // H_{m+1}, H_{m+2}), late waves — whose M#(m-1) comes after that barrier — at the end of R#(m-1) (younger: H_{m+1})
-            int n = 0;
-            for (; n + 3 < nh; ++n) {  // steady state
-                read_half(n);
-                if (late) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                mma_half_dma(n + 3);
-                if (!late) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                PP_BARRIER();
-            }
-            for (; n < nh; ++n) {  // the last three halves: nothing left to issue
-                read_half(n);
-                if (late) {
-                    if (n + 2 < nh) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                PP_BARRIER();
-                mma_half();
-                if (!late) {
-                    if (n + 2 < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                PP_BARRIER();
-            }
-        } else
         for (int n = 0; n < nhd; ++n) {
             if (!(g.dbg & 16384) || n == 0) read_half(n);
             if (n + 2 < nh) {
@@ -1020,12 +596,9 @@ int launch_pp3(const GemmArgs &g, hipStream_t s) {
     constexpr int smem = 2 * 32768 + 8 * 64 * (64 * 2 + 8);  // half-buffers 0/1 + epilogue staging (which overlays 2/3)
     static_assert(smem >= 4 * 32768, "staging must cover half-buffers 2 and 3");
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         int dev = 0;
         EILEV_HIP_CHECK(hipGetDevice(&dev));
         EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1033,31 +606,9 @@ int launch_pp3(const GemmArgs &g, hipStream_t s) {
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    const bool dm = (g.dbg & 65536) != 0;
-    if (dm) {
-        if (g.epi == 1) hipLaunchKernelGGL((gemm_pp3_kernel<1, 1>), dim3(grid), dim3(512), smem, s, g);
-        else if (g.epi == 2) hipLaunchKernelGGL((gemm_pp3_kernel<2, 1>), dim3(grid), dim3(512), smem, s, g);
-        else hipLaunchKernelGGL((gemm_pp3_kernel<0, 1>), dim3(grid), dim3(512), smem, s, g);
-    } else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp3_kernel<1, 0>), dim3(grid), dim3(512), smem, s, g);
-    else if (g.epi == 2) hipLaunchKernelGGL((gemm_pp3_kernel<2, 0>), dim3(grid), dim3(512), smem, s, g);
-    else hipLaunchKernelGGL((gemm_pp3_kernel<0, 0>), dim3(grid), dim3(512), smem, s, g);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-
-int launch_pp2(const GemmArgs &g, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr int smem = 8 * 128 * (64 * 2 + 8);  // 4 half-buffers = 128 KiB < epilogue staging 139264 B
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp2_kernel<1>, dim3(tiles), dim3(512), smem, s, g);
-    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp2_kernel<2>, dim3(tiles), dim3(512), smem, s, g);
-    else hipLaunchKernelGGL(gemm_pp2_kernel<0>, dim3(tiles), dim3(512), smem, s, g);
+    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp3_kernel<1>, dim3(grid), dim3(512), smem, s, g);
+    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp3_kernel<2>, dim3(grid), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL(gemm_pp3_kernel<0>, dim3(grid), dim3(512), smem, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
@@ -1267,28 +818,6 @@ int launch_tiled_e(const GemmArgs &g, hipStream_t s) {
     return EILEV_OK;
 }
 
-template <int BM, int BN, int NWM, int NWN, int EPI, int MINW>
-int launch_pp_e(const GemmArgs &g, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr int stages = 2 * (BM + BN) * 128, epi = NWM * NWN * (BM / NWM) * ((BN / NWN) * 2 + 8);
-    constexpr int smem = stages > epi ? stages : epi;
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_kernel<BM, BN, NWM, NWN, EPI, MINW>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, NWM, NWN, EPI, MINW>), dim3(tiles), dim3(64 * NWM * NWN), smem, s, g);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-template <int BM, int BN, int NWM, int NWN, int MINW>
-int launch_pp(const GemmArgs &g, hipStream_t s) {
-    if (g.epi == 1) return launch_pp_e<BM, BN, NWM, NWN, 1, MINW>(g, s);
-    if (g.epi == 2) return launch_pp_e<BM, BN, NWM, NWN, 2, MINW>(g, s);
-    return launch_pp_e<BM, BN, NWM, NWN, 0, MINW>(g, s);
-}
-
 template <int BM, int BN, int NWM, int NWN, int NSTAGE, int MINW, int PRIO = 0>
 int launch_tiled(const GemmArgs &g, hipStream_t s) {
     if (g.epi == 1) return launch_tiled_e<BM, BN, NWM, NWN, 1, NSTAGE, MINW, PRIO>(g, s);
@@ -1345,20 +874,14 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else cfg = 4;                                                            // 128x128
     bool wide_tiles = false;
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
-    if (force) cfg = force;
-    if (cfg == 0 && false) rc = 0;
-    else if (((g.dbg >> 4) & 15) == 8 && g.K % 64 == 0) rc = launch_pp2(g, s);
-    else if (((g.dbg >> 4) & 15) == 9 && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
-        rc = launch_pp3(g, s);
-    else if (cfg == 7 && g.K % 32 == 0) rc = launch_glds32<256, 128, 4, 2, 4>(g, s);
-    else if (cfg == 5 && g.K % BK == 0) rc = launch_pp<256, 256, 2, 4, 2>(g, s);
-    else if (cfg == 6 && g.K % BK == 0) rc = launch_pp<256, 128, 4, 2, 2>(g, s);
-    else if (cfg == 1 && !force && !wide_tiles && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+    if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
+    else if (force >= 1 && force <= 4) cfg = force;
+    if (cfg == 1 && !wide_tiles && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
+        (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp3(g, s);  // persistent half-K-step ping-pong kernel
-    else if (cfg == 1 || cfg == 5) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
-    else if (cfg == 3 && (g.dbg & 512)) rc = launch_tiled<256, 128, 4, 2, 1, 4, 0>(g, s);
+    else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
-    else if (cfg == 2 || cfg == 6) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
+    else if (cfg == 2) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
     else rc = launch_tiled<128, 128, 2, 2, 2, 2>(g, s);
     if (prof_kind >= 0) prof_end(s);
     return rc;

@@ -1,5 +1,13 @@
 #!/usr/bin/env python
-"""GPU probe: time eilev_linear on the ViT/OPT GEMM shapes; variants interleaved, several rounds (min / median)."""
+"""GPU probe: time eilev_linear on the ViT/OPT GEMM shapes; variants interleaved, several rounds (min / median).
+
+    [PROBE_M=rows] python tools/gemm_probe.py <flags,flags,...> <shape,shape,...> <rounds>
+
+flags (eilev_debug_gemm_flags): 4 register-staged reference kernel; 8 old skinny kernel; (n << 4) force tile config n
+(1: 256x256, 2: 256x128 two stages, 3: 256x128 one stage x 2 workgroups/CU, 4: 128x128, 9: persistent ping-pong kernel);
+1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0 (cache-resident operand);
+16384 / 32768 drop the fragment reads / the LDS-DMA of the persistent kernel's K loop (results are wrong: timing only).
+"""
 import ctypes as C
 import os
 import statistics
