@@ -436,5 +436,41 @@ class HipEngine:
         return torch.cat((start, out[:, :n]), dim=1)
 
 
+    def t5_beam(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1, pad_id=0, start_id=0,
+                early_stopping=False, num_return_sequences=1):
+        """Beam search for the encoder-decoder LM [sample default num_beams=5, length_penalty=-1; hf generation/utils.py:3208+]:
+        the encoder runs once per sample, its cross K/V are replicated to the beams, every step reorders the self-attention
+        cache rows by the surviving beams' parents and runs one decoder step on all rows."""
+        from .beam import beam_search
+
+        # hf generation/utils.py:3319 `output_fill_value = pad_token_id or eos_token_id[0] ...`: a pad id of 0 (T5) is falsy,
+        # so finished hypotheses are padded with the EOS id
+        if pad_id == 0:
+            pad_id = eos_id if eos_id >= 0 else -1
+        d = self.t5dims
+        enc = self.t5_encode(inputs_embeds, attention_mask)
+        B, L, _ = enc.shape
+        R = B * num_beams
+        planes = 2 * d.dec_layers
+        ckv = self.t5_cross_kv(enc).view(planes, B, -1).repeat_interleave(num_beams, dim=1).contiguous()
+        am = attention_mask.to(self.device, torch.int32).repeat_interleave(num_beams, dim=0).contiguous()
+        cap = max_new_tokens + 1
+        skv = torch.zeros(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), R, cap)), dtype=torch.uint8, device=self.device).view(planes, R, -1)
+        start = torch.full((R, 1), int(start_id), dtype=torch.int64, device=self.device)
+        first = self.t5_decode(start, am, 0, skv, cap, ckv, L)[:, 0]
+        steps = [0]
+
+        def step(next_tokens, beam_src):
+            nonlocal skv
+            skv = skv.index_select(1, beam_src)
+            steps[0] += 1
+            return self.t5_decode(next_tokens.view(R, 1), am, steps[0], skv, cap, ckv, L)[:, 0]
+
+        ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
+                          early_stopping, num_return_sequences)
+        head = torch.full((ids.shape[0], 1), int(start_id), dtype=torch.int64, device=self.device)
+        return torch.cat((head, ids), dim=1)
+
+
 def abi_dtype(t: torch.Tensor) -> int:
     return 0 if t.dtype == torch.float32 else 1

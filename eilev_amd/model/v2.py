@@ -390,10 +390,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             attention_mask = torch.ones_like(input_ids)
         emb, _, _ = self._encode(pixel_values, input_ids, video_input_mask)
         if self._is_t5:
-            if num_beams > 1:
-                raise NotImplementedError("beam search for the encoder-decoder LM is not built on the HIP path (greedy is)")
             t = self.config.text_config
             start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
+            if num_beams > 1:
+                return self.engine().t5_beam(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
+                                             eos_id=int(-1 if eos is None else eos), pad_id=int(pad), start_id=int(start),
+                                             early_stopping=early_stopping, num_return_sequences=int(num_return))
             return self.engine().t5_greedy(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
                                            start_id=int(start))
         if num_beams > 1:

@@ -259,6 +259,41 @@ class OracleModel:
                 break
         return np.concatenate(out, axis=1)
 
+    def t5_generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1,
+                         pad_id=0, start_id=0, early_stopping=False):
+        """Beam search for the encoder-decoder LM: eilev_amd.beam (the HF-equivalent selection rule) over the oracle decoder."""
+        import torch
+
+        from eilev_amd.beam import beam_search
+
+        if pad_id == 0:  # hf generation/utils.py:3319: `pad_token_id or eos_token_id[0]` — pad id 0 is falsy
+            pad_id = eos_id if eos_id >= 0 else -1
+        d = self.t5dims
+        emb = self.encode(pixels, input_ids, video_mask)
+        enc = self.t5_encode(emb, attn_mask)
+        B, L = enc.shape[:2]
+        R = B * num_beams
+        planes = 2 * d.dec_layers
+        ckv = np.ascontiguousarray(np.repeat(self.t5_cross_kv(enc).reshape(planes, B, -1), num_beams, axis=1))
+        am = np.repeat(np.ascontiguousarray(attn_mask, dtype=np.int32), num_beams, axis=0)
+        cap = max_new_tokens + 1
+        skv = np.zeros(self.lib.eilev_t5_self_kv_bytes(C.byref(d), R, cap) // 4, np.float32)
+        start = np.full((R, 1), start_id, np.int64)
+        first = self.t5_decode(start, am, 0, skv, cap, ckv, L)[:, 0]
+        steps = [0]
+
+        def step(next_tokens, beam_src):
+            nonlocal skv
+            src = beam_src.numpy()
+            skv = np.ascontiguousarray(skv.reshape(planes, R, -1)[:, src]).reshape(-1)
+            steps[0] += 1
+            logits = self.t5_decode(next_tokens.numpy().reshape(R, 1), am, steps[0], skv, cap, ckv, L)[:, 0]
+            return torch.from_numpy(logits)
+
+        ids = beam_search(step, torch.from_numpy(first[::num_beams].copy()), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
+                          early_stopping).numpy()
+        return np.concatenate((np.full((ids.shape[0], 1), start_id, np.int64), ids), axis=1)
+
     def generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1,
                       pad_id=1, early_stopping=False):
         """Beam search = reference generate(num_beams=k) with the oracle as the language model (eilev_amd.beam drives it)."""

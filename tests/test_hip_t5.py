@@ -156,3 +156,19 @@ def test_t5_xl_widths_decode_equals_teacher_forcing():
     for i in range(T):
         step = eng.t5_decode(dec[:, i:i + 1], am, i, skv, T, ckv, L)
         assert rel_rms(host(step[:, 0]), host(full[:, i])) <= 1e-2, i
+
+
+@pytest.mark.parametrize("nm,nb,lp", [("beam5_lpm1", 5, -1.0), ("beam3_lp1", 3, 1.0)])
+@pytest.mark.parametrize("name", CASES)
+def test_t5_beam_search(golden_dir, name, nm, nb, lp):
+    """generate(num_beams=k) for the encoder-decoder LM on the HIP path vs the reference's beam outputs (exact when the
+    reference's fp32 and bf16 runs agree, else the fp32 or the bf16 ids)."""
+    g, meta, px = load_case(golden_dir, name)
+    cfg, oracle, eng = models(meta["config"])
+    t = lambda a: torch.from_numpy(a).cuda()
+    emb = _encode(eng, g, px)
+    n = meta["new_tokens"]
+    for eos, suffix in ((int(g["fp32_eos_id"]), ""), (-1, "_free")):
+        ids = eng.t5_beam(emb, t(g["attention_mask"]), n, nb, lp, eos_id=eos).cpu().numpy()
+        cands = [g[f"fp32_{nm}{suffix}"], g[f"bf16_{nm}{suffix}"]]
+        assert any(ids.shape == c.shape and np.array_equal(ids, c) for c in cands), (ids, cands)

@@ -181,3 +181,21 @@ def shifted_ce_loss_t5(logits, labels):
     keep = labels >= 0
     tok = np.take_along_axis(x, np.where(keep, labels, 0)[..., None], axis=-1)[..., 0]
     return float(((lse - tok) * keep).sum() / keep.sum())
+
+
+@pytest.mark.parametrize("nm,nb,lp", BEAMS)
+@pytest.mark.parametrize("name", T5_CASES)
+def test_t5_beam_search_matches_reference(golden_dir, models, name, nm, nb, lp):
+    """eilev_amd.beam over the oracle's T5 decoder == HF _beam_search through the reference's generate() (encoder-decoder:
+    the decoder prompt is the start token, penalties count generated tokens only)."""
+    g, meta, cfg, px = load_case(golden_dir, name)
+    if f"fp32_{nm}" not in g:
+        pytest.skip("fixture without beam outputs")
+    m = models(meta["config"])
+    n = meta["new_tokens"]
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, nb, lp)
+    ids = m.t5_generate_beam(*args, eos_id=int(g["fp32_eos_id"]))
+    ref = g[f"fp32_{nm}"]
+    assert ids.shape == ref.shape and np.array_equal(ids, ref), (ids, ref)
+    free = m.t5_generate_beam(*args, eos_id=-1)
+    assert np.array_equal(free, g[f"fp32_{nm}_free"])

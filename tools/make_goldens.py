@@ -145,6 +145,11 @@ def run_t5_case(name):
                        max_new_tokens=new_tokens, num_beams=1, do_sample=False, eos_token_id=eos)
         out[f"{tag}_greedy_eos"] = g.numpy().astype(np.int64)
         out[f"{tag}_eos_id"] = np.asarray(eos, dtype=np.int64)
+        for nbm, lp, nm in ((5, -1.0, "beam5_lpm1"), (3, 1.0, "beam3_lp1")):
+            for e_id, suffix in ((eos, ""), (never, "_free")):
+                g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                               max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=e_id)
+                out[f"{tag}_{nm}{suffix}"] = g.numpy().astype(np.int64)
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="fanin",
                 torch=torch.__version__, transformers=transformers.__version__, generator="tools/make_goldens.py",
                 reference="/root/reference/eilev/model/v2.py", padding="right", scale_decoder_outputs=bool(cfg.text_config.scale_decoder_outputs))
