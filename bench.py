@@ -159,12 +159,22 @@ def main():
     assert px.shape[0] == len(mine)
     my_first_clip = rank * S * (N_CTX + 1)
 
+    def stamp(name):
+        if eng.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            eng.timing.append((name, ev))
+
     def step():
+        stamp("step_begin")
         feats = eng.encode_clips(px)                                         # (n_local*32, Dt) for my dealt clips
         allf = gather_clip_tokens(feats, total_clips, nq)                    # RCCL all-gather (identity at N=1)
         mine_f = allf[my_first_clip * nq:(my_first_clip + S * (N_CTX + 1)) * nq]  # clips of MY samples, global order
         emb = eng.embed_scatter(ids, vm, mine_f)
-        return eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)
+        stamp("encode_done")
+        out_ids = eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)  # stamps "prefill_done"
+        stamp("step_end")
+        return out_ids
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -176,11 +186,21 @@ def main():
         out = step()
     sync()
     eng.lib.eilev_prof_enable(1)
+    eng.timing = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync()
     dt = time.perf_counter() - t0
+    # phase breakdown from events recorded on the launch stream inside the timed region (SURVEY §8d asks for these)
+    phases = {"encode": 0.0, "prefill": 0.0, "decode": 0.0}
+    marks = eng.timing
+    eng.timing = None
+    for i in range(0, len(marks), 4):
+        (_, b0), (_, e1), (_, p1), (_, s1) = marks[i:i + 4]
+        phases["encode"] += b0.elapsed_time(e1)
+        phases["prefill"] += e1.elapsed_time(p1)
+        phases["decode"] += p1.elapsed_time(s1)
     assert out.shape == (S, NEW_TOKENS)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -216,6 +236,11 @@ def main():
                                     f"{'RCCL all-gather' if world > 1 else 'no collective at N=1'}"),
                        "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": 960, "new_tokens": NEW_TOKENS},
             "whole_path_tflops": round(TFLOP_PER_SAMPLE * world * S * args.steps / dt, 1),
+            "phases_rank0": {"encode_ms_per_step": round(phases["encode"] / args.steps, 2),
+                             "encode_only_clips_per_s": round(S * (N_CTX + 1) * args.steps / (phases["encode"] * 1e-3), 1),
+                             "prefill_ms_per_step": round(phases["prefill"] / args.steps, 2),
+                             "decode_ms_per_token": round(phases["decode"] / args.steps / (NEW_TOKENS - 1), 3),
+                             "samples_per_s": round(world * S * args.steps / dt, 3)},
         }
         if best is not None:
             nm, n, ms, fl = best

@@ -35,6 +35,7 @@ class HipEngine:
             raise RuntimeError(f"HipEngine weights must live on the GPU, got {self.device}")
         self._keep = {}
         self._ws = {}
+        self.timing = None  # bench.py sets this to a list to collect phase events
         self.parts = tuple(parts)
         self._load(named_tensors)
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
@@ -259,6 +260,10 @@ class HipEngine:
         cap = L + max_new_tokens
         am = attention_mask.to(self.device, torch.int32).contiguous()
         last, _, kv = self.prefill(inputs_embeds, am, kv_capacity=cap)
+        if self.timing is not None:  # optional phase stamps for bench.py (events on the launch stream, no sync)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.append(("prefill_done", ev))
         state = torch.zeros(2, dtype=torch.int32, device=self.device)
         finished = torch.zeros(B, dtype=torch.uint8, device=self.device)
         tokens = torch.zeros(B, dtype=torch.int64, device=self.device)
