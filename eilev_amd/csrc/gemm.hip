@@ -427,6 +427,57 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     const int nkd = (g.dbg & 2) ? 1 : nk;
+    // Half-empty last column tile (N % 256 <= 128, e.g. N = 1408 = 5.5 x 256): only columns [0, 128) of the tile exist.
+    // Instead of letting the waves of the two right-hand column blocks multiply padding, the 8 waves re-split the valid
+    // 256 x 128 region as 4 x 2 blocks of 64 x 64: half the MFMAs per wave, no DMA for the missing W rows.
+    constexpr bool HALF_OK = BM == 256 && BN == 256 && NWM == 2 && NWN == 4 && NSTAGE == 2;
+    const bool half_tile = HALF_OK && n0 + 128 >= g.N && !(g.dbg & 524288);
+    if (HALF_OK && half_tile) {
+        const int hm = wm * 2 + (wn >> 1), hn = wn & 1;  // 64-row block, 64-column block of this wave
+        auto stage_half_tile = [&](int buf, int kt) {
+            char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
+            char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
+#pragma unroll
+            for (int i = 0; i < A_PC; ++i) lds_dma16(g.A, sa + i * 1024, pa[i], kt * (BK * 2));
+            if (wid < NW / 2) {  // W rows 128..255 of the tile are beyond N
+#pragma unroll
+                for (int i = 0; i < B_PC; ++i) lds_dma16(g.W, sb + i * 1024, pb[i], kt * (BK * 2));
+            }
+        };
+        auto compute_half = [&](int buf) {
+            const char *sa = smem + buf * STAGE + (hm * 64) * 128;
+            const char *sb = smem + buf * STAGE + BM * 128 + (hn * 64) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 bfr[2];
+                const int kc = ks * 2 + hi;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = j * 32 + l31;
+                    bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(hn * 64 + row, kc));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 32 + l31;
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(hm * 64 + row, kc));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        stage_half_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nkd; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage_half_tile(cur ^ 1, kt + 1);
+            compute_half(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        gemm_epilogue<64, 64, EPI>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem, m0, n0, hm, hn, wid, lane);
+        return;
+    }
     if (NSTAGE == 2) {
         stage_in(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

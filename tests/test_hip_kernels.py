@@ -153,3 +153,14 @@ def test_attention_online_softmax_rescale_branch(hip):
     assert hip.eilev_attention(P(dq), P(dk), P(dv), P(out), 1, 1, sq, skv, hd, hd, hd, hd, 1.0, 0, None, stream_ptr()) == 0
     torch.cuda.synchronize()
     assert np.abs(host(out) - ref).max() <= 2e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(1000, 1408, 1408, 0), (700, 1408, 640, 1), (520, 1536, 128, 0), (300, 128, 256, 2)])
+def test_linear_256x256_half_column_tile(hip, m, n, k, epi):
+    """N % 256 <= 128 with the 256x256 kernel forced: the last column tile runs the 8-waves-as-4x2 half-tile path."""
+    raw = C.CDLL(abi.HIP_LIB_PATH)
+    raw.eilev_debug_gemm_flags(1 << 4)
+    try:
+        _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
+    finally:
+        raw.eilev_debug_gemm_flags(0)
