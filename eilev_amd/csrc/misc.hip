@@ -204,11 +204,14 @@ __global__ __launch_bounds__(256) void kv_write_kernel(const bf16 *__restrict__ 
 // hd/8 independent 16-byte loads in flight), thread = (key subset, d chunk) for p.V; HBM-bound.
 constexpr int DEC_KEYS = 256;
 
+// T5 use: state == nullptr (kv_total = seq_len, given by the host), attn_mask may be null (every key visible), ldq = row
+// stride of the query rows, rel_tab = per-head relative position bias over (key - query position), query at kv_total - 1.
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ kc,
                                                                 const bf16 *__restrict__ vc, float *__restrict__ part,
                                                                 const int32_t *__restrict__ attn_mask,
                                                                 const int32_t *__restrict__ state, int seq_len, int cap,
-                                                                int heads, int hd) {
+                                                                int heads, int hd, int64_t ldq, const float *__restrict__ rel_tab,
+                                                                int64_t rel_hs, int rel_off) {
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float sc[DEC_KEYS];
     __shared__ float red[DEC_KEYS * 17];  // per-key chunk partials (stride 17), later the p.V partials (nks * hd <= 2048)
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
     const int d = heads * hd, nch = hd >> 3;
-    const int kv_total = min(cap, seq_len + state[0]);
+    const int kv_total = min(cap, seq_len + (state ? state[0] : 0));
     const int k0 = sp * DEC_KEYS, k1 = min(kv_total, k0 + DEC_KEYS);
     float *po = part + (((int64_t)b * heads + h) * nsplit + sp) * (hd + 2);
     if (k0 >= kv_total) {  // nothing in this split yet
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     }
     const bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd;
     const bf16 *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
-    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * 3 * d + h * hd + tid];
+    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
     __syncthreads();
 
     // scores: thread = (key subset ks, d chunk c) so that consecutive lanes read consecutive 16-byte chunks (a K row is
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     if (j < k1) {
         float acc = 0.0f;
         for (int cc = 0; cc < nch; ++cc) acc += red[tid * 17 + cc];
-        const bool vis = j >= seq_len || attn_mask[(int64_t)b * seq_len + j] != 0;
+        const bool vis = j >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + j] != 0;
+        if (rel_tab) acc += rel_tab[(int64_t)h * rel_hs + (j - (kv_total - 1)) + rel_off];
         s = vis ? acc : -1e30f;
     }
     float mxw = wave_max(s);
@@ -527,12 +531,14 @@ size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
     return sizeof(float) * (size_t)batch * heads * nsplit * (hd + 2);
 }
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
-                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s) {
+                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0) {
+    if (ldq == 0) ldq = 3 * (int64_t)heads * hd;  // q | k | v rows
     if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
     const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
     if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap)) return EILEV_E_WORKSPACE;
     hipLaunchKernelGGL(attn_decode_split_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, kc, vc, scratch, attn_mask, state,
-                       seq_len, cap, heads, hd);
+                       seq_len, cap, heads, hd, ldq, rel_tab, rel_hs, rel_off);
     EILEV_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, nsplit);
     EILEV_LAUNCH_CHECK();

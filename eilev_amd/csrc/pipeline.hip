@@ -19,7 +19,9 @@ int launch_decode_embed(const bf16 *embed, const bf16 *pos, const int64_t *token
 int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per_b, int heads, int hd, int cap, int seq_len,
                     const int32_t *state, hipStream_t s, int slot0 = 0);
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
-                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s);
+                       int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0);
+size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
 
@@ -580,7 +582,7 @@ GemmArgs t5_gemm(const T5Bufs &b, const bf16 *A, int64_t lda, const void *W, int
                  int64_t ldc, int64_t M, int N, int K) {
     GemmArgs g = mk_gemm(A, lda, W, ldw, nullptr, resid, ldr, Cp, ldc, M, N, K, 0);
     g.scratch = b.scratch;
-    g.scratch_bytes = kSkinnyScratch;
+    g.scratch_bytes = kSkinnyScratch / 2;  // the other half holds the decode-attention partials
     return g;
 }
 // up to three projections of x with a shared input: one GEMM when the weights sit back to back in memory (the engine packs them)
@@ -688,6 +690,10 @@ extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, co
     // causal self-attention: key j of query at absolute position p: rel = j - p in [-(total-1), 0]: index rel + total - 1
     RC(launch_t5_rel_table((const bf16 *)w->dec_rel_bias, b.rel, (int)total, (int)total - 1, H, 0, d->rel_buckets, d->rel_max_dist, s));
     const size_t splane = (size_t)batch * H * kv_capacity * hd, cplane = (size_t)batch * H * enc_len * hd;
+    // single-query steps use the split decode-attention kernel; its partials live in the second half of the skinny scratch
+    const size_t skinny_f = kSkinnyScratch / 2 / sizeof(float);
+    const int64_t kmax = kv_capacity > enc_len ? kv_capacity : enc_len;
+    const bool single = new_len == 1 && attn_decode_scratch_bytes((int)batch, H, hd, (int)kmax) <= kSkinnyScratch / 2;
     for (int l = 0; l < d->dec_layers; ++l) {
         const EilevT5Layer *L = &w->dec_layers[l];
         bf16 *kc = (bf16 *)self_kv + 2 * (size_t)l * splane, *vc = kc + splane;
@@ -697,29 +703,40 @@ extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, co
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
         RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
         RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
+        if (single) {
+            // one query row per sequence: flash-decoding split kernel (keys 0 .. total - 1 of the cache, bias of a single row)
+            RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd, b.scratch + skinny_f,
+                                  kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, (int)total - 1));
+        } else {
         AttnArgs a;
-        a.q = b.qkv; a.k = kc; a.v = vc; a.o = b.att;
-        a.q_bs = new_len * 3 * (int64_t)I; a.o_bs = new_len * (int64_t)I;
-        a.k_bs = a.v_bs = (int64_t)H * kv_capacity * hd;
-        a.q_hs = a.o_hs = hd; a.k_hs = a.v_hs = kv_capacity * (int64_t)hd;
-        a.ldq = 3 * I; a.ldk = a.ldv = hd; a.ldo = I;
-        a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
-        a.key_mask = nullptr; a.mask_ld = 0; a.dbg = 0;
-        a.rel_tab = b.rel; a.rel_hs = total; a.rel_off = (int)total - 1; a.rel_n = (int)total;
-        RC(launch_attention(a, s));
+            a.q = b.qkv; a.k = kc; a.v = vc; a.o = b.att;
+            a.q_bs = new_len * 3 * (int64_t)I; a.o_bs = new_len * (int64_t)I;
+            a.k_bs = a.v_bs = (int64_t)H * kv_capacity * hd;
+            a.q_hs = a.o_hs = hd; a.k_hs = a.v_hs = kv_capacity * (int64_t)hd;
+            a.ldq = 3 * I; a.ldk = a.ldv = hd; a.ldo = I;
+            a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
+            a.key_mask = nullptr; a.mask_ld = 0; a.dbg = 0;
+            a.rel_tab = b.rel; a.rel_hs = total; a.rel_off = (int)total - 1; a.rel_n = (int)total;
+            RC(launch_attention(a, s));
+        }
         RC(launch_gemm(t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I), 5, s));
         // ---- cross-attention over the encoder output (T5LayerCrossAttention :404-432): no position bias, padding mask
         RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ca, b.x, D, M, D, d->eps, s));
         RC(launch_gemm(t5_gemm(b, b.x, D, L->cq_w, D, nullptr, 0, b.qkv, I, M, I, D), 5, s));
+        if (single) {
+            RC(launch_attn_decode(b.qkv, ck, cv, b.att, enc_mask, nullptr, (int)batch, (int)enc_len, (int)enc_len, H, hd, b.scratch + skinny_f,
+                                  kSkinnyScratch / 2, s, (int64_t)I));
+        } else {
         AttnArgs c;
-        c.q = b.qkv; c.k = ck; c.v = cv; c.o = b.att;
-        c.q_bs = new_len * (int64_t)I; c.o_bs = new_len * (int64_t)I;
-        c.k_bs = c.v_bs = (int64_t)H * enc_len * hd;
-        c.q_hs = c.o_hs = hd; c.k_hs = c.v_hs = enc_len * (int64_t)hd;
-        c.ldq = I; c.ldk = c.ldv = hd; c.ldo = I;
-        c.batch = (int)batch; c.heads = H; c.sq = (int)new_len; c.skv = (int)enc_len; c.hd = hd; c.scale = 1.0f; c.causal = 0;
-        c.key_mask = enc_mask; c.mask_ld = enc_len; c.dbg = 0;
-        RC(launch_attention(c, s));
+            c.q = b.qkv; c.k = ck; c.v = cv; c.o = b.att;
+            c.q_bs = new_len * (int64_t)I; c.o_bs = new_len * (int64_t)I;
+            c.k_bs = c.v_bs = (int64_t)H * enc_len * hd;
+            c.q_hs = c.o_hs = hd; c.k_hs = c.v_hs = enc_len * (int64_t)hd;
+            c.ldq = I; c.ldk = c.ldv = hd; c.ldo = I;
+            c.batch = (int)batch; c.heads = H; c.sq = (int)new_len; c.skv = (int)enc_len; c.hd = hd; c.scale = 1.0f; c.causal = 0;
+            c.key_mask = enc_mask; c.mask_ld = enc_len; c.dbg = 0;
+            RC(launch_attention(c, s));
+        }
         RC(launch_gemm(t5_gemm(b, b.att, I, L->co_w, I, b.h, D, b.h, D, M, D, I), 5, s));
         RC(t5_ff(d, L, b, M, s));
     }
