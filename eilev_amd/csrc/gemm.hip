@@ -914,6 +914,24 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         }
         return EILEV_OK;
     }
+    // The LDS-DMA kernels address A through a 32-bit buffer offset: an A operand of 2 GiB or more (the Q-Former k|v
+    // projection of a whole step: 1.1 M rows x 1408) is processed as row chunks that fit, each with the fast kernels
+    const int64_t a_bytes = (int64_t)g.M * g.lda * 2;
+    if (a_bytes >= 0x7fff0000ll && g.K % BK == 0 && g.patch_group == 0 && !g.dbg) {
+        const int64_t rows_per = (0x7fff0000ll / (g.lda * 2)) / 256 * 256;
+        if (rows_per >= 256) {
+            for (int64_t r0 = 0; r0 < g.M; r0 += rows_per) {
+                GemmArgs c = g_in;
+                c.M = (int)((g.M - r0) < rows_per ? (g.M - r0) : rows_per);
+                c.A = g.A + r0 * g.lda;
+                if (g.resid) c.resid = g.resid + r0 * g.ldr;
+                c.C = g.out_f32 ? (void *)(reinterpret_cast<float *>(g.C) + r0 * g.ldc) : (void *)(reinterpret_cast<bf16 *>(g.C) + r0 * g.ldc);
+                const int rc_chunk = launch_gemm(c, prof_kind, s);
+                if (rc_chunk != 0) return rc_chunk;
+            }
+            return EILEV_OK;
+        }
+    }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
     const int force = (g.dbg >> 4) & 15;  // probe-only override of the tile choice

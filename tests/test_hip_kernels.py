@@ -164,3 +164,26 @@ def test_linear_256x256_half_column_tile(hip, m, n, k, epi):
         _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
     finally:
         raw.eilev_debug_gemm_flags(0)
+
+
+def test_linear_operand_over_2gib(hip):
+    """An A operand beyond the 32-bit buffer-offset range of the LDS-DMA kernels (Q-Former k|v projection of a whole bench
+    step) is processed in row chunks: same result as the register-staged kernel, which addresses with 64-bit pointers."""
+    raw = C.CDLL(abi.HIP_LIB_PATH)
+    m, n, k = 800_000, 256, 1408  # 2.25 GB of A
+    torch.manual_seed(0)
+    a = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda").to(torch.bfloat16)
+    out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+    ref = torch.empty_like(out)
+    assert hip.eilev_linear(P(a), P(w), P(b), None, P(out), m, n, k, 0, 0, stream_ptr()) == 0
+    raw.eilev_debug_gemm_flags(4)
+    try:
+        assert hip.eilev_linear(P(a), P(w), P(b), None, P(ref), m, n, k, 0, 0, stream_ptr()) == 0
+    finally:
+        raw.eilev_debug_gemm_flags(0)
+    torch.cuda.synchronize()
+    for rows in (slice(0, 4096), slice(m // 2, m // 2 + 4096), slice(m - 4096, m)):
+        assert (out[rows].float() - ref[rows].float()).abs().max().item() <= 2e-2
+    assert torch.equal(out[::997], ref[::997]) or (out[::997].float() - ref[::997].float()).abs().max().item() <= 2e-2
