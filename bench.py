@@ -208,7 +208,7 @@ def main():
         dt = float(t.item())
 
     # dominant kernel: the ViT GEMM family, timed with hipEvents on the launch stream during the timed region
-    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [M x 6144 x 1408, M = 257 tokens x 544 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
+    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [M x 6144 x 1408, M = 257 tokens x 1088 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
              3: "gemm_nt ViT qkv (+bias) [M x 4224 x 1408]", 4: "gemm_nt ViT proj (+bias+residual) [M x 1408 x 1408]"}
     best = None
     tot_ms = 0.0
@@ -249,7 +249,7 @@ def main():
             try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
                 with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
                     tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
-                if tr:  # measured on the bench's launch shape (544 frames x 257 tokens per launch)
+                if tr:  # measured on the bench's launch shape (1088 frames x 257 tokens per launch)
                     traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
             except OSError:
                 pass

@@ -111,7 +111,7 @@ class HipEngine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- stages --------------------------------------------------------------------------------------
-    def vit(self, pixel_values: torch.Tensor, want_pooler: bool = False, max_frames_per_call: int = 544):
+    def vit(self, pixel_values: torch.Tensor, want_pooler: bool = False, max_frames_per_call: int = 1088):
         """(N, 3, T, H, W) fp32/bf16 -> (N, T*tokens, Dv) bf16 [ref:eilev/model/v2.py:24-103]."""
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
