@@ -897,7 +897,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         a.g = g;
         a.mr = g.M <= 16 ? 16 : 32;
         const int nb = (g.N + 15) / 16;
-        int ks = nb >= 512 ? 1 : (512 + nb - 1) / nb;
+        int ks = nb >= 384 ? 1 : (512 + nb - 1) / nb;  // >= 1.5 workgroups per CU: no split (and no reduce launch)
         const int ksteps = (g.K + 31) / 32;
         if (ks > ksteps / 32) ks = ksteps / 32 > 0 ? ksteps / 32 : 1;  // >= 8 K-steps of 32 per wave
         if (ks > 1 && (!g.scratch || (size_t)ks * a.mr * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
