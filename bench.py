@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lm", choices=["opt27", "t5xl"], default="opt27",
+                    help="opt27 = the headline configs[1]/[2]; t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), informational")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +150,8 @@ def main():
 
     from eilev_amd.engine import HipEngine
 
-    cfg = blip2_config("opt27")
+    cfg = blip2_config(args.lm)
+    is_t5 = args.lm == "t5xl"
     eng = HipEngine(cfg, random_weights(cfg, dev), device=dev)
     S = args.samples
     nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
@@ -172,7 +175,10 @@ def main():
         mine_f = allf[my_first_clip * nq:(my_first_clip + S * (N_CTX + 1)) * nq]  # clips of MY samples, global order
         emb = eng.embed_scatter(ids, vm, mine_f)
         stamp("encode_done")
-        out_ids = eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)  # stamps "prefill_done"
+        if is_t5:  # encoder-decoder LM: encoder + cross K/V take the place of the prefill
+            out_ids = eng.t5_greedy(emb, am, NEW_TOKENS, eos_id=-1, pad_id=0)[:, 1:]
+        else:
+            out_ids = eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)  # stamps "prefill_done"
         stamp("step_end")
         return out_ids
 
@@ -196,8 +202,13 @@ def main():
     phases = {"encode": 0.0, "prefill": 0.0, "decode": 0.0}
     marks = eng.timing
     eng.timing = None
-    for i in range(0, len(marks), 4):
-        (_, b0), (_, e1), (_, p1), (_, s1) = marks[i:i + 4]
+    per = 3 if is_t5 else 4
+    for i in range(0, len(marks), per):
+        if is_t5:
+            (_, b0), (_, e1), (_, s1) = marks[i:i + 3]
+            p1 = e1  # no separate prefill stamp: encoder + cross K/V + decode are reported together as "decode"
+        else:
+            (_, b0), (_, e1), (_, p1), (_, s1) = marks[i:i + 4]
         phases["encode"] += b0.elapsed_time(e1)
         phases["prefill"] += e1.elapsed_time(p1)
         phases["decode"] += p1.elapsed_time(s1)
@@ -227,15 +238,17 @@ def main():
         clips = world * S * (N_CTX + 1) * args.steps
         value = clips / dt
         res = {
-            "metric": "clips/sec (8-frame, 16 in-context) encode+generate, eilev-blip2-opt-2.7b",
+            "metric": "clips/sec (8-frame, 16 in-context) encode+generate, " + ("eilev-blip2-flan-t5-xl" if is_t5 else "eilev-blip2-opt-2.7b"),
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": (f"configs[1]: eilev-blip2-opt-2.7b (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
+            "config": {"workload": (f"configs[3]: eilev-blip2-flan-t5-xl (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
+                                    f"224x224, encoder L=960, 32 greedy decoder tokens (EOS off)") if is_t5 else
+                                   (f"configs[1]: eilev-blip2-opt-2.7b (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
                                     f"224x224, L=960 prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
                                     f"{'RCCL all-gather' if world > 1 else 'no collective at N=1'}"),
                        "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": 960, "new_tokens": NEW_TOKENS},
-            "whole_path_tflops": round(TFLOP_PER_SAMPLE * world * S * args.steps / dt, 1),
+            "whole_path_tflops": round((74.75 if is_t5 else TFLOP_PER_SAMPLE) * world * S * args.steps / dt, 1),
             "phases_rank0": {"encode_ms_per_step": round(phases["encode"] / args.steps, 2),
                              "encode_only_clips_per_s": round(S * (N_CTX + 1) * args.steps / (phases["encode"] * 1e-3), 1),
                              "prefill_ms_per_step": round(phases["prefill"] / args.steps, 2),
@@ -258,7 +271,7 @@ def main():
                                "launches": int(n), "avg_launch_ms": round(ms / n, 4),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_t5:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if world > 1:
