@@ -133,8 +133,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lm", choices=["opt27", "t5xl"], default="opt27",
-                    help="opt27 = the headline configs[1]/[2]; t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), informational")
+    ap.add_argument("--lm", choices=["opt27", "t5xl", "opt67"], default="opt27",
+                    help="opt27 = the headline configs[1]/[2]; informational: t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), "
+                         "opt67 = the OPT-6.7B backbone of configs[4] in bf16 (use --shots 32 for its 32-shot sequence)")
+    ap.add_argument("--shots", type=int, default=16, help="in-context examples per sample (16 = the headline workload)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,8 +152,11 @@ def main():
 
     from eilev_amd.engine import HipEngine
 
+    global N_CTX
+    N_CTX = args.shots
     cfg = blip2_config(args.lm)
     is_t5 = args.lm == "t5xl"
+    seq_len = 1 + (N_CTX + 1) * 33 + N_CTX * 24 + 14
     eng = HipEngine(cfg, random_weights(cfg, dev), device=dev)
     S = args.samples
     nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
@@ -238,17 +243,20 @@ def main():
         clips = world * S * (N_CTX + 1) * args.steps
         value = clips / dt
         res = {
-            "metric": "clips/sec (8-frame, 16 in-context) encode+generate, " + ("eilev-blip2-flan-t5-xl" if is_t5 else "eilev-blip2-opt-2.7b"),
+            "metric": f"clips/sec (8-frame, {N_CTX} in-context) encode+generate, " +
+                      {"t5xl": "eilev-blip2-flan-t5-xl", "opt27": "eilev-blip2-opt-2.7b", "opt67": "blip2-opt-6.7b backbone (bf16)"}[args.lm],
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"configs[3]: eilev-blip2-flan-t5-xl (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
                                     f"224x224, encoder L=960, 32 greedy decoder tokens (EOS off)") if is_t5 else
-                                   (f"configs[1]: eilev-blip2-opt-2.7b (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
-                                    f"224x224, L=960 prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
+                                   (f"{'configs[1]: eilev-blip2-opt-2.7b' if args.lm == 'opt27' else 'configs[4] backbone blip2-opt-6.7b in bf16'} (random-init), "
+                                    f"{S} samples/GPU/step x {N_CTX + 1} clips x 8 frames "
+                                    f"224x224, L={seq_len} prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
                                     f"{'RCCL all-gather' if world > 1 else 'no collective at N=1'}"),
-                       "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": 960, "new_tokens": NEW_TOKENS},
-            "whole_path_tflops": round((74.75 if is_t5 else TFLOP_PER_SAMPLE) * world * S * args.steps / dt, 1),
+                       "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": seq_len, "new_tokens": NEW_TOKENS},
+            "whole_path_tflops": (round((74.75 if is_t5 else TFLOP_PER_SAMPLE) * world * S * args.steps / dt, 1)
+                                  if N_CTX == 16 and args.lm != "opt67" else None),
             "phases_rank0": {"encode_ms_per_step": round(phases["encode"] / args.steps, 2),
                              "encode_only_clips_per_s": round(S * (N_CTX + 1) * args.steps / (phases["encode"] * 1e-3), 1),
                              "prefill_ms_per_step": round(phases["prefill"] / args.steps, 2),
@@ -271,7 +279,7 @@ def main():
                                "launches": int(n), "avg_launch_ms": round(ms / n, 4),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
-        if world == 1 and not args.no_cpu_baseline and not is_t5:
+        if world == 1 and not args.no_cpu_baseline and args.lm == "opt27" and N_CTX == 16:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if world > 1:
