@@ -240,7 +240,7 @@ EXPORTS = [
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
-    "eilev_t5_self_kv_bytes", "eilev_t5_decode",
+    "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step",
 ]
 
 
@@ -293,6 +293,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_t5_self_kv_bytes.argtypes = [TP, i64, i64]
     lib.eilev_t5_decode.restype = i32
     lib.eilev_t5_decode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.eilev_t5_decode_step.restype = i32
+    lib.eilev_t5_decode_step.argtypes = [TP, C.POINTER(T5Weights), vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_prof_enable.restype = i32
     lib.eilev_prof_enable.argtypes = [i32]
     lib.eilev_prof_collect.restype = i32

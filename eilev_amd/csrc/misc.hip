@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
         float acc = 0.0f;
         for (int cc = 0; cc < nch; ++cc) acc += red[tid * 17 + cc];
         const bool vis = j >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + j] != 0;
-        if (rel_tab) acc += rel_tab[(int64_t)h * rel_hs + (j - (kv_total - 1)) + rel_off];
+        if (rel_tab) acc += rel_tab[(int64_t)h * rel_hs + (rel_off >= 0 ? (j - (kv_total - 1)) + rel_off : j)];  // rel_off < 0: table of this query row
         s = vis ? acc : -1e30f;
     }
     float mxw = wave_max(s);
@@ -383,8 +383,15 @@ struct T5Buckets {
     int bidirectional, nb, max_exact, nthr;
     int thr[32];
 };
-__global__ void t5_rel_table_kernel(const bf16 *__restrict__ rel_w, float *__restrict__ tab, int n, int off, int heads, T5Buckets bk) {
+// state != null (decode step under a graph): the table of the single query at position state[0]: n = state[0] + 1 entries,
+// entry idx = bias of key idx (off = state[0]); `stride` is the row stride of the table.
+__global__ void t5_rel_table_kernel(const bf16 *__restrict__ rel_w, float *__restrict__ tab, int n, int off, int heads, T5Buckets bk,
+                                    const int32_t *__restrict__ state, int stride) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (state) {
+        off = state[0];
+        n = min(off + 1, stride);
+    }
     if (idx >= n) return;
     const int rel = idx - off;
     int ret = 0, rp;
@@ -399,7 +406,7 @@ __global__ void t5_rel_table_kernel(const bf16 *__restrict__ rel_w, float *__res
         b = bk.max_exact;
         for (int i = 0; i < bk.nthr; ++i) b += rp >= bk.thr[i];
     }
-    for (int h = 0; h < heads; ++h) tab[(int64_t)h * n + idx] = (float)rel_w[(int64_t)(ret + b) * heads + h];
+    for (int h = 0; h < heads; ++h) tab[(int64_t)h * stride + idx] = (float)rel_w[(int64_t)(ret + b) * heads + h];
 }
 // gated activation: out = bf16(bf16(gelu_new(a)) * b), gelu_new = tanh form (hf activations NewGELUActivation);
 // a = cols [0, F), b = cols [F, 2F) of rows of ld elements
@@ -424,7 +431,9 @@ __global__ __launch_bounds__(256) void gated_gelu_kernel(const bf16 *__restrict_
 }
 // rows (b, t) of a projection [M, ld] (columns col0 .. col0 + heads*hd) -> cache plane [B][H][cap][hd] at slots slot0 + t
 __global__ __launch_bounds__(256) void rows_to_cache_kernel(const bf16 *__restrict__ src, int64_t ld, int col0, bf16 *__restrict__ plane,
-                                                            int rows_per_b, int heads, int hd, int cap, int slot0) {
+                                                            int rows_per_b, int heads, int hd, int cap, int slot0,
+                                                            const int32_t *__restrict__ state) {
+    if (state) slot0 += state[0];
     const int64_t row = blockIdx.x;
     const int b = (int)(row / rows_per_b), t = (int)(row - (int64_t)b * rows_per_b);
     const int ch = hd >> 3;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void rows_to_cache_kernel(const bf16 *__restri
 }
 
 int launch_t5_rel_table(const bf16 *rel_w, float *tab, int n, int off, int heads, int bidirectional, int num_buckets, int max_dist,
-                        hipStream_t s) {
+                        hipStream_t s, const int32_t *state = nullptr) {
     T5Buckets bk;
     int nb = num_buckets;
     if (bidirectional) nb /= 2;
@@ -456,7 +465,7 @@ int launch_t5_rel_table(const bf16 *rel_w, float *tab, int n, int off, int heads
             ++prev;
         }
     }
-    hipLaunchKernelGGL(t5_rel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rel_w, tab, n, off, heads, bk);
+    hipLaunchKernelGGL(t5_rel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rel_w, tab, n, off, heads, bk, state, n);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
@@ -468,8 +477,9 @@ int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F
     return EILEV_OK;
 }
 int launch_rows_to_cache(const bf16 *src, int64_t ld, int col0, bf16 *plane, int batch, int rows_per_b, int heads, int hd, int cap,
-                         int slot0, hipStream_t s) {
-    hipLaunchKernelGGL(rows_to_cache_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, src, ld, col0, plane, rows_per_b, heads, hd, cap, slot0);
+                         int slot0, hipStream_t s, const int32_t *state = nullptr) {
+    hipLaunchKernelGGL(rows_to_cache_kernel, dim3(batch * rows_per_b), dim3(256), 0, s, src, ld, col0, plane, rows_per_b, heads, hd, cap, slot0,
+                       state);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -26,10 +26,10 @@ int launch_select(const float *logits, int batch, int vocab, int32_t *state, uin
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
 
 int launch_t5_rel_table(const bf16 *rel_w, float *tab, int n, int off, int heads, int bidirectional, int num_buckets, int max_dist,
-                        hipStream_t s);
+                        hipStream_t s, const int32_t *state = nullptr);
 int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F, hipStream_t s);
 int launch_rows_to_cache(const bf16 *src, int64_t ld, int col0, bf16 *plane, int batch, int rows_per_b, int heads, int hd, int cap,
-                         int slot0, hipStream_t s);
+                         int slot0, hipStream_t s, const int32_t *state = nullptr);
 
 #define RC(expr)                 \
     do {                         \
@@ -674,26 +674,32 @@ extern "C" int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, 
     return EILEV_OK;
 }
 
-extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
-                               int64_t batch, int64_t new_len, int64_t past_len, void *self_kv, int64_t kv_capacity,
-                               const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+// `state` != null: single-token step whose position is state[0] on the device (host past_len = 0, the buffers are sized
+// for the whole capacity); null: positions past_len .. past_len + new_len - 1 given by the host
+static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                          int64_t batch, int64_t new_len, int64_t past_len, const int32_t *state, void *self_kv, int64_t kv_capacity,
+                          const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
+                          void *stream) {
     if (!d || !w || !dec_ids || !enc_mask || !self_kv || !cross_kv || !logits || !workspace) return EILEV_E_BADARG;
     if (batch <= 0 || new_len <= 0 || past_len < 0 || past_len + new_len > kv_capacity || enc_len <= 0) return EILEV_E_BADARG;
+    if (state && (new_len != 1 || past_len != 0)) return EILEV_E_BADARG;
     if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int D = d->d_model, H = d->heads, hd = d->d_kv, I = H * hd;
-    const int64_t M = batch * new_len, total = past_len + new_len;
+    const int64_t M = batch * new_len, total = state ? kv_capacity : past_len + new_len;  // with `state`: an upper bound
     T5Bufs b;
     if (!carve_t5(d, M, total + 1, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
     RC(launch_embed_scatter((const bf16 *)w->shared, dec_ids, nullptr, nullptr, 0, M, d->vocab, b.h, D, s));
     // causal self-attention: key j of query at absolute position p: rel = j - p in [-(total-1), 0]: index rel + total - 1
-    RC(launch_t5_rel_table((const bf16 *)w->dec_rel_bias, b.rel, (int)total, (int)total - 1, H, 0, d->rel_buckets, d->rel_max_dist, s));
+    // (with `state` the table holds the single query row at position state[0]: entry j = bias of key j)
+    RC(launch_t5_rel_table((const bf16 *)w->dec_rel_bias, b.rel, (int)total, (int)total - 1, H, 0, d->rel_buckets, d->rel_max_dist, s,
+                           state));
     const size_t splane = (size_t)batch * H * kv_capacity * hd, cplane = (size_t)batch * H * enc_len * hd;
     // single-query steps use the split decode-attention kernel; its partials live in the second half of the skinny scratch
     const size_t skinny_f = kSkinnyScratch / 2 / sizeof(float);
     const int64_t kmax = kv_capacity > enc_len ? kv_capacity : enc_len;
     const bool single = new_len == 1 && attn_decode_scratch_bytes((int)batch, H, hd, (int)kmax) <= kSkinnyScratch / 2;
+    if (state && !single) return EILEV_E_UNSUPPORTED;
     for (int l = 0; l < d->dec_layers; ++l) {
         const EilevT5Layer *L = &w->dec_layers[l];
         bf16 *kc = (bf16 *)self_kv + 2 * (size_t)l * splane, *vc = kc + splane;
@@ -701,12 +707,16 @@ extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, co
         // ---- self-attention against the cache (T5LayerSelfAttention :372-401)
         RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
-        RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
-        RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s));
+        RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
+        RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
         if (single) {
             // one query row per sequence: flash-decoding split kernel (keys 0 .. total - 1 of the cache, bias of a single row)
-            RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd, b.scratch + skinny_f,
-                                  kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, (int)total - 1));
+            if (state)  // kv_total = 1 + state[0] on the device; the table is this query's row (entry j = key j)
+                RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, state, (int)batch, 1, (int)kv_capacity, H, hd, b.scratch + skinny_f,
+                                      kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, -1));
+            else
+                RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd,
+                                      b.scratch + skinny_f, kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, (int)total - 1));
         } else {
         AttnArgs a;
             a.q = b.qkv; a.k = kc; a.v = vc; a.o = b.att;
@@ -745,4 +755,20 @@ extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, co
     g.out_f32 = 1;
     if (d->scale_decoder_outputs) { g.scale = 1.0f / sqrtf((float)D); g.scale_cols = d->vocab; }
     return launch_gemm(g, 5, s);
+}
+
+extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                               int64_t batch, int64_t new_len, int64_t past_len, void *self_kv, int64_t kv_capacity,
+                               const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    return t5_decode_impl(d, w, dec_ids, enc_mask, batch, new_len, past_len, nullptr, self_kv, kv_capacity, cross_kv, enc_len, logits,
+                          workspace, workspace_bytes, stream);
+}
+
+extern "C" int eilev_t5_decode_step(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *tokens, const int32_t *state,
+                                    const int32_t *enc_mask, int64_t batch, void *self_kv, int64_t kv_capacity, const void *cross_kv,
+                                    int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!state) return EILEV_E_BADARG;
+    return t5_decode_impl(d, w, tokens, enc_mask, batch, 1, 0, state, self_kv, kv_capacity, cross_kv, enc_len, logits, workspace,
+                          workspace_bytes, stream);
 }

@@ -416,30 +416,61 @@ class HipEngine:
         skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T)), dtype=torch.uint8, device=self.device)
         return self.t5_decode(decoder_input_ids, attention_mask, 0, skv, T, ckv, enc.shape[1]), enc
 
-    def t5_greedy(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0):
+    def t5_greedy(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0, use_graph=True, poll_every=8):
         """Greedy generation for the encoder-decoder LM [ref:eilev/model/v2.py:318-322 -> hf _sample]: returns decoder ids
-        (B, 1 + n) INCLUDING the start token, like HF does for encoder-decoder models."""
+        (B, 1 + n) INCLUDING the start token, like HF does for encoder-decoder models.  One decoder step + token selection
+        (position and bookkeeping read from a device `state` word) is captured into a hipGraph and replayed."""
         d = self.t5dims
         enc = self.t5_encode(inputs_embeds, attention_mask)
         ckv = self.t5_cross_kv(enc)
         B, L, _ = enc.shape
-        cap = max_new_tokens + 1
+        if max_new_tokens <= 0:
+            return torch.full((B, 1), int(start_id), dtype=torch.int64, device=self.device)
+        cap = max_new_tokens
+        am = attention_mask.to(self.device, torch.int32).contiguous()
         skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, cap)), dtype=torch.uint8, device=self.device)
         state = torch.zeros(2, dtype=torch.int32, device=self.device)
         finished = torch.zeros(B, dtype=torch.uint8, device=self.device)
         tokens = torch.full((B,), int(start_id), dtype=torch.int64, device=self.device)
         out = torch.full((B, max_new_tokens), int(pad_id), dtype=torch.int64, device=self.device)
-        n = 0
-        for t in range(max_new_tokens):
-            logits = self.t5_decode(tokens.view(B, 1), attention_mask, t, skv, cap, ckv, L)
+        logits = torch.empty((B, d.vocab), dtype=torch.float32, device=self.device)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, 1, max(L, cap))
+        ws = self._workspace("t5dec", nb)
+
+        def one_step():
+            abi.check(self.lib.eilev_t5_decode_step(C.byref(d), C.byref(self.pack.t5), _ptr(tokens), _ptr(state), _ptr(am), B, _ptr(skv), cap,
+                                                    _ptr(ckv), L, _ptr(logits), _ptr(ws), ws.numel(), self._stream()), "eilev_t5_decode_step")
             abi.check(self.lib.eilev_greedy_select(_ptr(logits), B, d.vocab, _ptr(state), _ptr(finished), eos_id, pad_id, _ptr(tokens),
                                                    _ptr(out), max_new_tokens, self._stream()), "eilev_greedy_select")
-            n = t + 1
-            if eos_id >= 0 and int(state[1].item()) == 0:
-                break
-        start = torch.full((B, 1), int(start_id), dtype=torch.int64, device=self.device)
-        return torch.cat((start, out[:, :n]), dim=1)
 
+        graph = None
+        if use_graph and max_new_tokens > 1:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                snap = (state.clone(), finished.clone(), tokens.clone(), out.clone())
+                one_step()  # warm-up outside capture (lazy module loading); it only touched cache slot 0, rewritten below
+                state.copy_(snap[0]); finished.copy_(snap[1]); tokens.copy_(snap[2]); out.copy_(snap[3])
+                with torch.cuda.graph(graph, stream=side):
+                    one_step()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        n = 0
+        for t in range(max_new_tokens):
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
+            n = t + 1
+            if eos_id >= 0 and (n % poll_every == 0 or n == max_new_tokens) and int(state[1].item()) == 0:
+                break
+        ids = out[:, :n]
+        if eos_id >= 0:  # HF stops as soon as every row has emitted EOS: trim to that length
+            is_eos = ids == eos_id
+            first = torch.where(is_eos.any(dim=1), is_eos.float().argmax(dim=1) + 1, torch.full((B,), n, device=self.device))
+            ids = ids[:, : int(first.max().item())]
+        start = torch.full((B, 1), int(start_id), dtype=torch.int64, device=self.device)
+        return torch.cat((start, ids), dim=1)
 
     def t5_beam(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1, pad_id=0, start_id=0,
                 early_stopping=False, num_return_sequences=1):

@@ -221,6 +221,13 @@ int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t
                     const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
                     void *stream);
 
+/* One generation step of the decoder with the step counter on the DEVICE (so that a captured hipGraph replays for every
+ * step): position = state[0] = number of tokens fed so far; tokens (batch) int64 = the ids to feed (start token at step 0,
+ * then what eilev_greedy_select wrote); logits (batch, vocab) f32.  Same arithmetic as eilev_t5_decode(new_len = 1). */
+int eilev_t5_decode_step(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *tokens, const int32_t *state,
+                         const int32_t *enc_mask, int64_t batch, void *self_kv, int64_t kv_capacity, const void *cross_kv,
+                         int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stage 5: greedy decode ---------------------------------------------------------------
  * Replaces one iteration of GenerationMixin._sample with do_sample=False
  * (hf generation/utils.py:2876-2937): argmax of the fp32 last-row logits, pad-after-EOS,
