@@ -183,7 +183,8 @@ class HipEngine:
 
     def new_kv_cache(self, batch, capacity):
         nb = self.lib.eilev_opt_kv_cache_bytes(C.byref(self.dims), batch, capacity)
-        return torch.zeros(int(nb), dtype=torch.uint8, device=self.device)
+        # not zeroed (10 GB at batch 32): every slot is written (kv_write) before any kernel reads it
+        return torch.empty(int(nb), dtype=torch.uint8, device=self.device)
 
     def prefill(self, inputs_embeds, attention_mask, kv_cache=None, kv_capacity=None, all_logits=False, last_logits=True):
         d = self.dims
