@@ -37,6 +37,7 @@ class HipEngine:
         self._ws = {}
         self.timing = None  # bench.py sets this to a list to collect phase events
         self._decode_warm = False
+        self._dec_cache = None  # most recent captured decode step + the buffers it is bound to
         self.parts = tuple(parts)
         self._load(named_tensors)
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
@@ -260,23 +261,41 @@ class HipEngine:
         if B > 32:
             raise NotImplementedError("decode batch > 32 per call is not supported yet; split the batch")
         cap = L + max_new_tokens
-        am = attention_mask.to(self.device, torch.int32).contiguous()
-        last, _, kv = self.prefill(inputs_embeds, am, kv_capacity=cap)
+        n_dec = max_new_tokens - 1
+        graphable = use_graph and n_dec > 1 and not return_step_logits
+        # The captured decode step only depends on buffer ADDRESSES and on (B, L, cap, eos, pad): keep the most recent
+        # graph with its buffers (KV cache, state words, token / output buffers) and reuse it for calls of the same shape
+        key = (B, L, cap, max_new_tokens, int(eos_id), int(pad_id))
+        ent = self._dec_cache if (graphable and self._dec_cache is not None and self._dec_cache["key"] == key) else None
+        if ent is None:
+            ent = dict(key=key, graph=None,
+                       am=torch.empty((B, L), dtype=torch.int32, device=self.device),
+                       n_valid=torch.empty(B, dtype=torch.int32, device=self.device),
+                       kv=self.new_kv_cache(B, cap),
+                       state=torch.zeros(2, dtype=torch.int32, device=self.device),
+                       finished=torch.zeros(B, dtype=torch.uint8, device=self.device),
+                       tokens=torch.zeros(B, dtype=torch.int64, device=self.device),
+                       out=torch.empty((B, max_new_tokens), dtype=torch.int64, device=self.device),
+                       logits=torch.empty((B, d.vocab), dtype=torch.float32, device=self.device),
+                       ws=self._workspace("dec", self.lib.eilev_opt_workspace_bytes(C.byref(d), B, 1)))
+            if graphable:
+                self._dec_cache = None  # drop the previous entry (its KV cache) before keeping this one
+                self._dec_cache = ent
+        am, n_valid, kv = ent["am"], ent["n_valid"], ent["kv"]
+        state, finished, tokens, out, logits, ws = ent["state"], ent["finished"], ent["tokens"], ent["out"], ent["logits"], ent["ws"]
+        am.copy_(attention_mask.to(self.device, torch.int32))
+        n_valid.copy_(am.sum(dim=1))
+        state.zero_()
+        finished.zero_()
+        out.fill_(int(pad_id))
+        last, _, _ = self.prefill(inputs_embeds, am, kv_cache=kv, kv_capacity=cap)
         if self.timing is not None:  # optional phase stamps for bench.py (events on the launch stream, no sync)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.timing.append(("prefill_done", ev))
-        state = torch.zeros(2, dtype=torch.int32, device=self.device)
-        finished = torch.zeros(B, dtype=torch.uint8, device=self.device)
-        tokens = torch.zeros(B, dtype=torch.int64, device=self.device)
-        out = torch.full((B, max_new_tokens), int(pad_id), dtype=torch.int64, device=self.device)
-        n_valid = am.sum(dim=1).to(torch.int32).contiguous()
-        logits = torch.empty((B, d.vocab), dtype=torch.float32, device=self.device)
         step_logits = [last.clone()] if return_step_logits else None
         abi.check(self.lib.eilev_greedy_select(_ptr(last), B, d.vocab, _ptr(state), _ptr(finished), eos_id, pad_id,
                                                _ptr(tokens), _ptr(out), max_new_tokens, self._stream()), "eilev_greedy_select")
-        nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, 1)
-        ws = self._workspace("dec", nb)
 
         def one_step():
             abi.check(self.lib.eilev_opt_decode_step(
@@ -284,9 +303,8 @@ class HipEngine:
                 _ptr(logits), _ptr(finished), eos_id, pad_id, _ptr(out), max_new_tokens, _ptr(ws), ws.numel(),
                 self._stream()), "eilev_opt_decode_step")
 
-        n_dec = max_new_tokens - 1
-        graph = None
-        if use_graph and n_dec > 1 and not return_step_logits:
+        graph = ent["graph"] if graphable else None
+        if graphable and graph is None:
             # every per-step quantity is read from `state` on the device, so ONE captured step replays for all
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(self.device)
@@ -301,6 +319,7 @@ class HipEngine:
                 with torch.cuda.graph(graph, stream=side):
                     one_step()
             torch.cuda.current_stream(self.device).wait_stream(side)
+            ent["graph"] = graph
             # capture does not execute: nothing ran yet for step 1
         done_steps = 0
         while done_steps < n_dec:
@@ -323,6 +342,7 @@ class HipEngine:
             ids = ids[:, :n]
         else:
             ids = ids[:, : 1 + done_steps]
+        ids = ids.clone()  # `out` belongs to the cached graph entry
         return (ids, step_logits) if return_step_logits else ids
 
 
