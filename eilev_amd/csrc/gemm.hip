@@ -664,6 +664,163 @@ int launch_pp3(const GemmArgs &g, hipStream_t s) {
     return EILEV_OK;
 }
 
+// ---- persistent ping-pong kernel, DMA by whole 128-byte lines ------------------------------------------------
+// Same schedule as gemm_pp3_kernel (two groups of 4 waves alternate fragment reads and MFMAs per half K-step of 32), but
+// the LDS-DMA moves whole K-steps of 64: every buffer_load ... lds fetches 8 rows x 128 B — full cache lines — where the
+// half-step staging fetched 16 rows x 64 B.  Measured (tools/probes/lds_dma_rate.hip): the 64-byte pattern lands only
+// 56-64 B/ns per CU, which at 32 KiB per half-step is as long as the 16 MFMAs it should hide under; 128-byte rows land
+// 97-146 B/ns.  Two 64-KiB step buffers; step s + 1 is issued in the read phase of half 2s and waited for in the read
+// phase of half 2s + 1.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int STEP = (BM + BN) * 128;
+    constexpr int PC = 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / NWN, wn = wid % NWN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ns = g.K / 64;
+    const bool late = wid >= NW / 2;
+    const int prow = lane >> 3, pslot = lane & 7;
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
+    unsigned pa[PC], pb[PC];  // per-lane byte offsets of this wave's 1-KiB pieces (8 rows x 128 B, chunk-swizzled source)
+    auto set_tile = [&](int t, int &m0, int &n0) {
+        int tm_i, tn_i;
+        tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
+        m0 = tm_i * BM;
+        n0 = tn_i * BN;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int row = (wid * PC + i) * 8 + prow;
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
+            gr = n0 + row;
+            gr = gr < g.N ? gr : g.N - 1;
+            pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
+        }
+    };
+    auto stage_step = [&](int st) {
+        char *sa = smem + (st & 1) * STEP + (wid * PC) * 1024;
+        char *sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + i * 1024), 16, pa[i], st * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], st * 128, 0, 0);
+        }
+    };
+    f32x16 acc[TM][TN];
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read_half = [&](int st, int h) {
+        const char *sa = smem + (st & 1) * STEP + (wm * WM) * 128;
+        const char *sb = smem + (st & 1) * STEP + BM * 128 + (wn * WN) * 128;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kc = h * 4 + k2 * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 32 + l31;
+                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 32 + l31;
+                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+            }
+        }
+    };
+    auto mma_half = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER()                       \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    int t = blockIdx.x, m0, n0;
+    if (t >= ntiles) return;
+    set_tile(t, m0, n0);
+    stage_step(0);
+    for (; t < ntiles; t += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // step 0 of this tile was issued by the prologue above or by the previous tile's tail; the wait also covers the
+        // previous epilogue's stores, and the barrier its LDS staging reads (which overlay step buffer 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        if (late) PP_BARRIER();
+        const int nsd = (g.dbg & 2) ? 1 : ns;
+        for (int st = 0; st < nsd; ++st) {
+            read_half(st, 0);
+            if (st + 1 < ns) stage_step(st + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half();
+            PP_BARRIER();
+            read_half(st, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half();
+            PP_BARRIER();
+        }
+        if (!late) PP_BARRIER();
+        // every wave has finished reading both step buffers: start the next tile's first step (buffer 0), then store
+        // (the epilogue stages through buffer 1)
+        const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
+        if (tn < ntiles) {
+            set_tile(tn, m0, n0);
+            stage_step(0);
+        }
+        gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+        gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+    }
+#undef PP_BARRIER
+}
+
+int launch_pp4(const GemmArgs &g, hipStream_t s) {
+    static bool attr_set = false;
+    static int num_cu = 0;
+    constexpr int smem = 65536 + 8 * 64 * (64 * 2 + 8);  // step buffer 0 + epilogue staging (which overlays step buffer 1)
+    static_assert(smem >= 2 * 65536, "staging must cover step buffer 1");
+    if (!attr_set) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int dev = 0;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
+    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL(gemm_pp4_kernel<0>, dim3(grid), dim3(512), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 // ---- skinny GEMM (M <= 16): weight-streaming, one 16-row block of W per workgroup ----------------
 // grid = (ceil(N/16), KS).  Each of the 4 waves owns a contiguous slice of this workgroup's K range;
 // per K-step of 32 a lane loads 16 B of W (row n0 + lane%16, k-group lane/16) and 16 B of A (batch row
@@ -947,7 +1104,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (force >= 1 && force <= 4) cfg = force;
     if (cfg == 1 && !wide_tiles && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
-        rc = launch_pp3(g, s);  // persistent half-K-step ping-pong kernel
+        rc = (g.K % 64 == 0 && !(g.dbg & 131072)) ? launch_pp4(g, s) : launch_pp3(g, s);  // persistent ping-pong kernels
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
     else if (cfg == 2) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
