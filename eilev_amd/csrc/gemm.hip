@@ -40,7 +40,10 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
         tn = t % tiles_n;
         return;
     }
-    constexpr int GROUP_M = 8;
+    // rows per group: 8 x 4 tiles per XCD round; narrow N with a long K (fc2: 5.5 column tiles, K = 6144) shares better with 4 rows
+    // (measured on fc2: 2 / 4 / 8 / 16 rows = 1122 / 1132 / 1093 / 1045 TFLOP/s; wide N: 8 and 16 equal, 4 and 32 worse)
+    const int gsel = (g.dbg >> 22) & 3;  // probe override: 1 -> 4 rows, 2 -> 8 rows, 3 -> 16 rows
+    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 8 : gsel == 3 ? 16 : (tiles_n <= 8 && g.K >= 4096 ? 4 : 8);
     const int width = GROUP_M * tiles_n, group = t / width, first = group * GROUP_M;
     const int gsz = min(tiles_m - first, GROUP_M), in = t - group * width;
     tm = first + in % gsz;
@@ -701,19 +704,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             const int row = (wid * PC + i) * 8 + prow;
             int gr = m0 + row;
             gr = gr < g.M ? gr : g.M - 1;
+            if (g.dbg & 2097152) gr &= 1023;  // probe: A footprint of 1024 rows (L2-resident, still 8 distinct lines per piece)
             pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
             gr = n0 + row;
             gr = gr < g.N ? gr : g.N - 1;
             pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
         }
     };
-    auto stage_step = [&](int st) {
+    auto stage_step = [&](int st, bool w_too = true) {
         char *sa = smem + (st & 1) * STEP + (wid * PC) * 1024;
         char *sb = sa + BM * 128;
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + i * 1024), 16, pa[i], st * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], st * 128, 0, 0);
+            if (w_too) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], st * 128, 0, 0);
         }
     };
     f32x16 acc[TM][TN];
@@ -747,6 +751,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
+    // Half-empty last column tile (N % 256 <= 128, e.g. N = 1408 = 5.5 x 256): only columns [0, 128) of the tile exist.
+    // The 8 waves re-split the valid 256 x 128 region as 4 x 2 blocks of 64 x 64 (half the fragment reads and MFMAs per
+    // wave, same ping-pong schedule); waves 4..7 own W rows 128..255 of the tile and skip their W pieces.
+    const int hm = wm * 2 + (wn >> 1), hn = wn & 1;
+    auto read_half_ht = [&](int st, int h) {
+        const char *sa = smem + (st & 1) * STEP + (hm * 64) * 128;
+        const char *sb = smem + (st & 1) * STEP + BM * 128 + (hn * 64) * 128;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kc = h * 4 + k2 * 2 + hi;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = j * 32 + l31;
+                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = i * 32 + l31;
+                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+            }
+        }
+    };
+    auto mma_half_ht = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
 #define PP_BARRIER()                       \
     do {                                   \
         __builtin_amdgcn_sched_barrier(0); \
@@ -757,7 +794,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     int t = blockIdx.x, m0, n0;
     if (t >= ntiles) return;
     set_tile(t, m0, n0);
-    stage_step(0);
+    stage_step(0, !(n0 + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2);
     for (; t < ntiles; t += gridDim.x) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -771,18 +808,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         PP_BARRIER();
         if (late) PP_BARRIER();
         const int nsd = (g.dbg & 2) ? 1 : ns;
-        for (int st = 0; st < nsd; ++st) {
-            read_half(st, 0);
-            if (st + 1 < ns) stage_step(st + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            mma_half();
-            PP_BARRIER();
-            read_half(st, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            mma_half();
-            PP_BARRIER();
+        const bool half_tile = n0 + 128 >= g.N && !(g.dbg & 524288);
+        if (half_tile) {
+            const bool w_mine = wid < NW / 2;
+            for (int st = 0; st < nsd; ++st) {
+                read_half_ht(st, 0);
+                if (st + 1 < ns) stage_step(st + 1, w_mine);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PP_BARRIER();
+                mma_half_ht();
+                PP_BARRIER();
+                read_half_ht(st, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                PP_BARRIER();
+                mma_half_ht();
+                PP_BARRIER();
+            }
+        } else {
+            for (int st = 0; st < nsd; ++st) {
+                read_half(st, 0);
+                if (st + 1 < ns) stage_step(st + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PP_BARRIER();
+                mma_half();
+                PP_BARRIER();
+                read_half(st, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                PP_BARRIER();
+                mma_half();
+                PP_BARRIER();
+            }
         }
         if (!late) PP_BARRIER();
         // every wave has finished reading both step buffers: start the next tile's first step (buffer 0), then store
@@ -790,10 +845,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
         if (tn < ntiles) {
             set_tile(tn, m0, n0);
-            stage_step(0);
+            stage_step(0, !(n0 + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2);
         }
-        gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
-        gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+        if (half_tile) {
+            gemm_epilogue<64, 64, EPI>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
+        } else {
+            gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+        }
     }
 #undef PP_BARRIER
 }
@@ -1102,7 +1161,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
     else if (force >= 1 && force <= 4) cfg = force;
-    if (cfg == 1 && !wide_tiles && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
+    if (cfg == 1 && (!wide_tiles || (g.dbg & 1048576)) && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = (g.K % 64 == 0 && !(g.dbg & 131072)) ? launch_pp4(g, s) : launch_pp3(g, s);  // persistent ping-pong kernels
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
