@@ -14,7 +14,6 @@
 // Skinny kernel (M <= 16, the decode step): one MFMA row-block of 16 weight rows per workgroup, the K
 // range split over the 8 waves (and over gridDim.y when N is small) — HBM-bound weight streaming.
 #include "common.h"
-#include <type_traits>
 
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
@@ -507,174 +506,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     gemm_epilogue<WM, WN, EPI>(g, acc, smem, m0, n0, wm, wn, wid, lane);
 }
 
-// XOR swizzle of a 64-byte (32-element) K slice: 4 chunks per row
-__device__ __forceinline__ int swz32(int row, int c) { return (c ^ ((row >> 2) & 3)) << 4; }
-
-// ---- persistent form of the half-K-step ping-pong kernel --------------------------------------------------
-// One workgroup per CU walks tiles t = blockIdx.x, + gridDim.x, ...  What the per-tile launch form pays once
-// per tile — workgroup dispatch, the cold first DMA (~2 us of exposed latency), the store-bound tail of the
-// epilogue — is overlapped here: the first two halves of the NEXT tile are DMA'd into half-buffers 0/1 as soon
-// as the K loop ends, while the epilogue runs out of the other half of LDS (two passes of 64 rows per wave:
-// 69.6 KB at offset 64 KB), and the epilogue's global stores drain under the next tile's first K-steps.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp3_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
-    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
-    constexpr int HALF = (BM + BN) * 64;
-    constexpr int PC = 2;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / NWN, wn = wid % NWN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nh = g.K / 32;
-    const bool late = wid >= NW / 2;
-    const int prow = lane >> 2, pslot = lane & 3;
-
-    // LDS-DMA through buffer descriptors: one s_mov m0 + one buffer_load ... lds per 1-KiB piece, the K advance is
-    // a scalar offset — no per-piece 64-bit VALU address arithmetic (global_load_lds costs ~100+ issue cycles each)
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
-    unsigned pa[PC], pb[PC];  // per-lane byte offsets of this wave's pieces (row * ld * 2 + swizzled chunk * 16)
-    auto set_tile = [&](int t, int &m0, int &n0) {
-        int tm_i, tn_i;
-        tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
-        m0 = tm_i * BM;
-        n0 = tn_i * BN;
-#pragma unroll
-        for (int i = 0; i < PC; ++i) {
-            const int row = (wid * PC + i) * 16 + prow;
-            int gr = m0 + row;
-            gr = gr < g.M ? gr : g.M - 1;
-            pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
-            gr = n0 + row;
-            gr = gr < g.N ? gr : g.N - 1;
-            pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 2) & 3)) << 4);
-        }
-    };
-    auto stage_half = [&](int n) {
-        char *sa = smem + (n & 3) * HALF + (wid * PC) * 1024;
-        char *sb = sa + BM * 64;
-#pragma unroll
-        for (int i = 0; i < PC; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + i * 1024), 16, pa[i], n * 64, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], n * 64, 0, 0);
-        }
-    };
-    f32x16 acc[TM][TN];
-    bf16x8 af[2][TM], bfr[2][TN];
-    auto read_half = [&](int n) {
-        const char *sa = smem + (n & 3) * HALF + (wm * WM) * 64;
-        const char *sb = smem + (n & 3) * HALF + BM * 64 + (wn * WN) * 64;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int kc = k2 * 2 + hi;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = j * 32 + l31;
-                bfr[k2][j] = *reinterpret_cast<const bf16x8 *>(sb + row * 64 + swz32(row, kc));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = i * 32 + l31;
-                af[k2][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 64 + swz32(row, kc));
-            }
-        }
-    };
-    auto mma_half = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define PP_BARRIER()                       \
-    do {                                   \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-
-    int t = blockIdx.x, m0, n0;
-    if (t >= ntiles) return;
-    set_tile(t, m0, n0);
-    stage_half(0);
-    stage_half(1);
-    for (; t < ntiles; t += gridDim.x) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        // H_0 / H_1 of this tile were issued by the prologue above or by the previous tile's tail; the wait also
-        // covers the previous epilogue's stores, and the barrier its LDS staging reads
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        if (late) PP_BARRIER();
-        const int nhd = (g.dbg & 2) ? 2 : nh;
-        for (int n = 0; n < nhd; ++n) {
-            if (!(g.dbg & 16384) || n == 0) read_half(n);
-            if (n + 2 < nh) {
-                if (!(g.dbg & 32768)) stage_half(n + 2);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            }
-            PP_BARRIER();
-            mma_half();
-            PP_BARRIER();
-        }
-        if (!late) PP_BARRIER();
-        // every wave has finished reading every half-buffer: start the next tile's first two halves, then store
-        const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
-        if (tn < ntiles) {
-            set_tile(tn, m0, n0);
-            stage_half(0);
-            stage_half(1);
-        }
-        gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + 2 * HALF, cm0, cn0, wm, wn, wid, lane);
-        gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + 2 * HALF, cm0, cn0, wm, wn, wid, lane);
-    }
-#undef PP_BARRIER
-}
-
-int launch_pp3(const GemmArgs &g, hipStream_t s) {
-    static bool attr_set = false;
-    static int num_cu = 0;
-    constexpr int smem = 2 * 32768 + 8 * 64 * (64 * 2 + 8);  // half-buffers 0/1 + epilogue staging (which overlays 2/3)
-    static_assert(smem >= 4 * 32768, "staging must cover half-buffers 2 and 3");
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        int dev = 0;
-        EILEV_HIP_CHECK(hipGetDevice(&dev));
-        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    if (g.epi == 1) hipLaunchKernelGGL(gemm_pp3_kernel<1>, dim3(grid), dim3(512), smem, s, g);
-    else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp3_kernel<2>, dim3(grid), dim3(512), smem, s, g);
-    else hipLaunchKernelGGL(gemm_pp3_kernel<0>, dim3(grid), dim3(512), smem, s, g);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-
-// ---- persistent ping-pong kernel, DMA by whole 128-byte lines ------------------------------------------------
-// Same schedule as gemm_pp3_kernel (two groups of 4 waves alternate fragment reads and MFMAs per half K-step of 32), but
-// the LDS-DMA moves whole K-steps of 64: every buffer_load ... lds fetches 8 rows x 128 B — full cache lines — where the
-// half-step staging fetched 16 rows x 64 B.  Measured (tools/probes/lds_dma_rate.hip): the 64-byte pattern lands only
-// 56-64 B/ns per CU, which at 32 KiB per half-step is as long as the 16 MFMAs it should hide under; 128-byte rows land
-// 97-146 B/ns.  Two 64-KiB step buffers; step s + 1 is issued in the read phase of half 2s and waited for in the read
-// phase of half 2s + 1.
+// ---- persistent ping-pong kernel ------------------------------------------------------------------------------
+// One 512-thread workgroup per CU walks 256 x 256 tiles t = blockIdx.x, + gridDim.x, ... in the grouped XCD-aware order.
+// The 8 waves are two groups of 4 that alternate per HALF K-step (K = 32): while one group issues its 12 fragment reads
+// (and, every other half, its 8 LDS-DMA pieces) the other runs its 16 MFMAs at raised priority; raw s_barriers hand the
+// MFMA pipe over.  What a per-tile launch pays once per tile — workgroup dispatch, the cold first DMA, the store tail of the
+// epilogue — is overlapped: the first K-step of the NEXT tile is DMA'd into buffer 0 as soon as the K loop ends, while the
+// epilogue stages through buffer 1, and the epilogue's stores drain under the next tile's first K-steps.
+// The LDS-DMA moves whole K-steps of 64: every buffer_load ... lds fetches 8 rows x 128 B — full cache lines.  (Staging
+// half K-steps as 16 rows x 64 B lands only 56-64 B/ns per CU, as long as the 16 MFMAs it should hide under; 128-byte rows
+// land 97-146 B/ns: tools/probes/lds_dma_rate.hip.)  Two 64-KiB step buffers; step s + 1 is issued in the read phase of
+// half 2s and waited for in the read phase of half 2s + 1.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
@@ -705,7 +547,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             const int row = (wid * PC + i) * 8 + prow;
             int gr = m0 + row;
             gr = gr < g.M ? gr : g.M - 1;
-            if (g.dbg & 2097152) gr &= 1023;  // probe: A footprint of 1024 rows (L2-resident, still 8 distinct lines per piece)
             pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
             gr = n0 + row;
             gr = gr < g.N ? gr : g.N - 1;
@@ -877,185 +718,6 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
     if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);
     else hipLaunchKernelGGL(gemm_pp4_kernel<0>, dim3(grid), dim3(512), smem, s, g);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-
-// ---- one wave per SIMD: software-pipelined persistent kernel (256x128 tile, 4 waves of 128x64) ------------------
-// 3 LDS stages of one K-step of 64 (48 KiB each).  Everything a wave needs for sub-step k + 1 (6 fragment reads) and its
-// share of the LDS-DMA two K-steps ahead are slotted between the 8 MFMAs of sub-step k — one instruction stream, no
-// partner wave — and ONE workgroup barrier per K-step (X_s, between sub-steps 2 and 3 of step s) both publishes step s + 1
-// and frees the buffer of step s for DMA(s + 3).
-__device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t r, char *dst, unsigned voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 16, voff, soff, 0, 0);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 128, WM = 128, WN = 64, TM = 4, TN = 2, NF = TM + TN;
-    constexpr int STEP = (BM + BN) * 128, NST = 3;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int ns = g.K / 64;
-
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
-    unsigned pv[12];  // per-lane source offsets of this wave's 1-KiB pieces: 8 of A (8 rows x 128 B each), 4 of W
-    auto set_tile = [&](int t, int &m0, int &n0) {
-        int tm_i, tn_i;
-        tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
-        m0 = tm_i * BM;
-        n0 = tn_i * BN;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (wid * 8 + i) * 8 + (lane >> 3);
-            int gr = m0 + row;
-            gr = gr < g.M ? gr : g.M - 1;
-            pv[i] = (unsigned)gr * (unsigned)(g.lda * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wid * 4 + i) * 8 + (lane >> 3);
-            int gr = n0 + row;
-            gr = gr < g.N ? gr : g.N - 1;
-            pv[8 + i] = (unsigned)gr * (unsigned)(g.ldw * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        }
-    };
-    // piece idx (compile-time after unrolling) of K-step st into the stage buffer at byte offset soff
-    auto piece = [&](int idx, int st, int soff) {
-        if (idx < 8) w4_dma(ra, smem + soff + (wid * 8 + idx) * 1024, pv[idx], st * 128);
-        else w4_dma(rw, smem + soff + BM * 128 + (wid * 4 + idx - 8) * 1024, pv[idx], st * 128);
-    };
-    f32x16 acc[TM][TN];
-    bf16x8 f[2][NF];  // fragment sets: [.][0..3] activation rows (i), [.][4..5] weight rows (j)
-    const int xo = (l31 >> 1) & 7;
-    const int a_lane = (wm * WM + l31) * 128, b_lane = BM * 128 + (wn * WN + l31) * 128;
-    // one sub-step: 8 MFMAs out of fragment set MSET; between them the 6 reads of sub-step RSUB (stage offset rs) into
-    // the other set and NDMA pieces (first index DFIRST) of K-step dst_st into stage offset ds
-    auto phase = [&](auto mset_c, auto rsub_c, auto dfirst_c, auto ndma_c, auto mma_c, auto rd_c, auto dma_c, int rs, int dst_st, int ds) {
-        constexpr int MSET = decltype(mset_c)::value, RSUB = decltype(rsub_c)::value, DFIRST = decltype(dfirst_c)::value,
-                      NDMA = decltype(ndma_c)::value;
-        constexpr bool MMA = decltype(mma_c)::value, RD = decltype(rd_c)::value, DMA = decltype(dma_c)::value;
-        constexpr int RSET = MSET ^ 1;
-        // read order = consumption order of the MFMAs below (i-major): B0 A0 B1 A1 A2 A3 — every read has 8 MFMAs to land
-        constexpr int RORD[NF] = {TM + 0, 0, TM + 1, 1, 2, 3};
-        const int co = ((RSUB * 2 + hi) ^ xo) << 4;
-        const char *pa_ = smem + rs + a_lane + co, *pb_ = smem + rs + b_lane + co;
-#pragma unroll
-        for (int q = 0; q < TM * TN; ++q) {
-            const int i = q / TN, j = q % TN;
-            if (MMA) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[MSET][TM + j], f[MSET][i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (RD && q < NF) {
-                const int fi = RORD[q];
-                f[RSET][fi] = *reinterpret_cast<const bf16x8 *>((fi < TM ? pa_ + fi * 4096 : pb_ + (fi - TM) * 4096));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (DMA && q >= TM * TN - NDMA) {
-                piece(DFIRST + q - (TM * TN - NDMA), dst_st, ds);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    using I6 = std::integral_constant<int, 6>;
-    using I9 = std::integral_constant<int, 9>;
-    using T = std::true_type;
-    using F = std::false_type;
-#define W4_BARRIER()                       \
-    do {                                   \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-
-    int t = blockIdx.x, m0, n0;
-    if (t >= ntiles) return;
-    set_tile(t, m0, n0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) piece(i, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) piece(i, 1, STEP);
-    for (; t < ntiles; t += gridDim.x) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        // steps 0 and 1 of this tile were issued by the prologue above / the previous tile's tail (before its epilogue,
-        // which staged through buffer 2): wait for them and for the epilogue's stores, then everyone may overwrite buffer 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W4_BARRIER();
-        if (2 < ns) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) piece(i, 2, 2 * STEP);
-        }
-        phase(I1{}, I0{}, I0{}, I0{}, F{}, T{}, F{}, 0, 0, 0);  // fragments of (step 0, sub-step 0) -> set 0
-        int so = 0;  // stage offset of step st
-        // one K-step; D2: step st + 2 exists (its pieces 3..11 are issued here), D3: step st + 3 exists (pieces 0..2), N1: step st + 1 exists
-        auto kstep = [&](int st, auto d2_c, auto d3_c, auto n1_c) {
-            constexpr bool D2 = decltype(d2_c)::value;
-            const int so1 = so + STEP >= NST * STEP ? so + STEP - NST * STEP : so + STEP;     // stage of step st + 1
-            const int so2 = so1 + STEP >= NST * STEP ? so1 + STEP - NST * STEP : so1 + STEP;  // stage of step st + 2 (= st - 1)
-            phase(I0{}, I1{}, I3{}, I3{}, T{}, T{}, d2_c, so, st + 2, so2);
-            phase(I1{}, I2{}, I6{}, I3{}, T{}, T{}, d2_c, so, st + 2, so2);
-            phase(I0{}, I3{}, I9{}, I3{}, T{}, T{}, d2_c, so, st + 2, so2);
-            // X_st: my pieces of step st + 1 have landed (the 12 of step st + 2 may still fly); every wave has read all of step st
-            if (D2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            W4_BARRIER();
-            phase(I1{}, I0{}, I0{}, I3{}, T{}, n1_c, d3_c, so1, st + 3, so);
-            so = so1;
-        };
-        int st = 0;
-        for (; st < ns - 3; ++st) kstep(st, T{}, T{}, T{});
-        kstep(st++, T{}, F{}, T{});
-        kstep(st++, F{}, F{}, T{});
-        kstep(st++, F{}, F{}, F{});
-        W4_BARRIER();  // every wave is done with every stage buffer
-        const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
-        if (tn < ntiles) {
-            set_tile(tn, m0, n0);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) piece(i, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) piece(i, 1, STEP);
-        }
-        gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + 2 * STEP, cm0, cn0, wm, wn, wid, lane);
-        gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + 2 * STEP, cm0, cn0, wm, wn, wid, lane);
-    }
-#undef W4_BARRIER
-}
-
-int launch_w4(const GemmArgs &g, hipStream_t s) {
-    static bool attr_set = false;
-    static int num_cu = 0;
-    constexpr int smem = 3 * 49152;
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_w4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_w4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_w4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        int dev = 0;
-        EILEV_HIP_CHECK(hipGetDevice(&dev));
-        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    if (g.epi == 1) hipLaunchKernelGGL(gemm_w4_kernel<1>, dim3(grid), dim3(256), smem, s, g);
-    else if (g.epi == 2) hipLaunchKernelGGL(gemm_w4_kernel<2>, dim3(grid), dim3(256), smem, s, g);
-    else hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3(grid), dim3(256), smem, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
@@ -1341,11 +1003,9 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
     else if (force >= 1 && force <= 4) cfg = force;
-    if (force == 10 && g.K % 64 == 0 && g.K >= 192 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
-        rc = launch_w4(g, s);  // probe: one-wave-per-SIMD pipelined kernel
-    else if (cfg == 1 && (!wide_tiles || (g.dbg & 1048576)) && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
+    if (cfg == 1 && (!wide_tiles || (g.dbg & 1048576)) && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
-        rc = (g.K % 64 == 0 && !(g.dbg & 131072)) ? launch_pp4(g, s) : launch_pp3(g, s);  // persistent ping-pong kernels
+        rc = launch_pp4(g, s);  // persistent ping-pong kernel
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
     else if (cfg == 2) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
