@@ -941,6 +941,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     g.dbg = g_gemm_debug;
     if (g.dbg & 4096) g.lda = 0;   // probe: every A row aliases row 0 (cache-resident operand)
     if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
+    if (g.dbg & 131072) g.ldc = 0;  // probe: every output row aliases row 0 (stores stay in L2)
     if (g.M <= 0) return EILEV_OK;
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;

@@ -6,7 +6,8 @@
 flags (eilev_debug_gemm_flags): 4 register-staged reference kernel; 8 old skinny kernel; (n << 4) force tile config n
 (1: 256x256, 2: 256x128 two stages, 3: 256x128 one stage x 2 workgroups/CU, 4: 128x128, 9: persistent ping-pong kernel);
 1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0 (cache-resident operand);
-16384 / 32768 drop the fragment reads / the LDS-DMA of the persistent kernel's K loop (results are wrong: timing only).
+131072 alias all output rows onto row 0; 524288 no half-tile path; 1048576 persistent kernel also for N = 1408;
+(n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
 """
 import ctypes as C
 import os
