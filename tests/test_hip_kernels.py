@@ -54,6 +54,17 @@ def test_linear_tiled(hip, m, n, k, epi):
     _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
 
 
+@pytest.mark.parametrize("m,n,k,epi,bias", [
+    (8229, 2048, 320, 0, True),     # one-wave-per-SIMD persistent kernel (bias-only wide N): M tail of 37 rows, short K
+    (8229, 2304, 1408, 0, False),   # N a multiple of 128 but not of 256, no bias
+    (16500, 4224, 256, 0, True),    # minimum K (4 K-steps), ViT qkv width
+    (8229, 2048, 1408, 1, True),    # same shapes through the ping-pong kernel (GELU) ...
+    (8229, 2560, 2560, 2, True),    # ... and ReLU
+])
+def test_linear_persistent_kernels(hip, m, n, k, epi, bias):
+    _lin_case(hip, m, n, k, epi, bias=bias, resid=False)
+
+
 @pytest.mark.parametrize("m,n,k", [(1, 160, 160), (8, 2560, 2560), (8, 7680, 2560), (3, 320, 160), (16, 1000, 10240), (8, 50272, 2560),
                                    (32, 2560, 2560), (17, 7680, 2560), (25, 2560, 10240), (20, 320, 160)])
 def test_linear_skinny(hip, m, n, k):
