@@ -240,7 +240,7 @@ EXPORTS = [
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
-    "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step",
+    "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
 ]
 
 
@@ -259,6 +259,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_qformer_forward.argtypes = [DP, C.POINTER(QfWeights), vp, i64, i64, vp, vp, sz, vp]
     lib.eilev_project_rows.restype = i32
     lib.eilev_project_rows.argtypes = [DP, vp, vp, vp, i64, vp, vp]
+    lib.eilev_process_workspace_bytes.restype = sz
+    lib.eilev_process_workspace_bytes.argtypes = [i64, i64, i64, i64]
+    lib.eilev_process_frames.restype = i32
+    lib.eilev_process_frames.argtypes = [vp, i64, i64, i64, i64, i64, i64, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, sz, vp]
     lib.eilev_embed_scatter.restype = i32
     lib.eilev_embed_scatter.argtypes = [DP, vp, vp, vp, vp, i64, i64, i64, vp, vp]
     lib.eilev_opt_workspace_bytes.restype = sz

@@ -562,3 +562,90 @@ int launch_select(const float *logits, int batch, int vocab, int32_t *state, uin
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+
+// ---- stage 0: frames -> pixel_values (include/eilev.h: eilev_process_frames) --------------------------------------------
+// Pillow's 8-bit two-pass resample, bit-exact: per output byte the 22-bit fixed-point taps of its row of the coefficient
+// table, 1 << 21 rounding, arithmetic shift, clip to 0..255; then the byte indexes the 3 x 256 normalisation table.
+// HBM-bound byte work: one thread per output byte, adjacent threads read adjacent (horizontal pass: overlapping) bytes.
+namespace {
+constexpr int kResampleBits = 32 - 8 - 2;
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= kResampleBits;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ void resample_h_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ coef,
+                                  const int32_t *__restrict__ bounds, int ksize, int64_t rows, int w_in, int w_out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * w_out) return;
+    const int64_t row = idx / w_out;
+    const int xx = (int)(idx - row * w_out);
+    const int xmin = bounds[xx * 2], n = bounds[xx * 2 + 1];
+    const int32_t *k = coef + (int64_t)xx * ksize;
+    const uint8_t *s = src + row * w_in + xmin;
+    int ss = 1 << (kResampleBits - 1);
+    for (int x = 0; x < n; ++x) ss += (int)s[x] * k[x];
+    dst[idx] = (uint8_t)clip8(ss);
+}
+
+template <typename OutT>
+__global__ void resample_v_lut_kernel(const uint8_t *__restrict__ src, OutT *__restrict__ dst, const int32_t *__restrict__ coef,
+                                      const int32_t *__restrict__ bounds, int ksize, const float *__restrict__ lut, int64_t planes,
+                                      int frames, int h_in, int h_out, int w) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= planes * h_out * w) return;
+    const int x = (int)(idx % w);
+    const int64_t py = idx / w;
+    const int yy = (int)(py % h_out);
+    const int64_t p = py / h_out;
+    int v;
+    if (coef) {
+        const int ymin = bounds[yy * 2], n = bounds[yy * 2 + 1];
+        const int32_t *k = coef + (int64_t)yy * ksize;
+        const uint8_t *s = src + (p * h_in + ymin) * w + x;
+        int ss = 1 << (kResampleBits - 1);
+        for (int y = 0; y < n; ++y) ss += (int)s[(int64_t)y * w] * k[y];
+        v = clip8(ss);
+    } else {
+        v = src[(p * h_in + yy) * w + x];
+    }
+    dst[idx] = (OutT)lut[((p / frames) % 3) * 256 + v];
+}
+}  // namespace
+
+extern "C" size_t eilev_process_workspace_bytes(int64_t batch, int64_t frames, int64_t h_in, int64_t w_out) {
+    return (size_t)(batch * 3 * frames * h_in * w_out);
+}
+
+extern "C" int eilev_process_frames(const uint8_t *video, int64_t batch, int64_t frames, int64_t h_in, int64_t w_in, int64_t h_out,
+                                    int64_t w_out, const int32_t *coef_h, const int32_t *bounds_h, int32_t ksize_h,
+                                    const int32_t *coef_v, const int32_t *bounds_v, int32_t ksize_v, const float *lut, void *out,
+                                    int32_t out_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!video || !lut || !out || batch < 0 || frames < 0 || h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0) return EILEV_E_BADARG;
+    if ((!coef_h) != (!bounds_h) || (!coef_v) != (!bounds_v)) return EILEV_E_BADARG;
+    if ((!coef_h && w_in != w_out) || (!coef_v && h_in != h_out)) return EILEV_E_BADARG;
+    if (out_dtype != 0 && out_dtype != 1) return EILEV_E_UNSUPPORTED;
+    if (frames > 0x7fffffff || h_in > 0x7fffffff || w_in > 0x7fffffff || h_out > 0x7fffffff || w_out > 0x7fffffff) return EILEV_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t planes = batch * 3 * frames;
+    if (planes == 0) return EILEV_OK;
+    const uint8_t *mid = video;
+    if (coef_h) {
+        if (!workspace || workspace_bytes < eilev_process_workspace_bytes(batch, frames, h_in, w_out)) return EILEV_E_WORKSPACE;
+        const int64_t rows = planes * h_in, total = rows * w_out;
+        hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, (uint8_t *)workspace, coef_h,
+                           bounds_h, ksize_h, rows, (int)w_in, (int)w_out);
+        EILEV_LAUNCH_CHECK();
+        mid = (const uint8_t *)workspace;
+    }
+    const int64_t total = planes * h_out * w_out;
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(resample_v_lut_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid, (float *)out, coef_v,
+                           bounds_v, ksize_v, lut, planes, (int)frames, (int)h_in, (int)h_out, (int)w_out);
+    else
+        hipLaunchKernelGGL(resample_v_lut_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid, (bf16 *)out, coef_v,
+                           bounds_v, ksize_v, lut, planes, (int)frames, (int)h_in, (int)h_out, (int)w_out);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

@@ -147,6 +147,25 @@ int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens, const int6
                         const uint8_t *video_mask, const void *video_feats, int64_t n_rows,
                         int64_t batch, int64_t seq_len, void *inputs_embeds, void *stream);
 
+/* ---- stage 0: frames -> pixel_values (device-side process()) -------------------------------------------
+ * Replaces the image half of process() (ref:eilev/model/utils.py:5-26: frames flattened into the HF image batch,
+ * Blip2Processor -> BlipImageProcessor: PIL BICUBIC resize to size x size on uint8, x * (1/255), (x - mean) / std
+ * [hf:models/blip/image_processing_blip.py], folded back to (B, C, T, H, W)).  Bit-exact restatement of Pillow's
+ * two-pass 8-bit resample (horizontal then vertical, 22-bit fixed-point coefficients, rounding, clip to 0..255;
+ * Pillow src/libImaging/Resample.c): the coefficient / bounds tables depend only on the sizes and are built on the
+ * host (eilev_amd/preprocess.py, oracle/eilev_ref.c::eilev_resample_coeffs) exactly as precompute_coeffs +
+ * normalize_coeffs_8bpc do; rescale + normalize of a byte is a 3 x 256 table of the fp32 values the HF code produces.
+ *   video:   uint8 (B, 3, T, Hin, Win)      out: (B, 3, T, Hout, Wout), out_dtype 0 = fp32 (what process() returns), 1 = bf16
+ *   coef_h:  int32 (Wout, ksize_h), bounds_h: int32 (Wout, 2) = (first input column, taps); NULL when Win == Wout
+ *   coef_v:  int32 (Hout, ksize_v), bounds_v: int32 (Hout, 2);                               NULL when Hin == Hout
+ *   lut:     fp32 (3, 256)
+ * workspace: the horizontally resized planes, uint8 (B * 3 * T, Hin, Wout). */
+size_t eilev_process_workspace_bytes(int64_t batch, int64_t frames, int64_t h_in, int64_t w_out);
+int eilev_process_frames(const uint8_t *video, int64_t batch, int64_t frames, int64_t h_in, int64_t w_in, int64_t h_out, int64_t w_out,
+                         const int32_t *coef_h, const int32_t *bounds_h, int32_t ksize_h, const int32_t *coef_v,
+                         const int32_t *bounds_v, int32_t ksize_v, const float *lut, void *out, int32_t out_dtype,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stage 4: OPT prefill -----------------------------------------------------------------
  * Replaces OPTForCausalLM.forward on inputs_embeds (hf modeling_opt.py:321-396, 464-524) as called
  * from ref:eilev/model/v2.py:220-227 (forward) and through GenerationMixin._prefill from

@@ -346,3 +346,36 @@ def shifted_ce_loss(logits: np.ndarray, labels: np.ndarray) -> float:
     sel = lb != -100
     picked = np.take_along_axis(lg, np.where(sel, lb, 0)[..., None], -1)[..., 0]
     return float(((lse - picked) * sel).sum() / sel.sum())
+
+
+def process_frames(video: np.ndarray, size: int = 224, lut: np.ndarray | None = None) -> np.ndarray:
+    """Oracle for eilev_process_frames: uint8 (B, 3, T, H, W) -> fp32 (B, 3, T, size, size); coefficient tables from the
+    oracle's own restatement of Pillow's precompute_coeffs (eilev_resample_coeffs)."""
+    from eilev_amd.preprocess import normalize_lut
+
+    L = lib()
+    L.eilev_resample_coeffs.restype = C.c_int
+    L.eilev_resample_coeffs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    video = np.ascontiguousarray(video, np.uint8)
+    b, c, t, h, w = video.shape
+    assert c == 3
+
+    def table(n_in):
+        if n_in == size:
+            return None, None, 0
+        ks = L.eilev_resample_coeffs(n_in, size, None, None)
+        coef = np.zeros((size, ks), np.int32)
+        bounds = np.zeros((size, 2), np.int32)
+        L.eilev_resample_coeffs(n_in, size, coef.ctypes.data, bounds.ctypes.data)
+        return coef, bounds, ks
+
+    ch, bh, kh = table(w)
+    cv, bv, kv = table(h)
+    lut = np.ascontiguousarray(normalize_lut() if lut is None else lut, np.float32)
+    out = np.empty((b, 3, t, size, size), np.float32)
+    nb = L.eilev_process_workspace_bytes(b, t, h, size)
+    ws = np.empty(max(nb, 1), np.uint8)
+    pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    abi.check(L.eilev_process_frames(pp(video), b, t, h, w, size, size, pp(ch), pp(bh), kh, pp(cv), pp(bv), kv, pp(lut), pp(out), 0,
+                                     pp(ws), nb, None), "eilev_process_frames (oracle)")
+    return out
