@@ -575,42 +575,64 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+// 4 adjacent output bytes per thread (one 4-byte store); w_out % 4 == 0
 __global__ void resample_h_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ coef,
                                   const int32_t *__restrict__ bounds, int ksize, int64_t rows, int w_in, int w_out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * w_out) return;
-    const int64_t row = idx / w_out;
-    const int xx = (int)(idx - row * w_out);
-    const int xmin = bounds[xx * 2], n = bounds[xx * 2 + 1];
-    const int32_t *k = coef + (int64_t)xx * ksize;
-    const uint8_t *s = src + row * w_in + xmin;
-    int ss = 1 << (kResampleBits - 1);
-    for (int x = 0; x < n; ++x) ss += (int)s[x] * k[x];
-    dst[idx] = (uint8_t)clip8(ss);
+    const int wq = w_out >> 2;
+    if (idx >= rows * wq) return;
+    const int64_t row = idx / wq;
+    const int x0 = (int)(idx - row * wq) * 4;
+    const uint8_t *srow = src + row * w_in;
+    unsigned packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int xx = x0 + e;
+        const int xmin = bounds[xx * 2], n = bounds[xx * 2 + 1];
+        const int32_t *k = coef + (int64_t)xx * ksize;
+        const uint8_t *s = srow + xmin;
+        int ss = 1 << (kResampleBits - 1);
+        for (int x = 0; x < n; ++x) ss += (int)s[x] * k[x];
+        packed |= (unsigned)clip8(ss) << (8 * e);
+    }
+    *reinterpret_cast<unsigned *>(dst + row * w_out + x0) = packed;
 }
 
+// 4 adjacent columns per thread: 4-byte loads per tap, one 16-byte (fp32) / 8-byte (bf16) store; w % 4 == 0
 template <typename OutT>
 __global__ void resample_v_lut_kernel(const uint8_t *__restrict__ src, OutT *__restrict__ dst, const int32_t *__restrict__ coef,
                                       const int32_t *__restrict__ bounds, int ksize, const float *__restrict__ lut, int64_t planes,
                                       int frames, int h_in, int h_out, int w) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= planes * h_out * w) return;
-    const int x = (int)(idx % w);
-    const int64_t py = idx / w;
+    const int wq = w >> 2;
+    if (idx >= planes * h_out * wq) return;
+    const int x = (int)(idx % wq) * 4;
+    const int64_t py = idx / wq;
     const int yy = (int)(py % h_out);
     const int64_t p = py / h_out;
-    int v;
+    int v[4];
     if (coef) {
         const int ymin = bounds[yy * 2], n = bounds[yy * 2 + 1];
         const int32_t *k = coef + (int64_t)yy * ksize;
         const uint8_t *s = src + (p * h_in + ymin) * w + x;
-        int ss = 1 << (kResampleBits - 1);
-        for (int y = 0; y < n; ++y) ss += (int)s[(int64_t)y * w] * k[y];
-        v = clip8(ss);
+        int ss[4] = {1 << (kResampleBits - 1), 1 << (kResampleBits - 1), 1 << (kResampleBits - 1), 1 << (kResampleBits - 1)};
+        for (int y = 0; y < n; ++y) {
+            const unsigned q = *reinterpret_cast<const unsigned *>(s + (int64_t)y * w);
+            const int kv = k[y];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss[e] += (int)((q >> (8 * e)) & 255u) * kv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = clip8(ss[e]);
     } else {
-        v = src[(p * h_in + yy) * w + x];
+        const unsigned q = *reinterpret_cast<const unsigned *>(src + (p * h_in + yy) * w + x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (int)((q >> (8 * e)) & 255u);
     }
-    dst[idx] = (OutT)lut[((p / frames) % 3) * 256 + v];
+    const float *l = lut + ((p / frames) % 3) * 256;
+    OutT *o = dst + (p * h_out + yy) * w + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (OutT)l[v[e]];
 }
 }  // namespace
 
@@ -627,19 +649,20 @@ extern "C" int eilev_process_frames(const uint8_t *video, int64_t batch, int64_t
     if ((!coef_h && w_in != w_out) || (!coef_v && h_in != h_out)) return EILEV_E_BADARG;
     if (out_dtype != 0 && out_dtype != 1) return EILEV_E_UNSUPPORTED;
     if (frames > 0x7fffffff || h_in > 0x7fffffff || w_in > 0x7fffffff || h_out > 0x7fffffff || w_out > 0x7fffffff) return EILEV_E_UNSUPPORTED;
+    if (w_out % 4 != 0 || ((uintptr_t)video & 3) || (!coef_h && (w_in & 3))) return EILEV_E_UNSUPPORTED;  // 4 columns per thread
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t planes = batch * 3 * frames;
     if (planes == 0) return EILEV_OK;
     const uint8_t *mid = video;
     if (coef_h) {
         if (!workspace || workspace_bytes < eilev_process_workspace_bytes(batch, frames, h_in, w_out)) return EILEV_E_WORKSPACE;
-        const int64_t rows = planes * h_in, total = rows * w_out;
+        const int64_t rows = planes * h_in, total = rows * (w_out / 4);
         hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, (uint8_t *)workspace, coef_h,
                            bounds_h, ksize_h, rows, (int)w_in, (int)w_out);
         EILEV_LAUNCH_CHECK();
         mid = (const uint8_t *)workspace;
     }
-    const int64_t total = planes * h_out * w_out;
+    const int64_t total = planes * h_out * (w_out / 4);
     if (out_dtype == 0)
         hipLaunchKernelGGL(resample_v_lut_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid, (float *)out, coef_v,
                            bounds_v, ksize_v, lut, planes, (int)frames, (int)h_in, (int)h_out, (int)w_out);

@@ -67,6 +67,9 @@ def normalize_lut(mean=CLIP_MEAN, std=CLIP_STD, rescale_factor: float = 1 / 255)
     return ((t[None, :] - m) / s).astype(np.float32)
 
 
+_DEVICE_TABLES: dict = {}
+
+
 def process_frames(video, size: int = 224, mean=CLIP_MEAN, std=CLIP_STD, rescale_factor: float = 1 / 255, dtype=None, lib=None):
     """uint8 CUDA tensor (B, 3, T, H, W) or (3, T, H, W) -> pixel_values (B, 3, T, size, size) (float32 unless ``dtype`` is
     torch.bfloat16), on the tensor's device and the current stream."""
@@ -91,12 +94,18 @@ def process_frames(video, size: int = 224, mean=CLIP_MEAN, std=CLIP_STD, rescale
     def table(n_in):
         if n_in == size:
             return None, None, 0
-        coef, bounds = resample_coeffs(int(n_in), int(size))
-        return torch.from_numpy(coef).to(dev), torch.from_numpy(bounds).to(dev), coef.shape[1]
+        key = ("axis", int(n_in), int(size), str(dev))
+        if key not in _DEVICE_TABLES:  # the tables depend only on the sizes: one upload per (size pair, device)
+            coef, bounds = resample_coeffs(int(n_in), int(size))
+            _DEVICE_TABLES[key] = (torch.from_numpy(coef).to(dev), torch.from_numpy(bounds).to(dev), coef.shape[1])
+        return _DEVICE_TABLES[key]
 
     ch, bh, kh = table(w_in)
     cv, bv, kv = table(h_in)
-    lut = torch.from_numpy(normalize_lut(tuple(mean), tuple(std), rescale_factor)).to(dev)
+    lkey = ("lut", tuple(mean), tuple(std), float(rescale_factor), str(dev))
+    if lkey not in _DEVICE_TABLES:
+        _DEVICE_TABLES[lkey] = torch.from_numpy(normalize_lut(tuple(mean), tuple(std), rescale_factor)).to(dev)
+    lut = _DEVICE_TABLES[lkey]
     out = torch.empty((b, 3, t, size, size), dtype=out_dtype, device=dev)
     nb = lib.eilev_process_workspace_bytes(b, t, h_in, size) if ch is not None else 0
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
