@@ -845,6 +845,32 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
                             (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);  // provably wave-uniform: no waterfall loops
         return __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, __builtin_amdgcn_readfirstlane(rows * (int)(g.ldc * 2)), 0x00020000);
     };
+    // residual (fc2 / proj): the unit's 32 rows x 64 columns go through the same staging rows first (coalesced 128-byte row
+    // segments, same swizzle), each lane then adds its 8-byte cell in place.  (Vector loads: the compiler waits vmcnt(0) at
+    // their first use, i.e. also for the next tile's first K-steps already in flight — they are due within a K-step anyway.)
+    const bool has_res = g.resid != nullptr;
+    __amdgpu_buffer_rsrc_t rr = rc;
+    const unsigned rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
+    auto rsrc_r = [&](int m0, int n0) {
+        const int r0 = m0 + wm * WM;
+        const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
+        const uint64_t base = (uint64_t)(g.resid + (int64_t)r0 * g.ldr + n0 + wn * WN);
+        const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, __builtin_amdgcn_readfirstlane(rows * (int)(g.ldr * 2)), 0x00020000);
+    };
+    auto stage_resid = [&](auto unit_c) {
+        constexpr int U = decltype(unit_c)::value;
+        typedef __attribute__((ext_vector_type(4))) unsigned w6_u32x4;
+        w6_u32x4 rv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (U * 32 + it * 8) * (int)(g.ldr * 2), 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + srow;
+            *reinterpret_cast<w6_u32x4 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[it];
+        }
+    };
     auto epi_chunk = [&](auto unit_c, auto ch_c) {
         constexpr int U = decltype(unit_c)::value, CH = decltype(ch_c)::value;
         constexpr float gc[13] = EILEV_GELU_COEFFS;
@@ -880,6 +906,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
                 constexpr int c = J * 4 + 2 * QP + h;
                 unsigned ca;
                 asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(c << 4), "v"(stg_sw));
+                if (has_res) {
+                    const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(smem + ca);
+                    y0 = y0 + (f32x2){(float)r4[0], (float)r4[1]};
+                    y1 = y1 + (f32x2){(float)r4[2], (float)r4[3]};
+                }
                 *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)y0.x, (bf16)y0.y, (bf16)y1.x, (bf16)y1.y};
             }
         } else {
@@ -999,7 +1030,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) accp[i][j] = acc[i][j];
         rc = rsrc_c(m0, n0);
-        static_for<4>([&](auto u_c) { static_for<NCH>([&](auto c_c) { epi_chunk(u_c, c_c); }); });
+        if (has_res) rr = rsrc_r(m0, n0);
+        static_for<4>([&](auto u_c) {
+            if (has_res) stage_resid(u_c);
+            static_for<NCH>([&](auto c_c) { epi_chunk(u_c, c_c); });
+        });
         if (!has_next) break;
         ra = ra1;
         rw = rw1;
@@ -1314,10 +1349,15 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
     else if (force >= 1 && force <= 4) cfg = force;
-    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && !g.resid && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 &&
+    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 &&
                        (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
-    if ((force == 12 || (force == 0 && cfg == 1 && !wide_tiles && g.epi == 0 && !(g.dbg & 2097152))) && w6_ok)
-        rc = launch_w6(g, s);  // one-wave-per-SIMD continuous-stream kernel: bias-only epilogues +2.5-4 % over pp4 (GELU / ReLU: equal or -1 %)
+    // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): bias-only epilogues +2.5-4 % over pp4 (GELU / ReLU: equal or
+    // -1 %); with a residual +3-6 % for K <= 2560 (proj, OPT out_proj) but -7 % for long K (fc2: fabric-bound, 1.5x the DMA bytes);
+    // and its smaller tiles balance better when there are fewer than 4 rounds of 256 x 256 tiles (M = 7680 prefill: +28 %)
+    const int64_t tiles256 = tm256 * ceil_div64(g.N, 256);
+    const bool w6_pick = cfg == 1 && ((g.epi == 0 && !g.resid && !wide_tiles) || (g.resid && g.K <= 2560) || tiles256 < 1024);
+    if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & 2097152))) && w6_ok)
+        rc = launch_w6(g, s);
     else if (cfg == 1 && (!wide_tiles || (g.dbg & 1048576)) && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp4(g, s);  // persistent ping-pong kernel

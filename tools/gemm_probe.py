@@ -27,6 +27,7 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        "proj": (34952, 1408, 1408, 0, True), "opt_fc1": (7680, 10240, 2560, 2, False), "opt_qkv": (7680, 7680, 2560, 0, False),
        "qf_kv": (34952, 1536, 1408, 0, False), "opt_fc2": (7680, 2560, 10240, 0, True),
        "fc2_k6208": (34952, 1408, 6208, 0, True), "fc2_k6080": (34952, 1408, 6080, 0, True), "fc1_k1472": (34952, 6144, 1472, 0, False),
+       "opt_out": (7680, 2560, 2560, 0, True),
        "fc1_noact": (34952, 6144, 1408, 0, False), "fc1_relu": (34952, 6144, 1408, 2, False)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
@@ -35,6 +36,8 @@ for name in names:
     m, n, k, epi, resid = ALL[name]
     if os.environ.get("PROBE_M") and m == 34952:
         m = int(os.environ["PROBE_M"])
+    if os.environ.get("PROBE_MOPT") and m == 7680:
+        m = int(os.environ["PROBE_MOPT"])
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda").to(torch.bfloat16)
