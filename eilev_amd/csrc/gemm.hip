@@ -29,6 +29,16 @@ constexpr int BK = 64;  // bf16 elements per K-step = one 128-byte LDS row
 // slots of the 256-byte bank row, for the 32-row fragment pattern of the 32x32x16 MFMA.
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ ((row >> 1) & 7)) << 4; }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // Workgroup -> tile map.  (1) XCD-aware: block b runs on XCD b % 8, so each XCD (private 4 MiB L2) gets a
 // contiguous range of the tile order.  (2) Grouped order: consecutive tiles walk down GROUP_M tile rows before
 // moving to the next tile column, so the ~32-64 tiles an XCD runs concurrently form a compact 2-D block and
@@ -628,6 +638,108 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
+    // ---- lean epilogue (interior tiles, bf16 output, no column tail / patch remap / column scaling) -------------------------
+    // 4 KiB of LDS staging per wave OUTSIDE the two step buffers, so the next tile's first TWO K-steps are already in flight
+    // while it runs (the general epilogue below stages 69.6 KB through step buffer 1 and leaves a DMA-latency bubble at the top
+    // of the next tile).  Units of 32 rows x 64 columns (one i block of the wave): bias / activation / residual / bf16 into the
+    // staging rows (16-byte chunk c of row r at chunk c ^ (r & 7)), read back as 128-byte row segments, buffer stores whose
+    // descriptor drops rows past M.
+    char *const stg = smem + 2 * STEP + wid * 4096;
+    const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
+    const int srow = lane >> 3, schunk = lane & 7;
+    auto lean_epilogue = [&](int cm0, int cn0) {
+        constexpr int CPC = EPI == 1 ? 16 : 4, NCH = 4 * CPC + 8;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        const int r0 = cm0 + wm * WM;
+        const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
+        auto uniform_rsrc = [&](const void *ptr, int bytes) {
+            const uint64_t base = (uint64_t)ptr;
+            const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);  // provably wave-uniform: no waterfall loops
+            return __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + wn * WN, rows * (int)(g.ldc * 2));
+        const bool has_res = g.resid != nullptr;
+        const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(has_res ? g.resid + (int64_t)r0 * g.ldr + cn0 + wn * WN : g.A, has_res ? rows * (int)(g.ldr * 2) : 0);
+        const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
+        bf16x4 biasr[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (g.bias) biasr[j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + cn0 + wn * WN + j * 32 + q * 8 + hi * 4);
+                else biasr[j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            }
+        f32x2 ex[4], eu[4], et[4], ep[4];
+        bf16x8 erb[2];
+        auto chunk = [&](auto unit_c, auto ch_c) {
+            constexpr int U = decltype(unit_c)::value, CH = decltype(ch_c)::value;
+            constexpr float gc[13] = EILEV_GELU_COEFFS;
+            if constexpr (CH < 4 * CPC) {
+                constexpr int CP = CH / CPC, SUB = CH % CPC, J = CP >> 1, QP = CP & 1;
+                if constexpr (SUB < 2) {  // prepare half h = SUB: x = acc + bias (ReLU / GELU argument reduction)
+                    constexpr int h = SUB;
+                    const bf16x4 b4 = biasr[J][2 * QP + h];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        f32x2 v = {acc[U][J][(2 * QP + h) * 4 + 2 * e2] + (float)b4[2 * e2], acc[U][J][(2 * QP + h) * 4 + 2 * e2 + 1] + (float)b4[2 * e2 + 1]};
+                        if (EPI == 2) v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
+                        if (EPI == 1) {
+                            eu[h * 2 + e2] = (f32x2){fminf(fabsf(v.x), 5.0f), fminf(fabsf(v.y), 5.0f)};
+                            et[h * 2 + e2] = eu[h * 2 + e2] * 0.4f + (-1.0f);
+                            ep[h * 2 + e2] = (f32x2){gc[12], gc[12]};
+                            v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
+                        }
+                        ex[h * 2 + e2] = v;
+                    }
+                }
+                if constexpr (EPI == 1 && SUB >= 2 && SUB < 14) {
+                    constexpr int kk = 13 - SUB;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) ep[n] = ep[n] * et[n] + gc[kk];
+                }
+                if constexpr (SUB >= CPC - 2) {  // finish half h: (GELU: relu(x) - u p(t),) + residual, bf16, one 8-byte cell
+                    constexpr int h = SUB - (CPC - 2);
+                    f32x2 y0 = ex[h * 2], y1 = ex[h * 2 + 1];
+                    if (EPI == 1) {
+                        y0 = y0 - eu[h * 2] * ep[h * 2];
+                        y1 = y1 - eu[h * 2 + 1] * ep[h * 2 + 1];
+                    }
+                    constexpr int c = J * 4 + 2 * QP + h;
+                    unsigned ca;
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(c << 4), "v"(stg_sw));
+                    if (has_res) {
+                        const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(smem + ca);
+                        y0 = y0 + (f32x2){(float)r4[0], (float)r4[1]};
+                        y1 = y1 + (f32x2){(float)r4[2], (float)r4[3]};
+                    }
+                    *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)y0.x, (bf16)y0.y, (bf16)y1.x, (bf16)y1.y};
+                }
+            } else {  // read-backs and stores in the order R0 R1 S0 S1 R2 R3 S2 S3 (two buffers)
+                constexpr int X = CH - 4 * CPC, IT = (X >> 2) * 2 + (X & 1);
+                if constexpr ((X & 2) == 0) {
+                    const int row = IT * 8 + srow;
+                    erb[IT & 1] = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4));
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[IT & 1]), rc, st_voff, (U * 32 + IT * 8) * (int)(g.ldc * 2), 0);
+                }
+            }
+        };
+        static_for<TM>([&](auto u_c) {
+            constexpr int U = decltype(u_c)::value;
+            if (has_res) {  // the unit's residual rows -> staging (coalesced), each lane then adds its cell in place
+                u32x4_t rv[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (U * 32 + it * 8) * (int)(g.ldr * 2), 0);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + srow;
+                    *reinterpret_cast<u32x4_t *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[it];
+                }
+            }
+            static_for<NCH>([&](auto c_c) { chunk(u_c, c_c); });
+        });
+    };
 #define PP_BARRIER()                       \
     do {                                   \
         __builtin_amdgcn_sched_barrier(0); \
@@ -638,7 +750,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     int t = blockIdx.x, m0, n0;
     if (t >= ntiles) return;
     set_tile(t, m0, n0);
-    stage_step(0, !(n0 + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2);
+    auto w_piece_mine = [&](int n0_) { return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2; };
+    stage_step(0, w_piece_mine(n0));
+    bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
+    if (pre1) stage_step(1, w_piece_mine(n0));
     for (; t < ntiles; t += gridDim.x) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -657,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             const bool w_mine = wid < NW / 2;
             for (int st = 0; st < nsd; ++st) {
                 read_half_ht(st, 0);
-                if (st + 1 < ns) stage_step(st + 1, w_mine);
+                if (st + 1 < ns && !(st == 0 && pre1)) stage_step(st + 1, w_mine);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_BARRIER();
                 mma_half_ht();
@@ -671,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         } else {
             for (int st = 0; st < nsd; ++st) {
                 read_half(st, 0);
-                if (st + 1 < ns) stage_step(st + 1);
+                if (st + 1 < ns && !(st == 0 && pre1)) stage_step(st + 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_BARRIER();
                 mma_half();
@@ -684,14 +799,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             }
         }
         if (!late) PP_BARRIER();
-        // every wave has finished reading both step buffers: start the next tile's first step (buffer 0), then store
-        // (the epilogue stages through buffer 1)
+        // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
+        // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
         const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
+        const bool lean = !half_tile && cn0 + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !(g.dbg & (1024 | 2048 | 1)) &&
+                          !(g.dbg & 16777216);
+        pre1 = false;
         if (tn < ntiles) {
             set_tile(tn, m0, n0);
-            stage_step(0, !(n0 + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2);
+            stage_step(0, w_piece_mine(n0));
+            pre1 = lean && ns > 1;
+            if (pre1) stage_step(1, w_piece_mine(n0));
         }
-        if (half_tile) {
+        if (lean) {
+            lean_epilogue(cm0, cn0);
+        } else if (half_tile) {
             gemm_epilogue<64, 64, EPI>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
         } else {
             gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
@@ -704,8 +826,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 int launch_pp4(const GemmArgs &g, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
-    constexpr int smem = 65536 + 8 * 64 * (64 * 2 + 8);  // step buffer 0 + epilogue staging (which overlays step buffer 1)
-    static_assert(smem >= 2 * 65536, "staging must cover step buffer 1");
+    constexpr int smem = 2 * 65536 + 8 * 4096;  // two step buffers + 4 KiB of lean-epilogue staging per wave (the general epilogue
+                                                // stages 69.6 KB from step buffer 1 on: 65536 + 69632 < 163840)
     if (!attr_set) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -738,14 +860,6 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
 // cost 7 % instead of 16 %: +3-4 % on bias-only epilogues, equal on the GELU one.
 __device__ __forceinline__ void w6_dma(__amdgpu_buffer_rsrc_t r, char *dst, unsigned voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 16, voff, soff, 0, 0);
-}
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 typedef int w6_i32x16 __attribute__((ext_vector_type(16)));
@@ -1351,14 +1465,14 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (force >= 1 && force <= 4) cfg = force;
     const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 &&
                        (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
-    // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): bias-only epilogues +2.5-4 % over pp4 (GELU / ReLU: equal or
-    // -1 %); with a residual +3-6 % for K <= 2560 (proj, OPT out_proj) but -7 % for long K (fc2: fabric-bound, 1.5x the DMA bytes);
-    // and its smaller tiles balance better when there are fewer than 4 rounds of 256 x 256 tiles (M = 7680 prefill: +28 %)
+    // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): its smaller tiles balance better when there are fewer than
+    // 4 rounds of 256 x 256 tiles (M = 7680 prefill GEMMs: +28 %); with more tiles the ping-pong kernel with the lean epilogue wins
+    // (qkv +5 %, OPT out_proj +3 %)
     const int64_t tiles256 = tm256 * ceil_div64(g.N, 256);
-    const bool w6_pick = cfg == 1 && ((g.epi == 0 && !g.resid && !wide_tiles) || (g.resid && g.K <= 2560) || tiles256 < 1024);
-    if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & 2097152))) && w6_ok)
+    const bool w6_pick = cfg == 1 && tiles256 < 1024;
+    if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
         rc = launch_w6(g, s);
-    else if (cfg == 1 && (!wide_tiles || (g.dbg & 1048576)) && (force == 0 || force == 9) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
+    else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp4(g, s);  // persistent ping-pong kernel
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
