@@ -54,15 +54,20 @@ def test_linear_tiled(hip, m, n, k, epi):
     _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
 
 
-@pytest.mark.parametrize("m,n,k,epi,bias", [
-    (8229, 2048, 320, 0, True),     # one-wave-per-SIMD persistent kernel (bias-only wide N): M tail of 37 rows, short K
-    (8229, 2304, 1408, 0, False),   # N a multiple of 128 but not of 256, no bias
-    (16500, 4224, 256, 0, True),    # minimum K (4 K-steps), ViT qkv width
-    (8229, 2048, 1408, 1, True),    # same shapes through the ping-pong kernel (GELU) ...
-    (8229, 2560, 2560, 2, True),    # ... and ReLU
+@pytest.mark.parametrize("m,n,k,epi,bias,resid", [
+    # fewer than 4 rounds of 256x256 tiles -> one-wave-per-SIMD persistent kernel (w6)
+    (8229, 2048, 320, 0, True, False),     # M tail of 37 rows, short K
+    (8229, 2304, 1408, 0, False, False),   # N a multiple of 128 but not of 256, no bias
+    (16500, 4224, 256, 0, True, False),    # minimum K (4 K-steps), ViT qkv width
+    (8229, 2048, 1408, 1, True, False),    # GELU
+    (8229, 2560, 2560, 2, True, True),     # ReLU + residual (rows staged through the epilogue unit)
+    # >= 4 rounds -> ping-pong kernel (pp4) with the lean epilogue on interior tiles
+    (70001, 4096, 256, 1, True, True),     # GELU + residual, M tail of 113 rows (stores dropped by the descriptor)
+    (70001, 4224, 320, 0, True, False),    # last column tile half empty (general epilogue) next to lean tiles
+    (90003, 1408, 256, 0, True, True),     # N = 1408: 5 lean column tiles + the half tile, residual
 ])
-def test_linear_persistent_kernels(hip, m, n, k, epi, bias):
-    _lin_case(hip, m, n, k, epi, bias=bias, resid=False)
+def test_linear_persistent_kernels(hip, m, n, k, epi, bias, resid):
+    _lin_case(hip, m, n, k, epi, bias=bias, resid=resid)
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 160, 160), (8, 2560, 2560), (8, 7680, 2560), (3, 320, 160), (16, 1000, 10240), (8, 50272, 2560),
