@@ -4,10 +4,12 @@
     [PROBE_M=rows] python tools/gemm_probe.py <flags,flags,...> <shape,shape,...> <rounds>
 
 flags (eilev_debug_gemm_flags): 4 register-staged reference kernel; 8 old skinny kernel; (n << 4) force tile config n
-(1: 256x256, 2: 256x128 two stages, 3: 256x128 one stage x 2 workgroups/CU, 4: 128x128, 9: persistent ping-pong kernel);
-1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0 (cache-resident operand);
-131072 alias all output rows onto row 0; 524288 no half-tile path; 1048576 persistent kernel also for N = 1408;
-(n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
+(1: 256x256 per-tile kernel, 2: 256x128 two stages, 3: 256x128 one stage x 2 workgroups/CU, 4: 128x128, 9: persistent ping-pong
+kernel pp4, 12: one-wave-per-SIMD kernel w6); 1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0
+(cache-resident operand — also changes the MFMA data statistics and with them the clock: not a memory-system measurement);
+131072 alias all output rows onto row 0; 524288 no half-tile path; 1048576 per-tile kernel for N = 1408; 2097152 never pick w6;
+16777216 pp4 without the lean epilogue / second pre-staged K-step; (n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
+PROBE_M / PROBE_MOPT override the row count of the ViT / OPT shapes.
 """
 import ctypes as C
 import os
