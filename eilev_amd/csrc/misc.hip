@@ -35,6 +35,53 @@ __global__ void im2col_kernel(const T *__restrict__ pix, bf16 *__restrict__ out,
     *reinterpret_cast<bf16x8 *>(out + row * kp + c * 8) = pack8(v);
 }
 
+// Same result, frame tensor read with coalesced 16-byte loads: one workgroup per (frame, patch row) stages the 3 x patch x img
+// strip of pixels in LDS (as bf16) and writes the strip's img / patch im2col rows with coalesced 16-byte stores.
+// IMG / PATCH are compile-time (ViT-g/14 at 224): every index division becomes a multiply-shift.
+template <typename T, int IMG, int PATCH>
+__global__ __launch_bounds__(256) void im2col_strip_kernel(const T *__restrict__ pix, bf16 *__restrict__ out, int frames, int kp) {
+    constexpr int img = IMG, patch = PATCH;
+    extern __shared__ __attribute__((aligned(16))) char im2col_smem[];
+    bf16 *strip = reinterpret_cast<bf16 *>(im2col_smem);  // [3][patch][img]
+    const int g = img / patch, pp = patch * patch;
+    const int64_t f = blockIdx.x / g;
+    const int py = (int)(blockIdx.x - f * g);
+    const int64_t n = f / frames;
+    const int t = (int)(f - n * frames);
+    const int cpr = img >> 3;  // 8-pixel chunks per image row
+    for (int i = threadIdx.x; i < 3 * patch * cpr; i += blockDim.x) {
+        const int ch = i / (patch * cpr), rem = i - ch * patch * cpr, dy = rem / cpr, cx = rem - dy * cpr;
+        const T *src = pix + (((n * 3 + ch) * frames + t) * img + py * patch + dy) * (int64_t)img + cx * 8;
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 q = *reinterpret_cast<const bf16x8 *>(src);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)q[e];
+        } else {
+            const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        *reinterpret_cast<bf16x8 *>(strip + (ch * patch + dy) * img + cx * 8) = pack8(v);
+    }
+    __syncthreads();
+    const int chunks = kp >> 3;
+    for (int i = threadIdx.x; i < g * chunks; i += blockDim.x) {
+        const int px = i / chunks, c = i - px * chunks;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = c * 8 + e;
+            float val = 0.0f;
+            if (k < 3 * pp) {
+                const int ch = k / pp, rem = k - ch * pp, dy = rem / patch, dx = rem - dy * patch;
+                val = (float)strip[(ch * patch + dy) * img + px * patch + dx];
+            }
+            v[e] = val;
+        }
+        *reinterpret_cast<bf16x8 *>(out + ((f * g + py) * g + px) * (int64_t)kp + c * 8) = pack8(v);
+    }
+}
+
 __global__ void pad_rows_kernel(const bf16 *__restrict__ w, bf16 *__restrict__ out, int rows, int k, int kp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * kp) return;
@@ -484,6 +531,15 @@ int launch_rows_to_cache(const bf16 *src, int64_t ld, int col0, bf16 *plane, int
     return EILEV_OK;
 }
 int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s) {
+    const int g = img / patch;
+    const size_t strip_bytes = (size_t)3 * patch * img * sizeof(bf16);
+    if (img == 224 && patch == 14 && rows % ((int64_t)g * g) == 0 && ((uintptr_t)pix & 15) == 0 && (dtype == EILEV_F32 || dtype == EILEV_BF16)) {
+        const unsigned nblk = (unsigned)(rows / g);  // (frame, patch row) pairs
+        if (dtype == EILEV_F32) hipLaunchKernelGGL((im2col_strip_kernel<float, 224, 14>), dim3(nblk), dim3(256), strip_bytes, s, (const float *)pix, out, frames, kp);
+        else hipLaunchKernelGGL((im2col_strip_kernel<bf16, 224, 14>), dim3(nblk), dim3(256), strip_bytes, s, (const bf16 *)pix, out, frames, kp);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     const int64_t total = rows * (kp >> 3);
     const dim3 grid((unsigned)ceil_div64(total, 256)), block(256);
     if (dtype == EILEV_F32) hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, (const float *)pix, out, rows, frames, img, patch, kp);
