@@ -241,6 +241,7 @@ EXPORTS = [
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
+    "eilev_linear_w8_scratch_bytes", "eilev_linear_w8",
 ]
 
 
@@ -259,6 +260,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_qformer_forward.argtypes = [DP, C.POINTER(QfWeights), vp, i64, i64, vp, vp, sz, vp]
     lib.eilev_project_rows.restype = i32
     lib.eilev_project_rows.argtypes = [DP, vp, vp, vp, i64, vp, vp]
+    lib.eilev_linear_w8_scratch_bytes.restype = sz
+    lib.eilev_linear_w8_scratch_bytes.argtypes = [i64, i64, i64]
+    lib.eilev_linear_w8.restype = i32
+    lib.eilev_linear_w8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
     lib.eilev_process_workspace_bytes.restype = sz
     lib.eilev_process_workspace_bytes.argtypes = [i64, i64, i64, i64]
     lib.eilev_process_frames.restype = i32

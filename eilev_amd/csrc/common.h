@@ -121,6 +121,10 @@ struct GemmArgs {
     int dbg;            // probe-only
     float *scratch;     // optional fp32 scratch for the skinny kernel's split-K partials
     size_t scratch_bytes;
+    // fp8 (OCP e4m3) weights with one fp32 scale per output channel: C = (A . Wq^T) * wscale + bias (eilev_linear_w8)
+    const float *wscale = nullptr;  // [N] or null
+    const uint8_t *W8 = nullptr;    // [N, K] e4m3 bytes (ldw = K) when the weights are still quantised (skinny kernel)
+    bf16 *w8_scratch = nullptr;     // [N, K] bf16: where a large-M call expands W8 to (exact: every e4m3 value is a bf16 value)
 };
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);

@@ -91,6 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float v = acc[i][j][q * 4 + e];
+                            if (g.wscale && col + e < g.N) v *= g.wscale[col + e];
                             if (g.bias) v += (float)g.bias[col + e];
                             if (col + e < g.scale_cols) v *= g.scale;
                             if (EPI == 1) v = gelu_erf(v);
@@ -168,6 +169,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
             char *cp = reg + l31 * RS + lc * 2;
             constexpr int NI = IEND - IBEG;
             float v[NI][4];
+            if (g.wscale) {  // fp8 weights: per-output-channel scale before the bias
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ws = col + e < g.N ? g.wscale[col + e] : 1.0f;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[IBEG + i][j][q * 4 + e] *= ws;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
         const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
-        const bool lean = !half_tile && cn0 + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !(g.dbg & (1024 | 2048 | 1)) &&
+        const bool lean = !half_tile && cn0 + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !(g.dbg & (1024 | 2048 | 1)) &&
                           !(g.dbg & 16777216);
         pre1 = false;
         if (tn < ntiles) {
@@ -1195,6 +1204,7 @@ struct SkinnyArgs {
 };
 
 __device__ __forceinline__ void skinny_epilogue(const GemmArgs &g, int row, int col, float v) {
+    if (g.wscale) v *= g.wscale[col];
     if (g.bias) v += (float)g.bias[col];
     if (col < g.scale_cols) v *= g.scale;
     if (g.epi == 1) v = gelu_erf(v);
@@ -1355,6 +1365,124 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
     }
 }
 
+// Skinny kernel for fp8 (OCP e4m3) weights: the same per-wave 2-deep LDS-DMA pipeline over 16-row x 256-K tiles, which are now
+// 4 KiB (half the bytes of the bound stream).  Piece i = rows 4i .. 4i+3 x 256 B; 16-byte chunk c of row r is stored at chunk
+// c ^ (r & 15).  A lane's 8 weights of an MFMA k-step are 8 bytes: v_cvt_pk_f32_fp8 + one v_perm_b32 per pair make the bf16
+// fragment (every e4m3 value is exactly a bf16 value); the per-channel scale is applied to the fp32 sum in the epilogue.
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a) {
+    const GemmArgs &g = a.g;
+    __shared__ __attribute__((aligned(16))) char wbuf[4][2][4096];
+    __shared__ float red[4][MB][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int ktiles = g.K / 256;
+    const int per_wg = (ktiles + a.ks - 1) / a.ks;
+    const int wg_beg = blockIdx.y * per_wg, wg_end = min(ktiles, wg_beg + per_wg);
+    const int per_w = (max(wg_end - wg_beg, 0) + 3) / 4;
+    const int beg = wg_beg + wid * per_w, end = min(wg_end, beg + per_w);
+
+    const int prow = lane >> 4, pslot = lane & 15;
+    const uint8_t *src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + prow;
+        int gr = n0 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        src[i] = g.W8 + (int64_t)gr * g.ldw + ((pslot ^ (row & 15)) << 4);
+    }
+    auto stage_in = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(src[i] + t * 256), (lds_void *)(&wbuf[wid][buf][i * 1024]), 16, 0, 0);
+    };
+    const bf16 *ap[MB];
+    bool arow[MB];
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = mb * 16 + l15;
+        arow[mb] = r < g.M;
+        ap[mb] = g.A + (int64_t)(arow[mb] ? r : 0) * g.lda + lg * 8;
+        acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (beg < end) stage_in(0, beg);
+    for (int t = beg; t < end; ++t) {
+        const int cur = (t - beg) & 1;
+        bf16x8 av[MB][8];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
+        if (t + 1 < end) {
+            stage_in(cur ^ 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the 4 pieces of tile t (older than the 4 just issued)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char *wb = &wbuf[wid][cur][0] + l15 * 256 + (lg & 1) * 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const u32x2_t q = *reinterpret_cast<const u32x2_t *>(wb + (((u * 2 + (lg >> 1)) ^ l15) << 4));
+            u32x4_t wbits;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // (element reads through float variables: __builtin_bit_cast of a vector subscript picks element 0 twice here)
+                const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
+                const float l0 = lo.x, l1 = lo.y, h0 = hi2.x, h1 = hi2.y;
+                // bf16 pair = high halves of the two floats (exact)
+                wbits[2 * h] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+                wbits[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
+            }
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, wbits);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wid][mb][lane][r] = acc[mb][r];
+    __syncthreads();
+    if (wid < MB) {
+        const int col = n0 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w][wid][lane][r];
+            const int row = wid * 16 + lg * 4 + r;
+            if (row < g.M && col < g.N) {
+                if (a.ks == 1) skinny_epilogue(g, row, col, v);
+                else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
+            }
+        }
+    }
+}
+
+// e4m3 bytes -> bf16 (exact), 16 bytes per thread
+__global__ void w8_expand_kernel(const uint8_t *__restrict__ src, bf16 *__restrict__ dst, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(src + i * 16);
+    u32x4_t o[2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
+        const float l0 = lo.x, l1 = lo.y, h0 = hi2.x, h1 = hi2.y;
+        o[h >> 1][(h & 1) * 2] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+        o[h >> 1][(h & 1) * 2 + 1] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
+    }
+    *reinterpret_cast<u32x4_t *>(dst + i * 16) = o[0];
+    *reinterpret_cast<u32x4_t *>(dst + i * 16 + 8) = o[1];
+}
+
 __global__ void skinny_reduce_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1402,9 +1530,25 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
     if (g.dbg & 131072) g.ldc = 0;  // probe: every output row aliases row 0 (stores stay in L2)
     if (g.M <= 0) return EILEV_OK;
+    if (g.W8) {
+        // fp8 weights.  M <= 32 (decode): streamed as bytes by the fp8 skinny kernel.  Larger M (prefill): expanded to bf16 in the
+        // caller's scratch (exact), then the bf16 kernels with the per-channel scale in their epilogue.
+        if (!g.A || !g.C || !g.wscale || g.N <= 0 || g.K <= 0 || g.ldw != g.K || ((uintptr_t)g.W8 & 15) || (g.K & 15)) return EILEV_E_BADARG;
+        if (!(g.M <= 32 && g.K % 256 == 0 && g.patch_group == 0)) {
+            if (!g.w8_scratch) return EILEV_E_WORKSPACE;
+            const int64_t n16 = (int64_t)g.N * g.K / 16;
+            hipLaunchKernelGGL(w8_expand_kernel, dim3((unsigned)ceil_div64(n16, 256)), dim3(256), 0, s, g.W8, g.w8_scratch, n16);
+            EILEV_LAUNCH_CHECK();
+            GemmArgs e = g_in;
+            e.W = g.w8_scratch;
+            e.W8 = nullptr;
+            return launch_gemm(e, prof_kind, s);
+        }
+        g.W = reinterpret_cast<const bf16 *>(g.W8);  // (never dereferenced as bf16: the skinny fp8 kernel reads W8)
+    }
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
-    const bool dma_ok = g.K % 256 == 0 && !(g.dbg & 8);
+    const bool dma_ok = g.K % 256 == 0 && (!(g.dbg & 8) || g.W8);
     const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0;
     if (!skinny && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
                                    (g.bias && ((uintptr_t)g.bias & 7))))
@@ -1421,7 +1565,9 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         if (ks > 1 && (!g.scratch || (size_t)ks * a.mr * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
         a.ks = ks;
         a.part = g.scratch;
-        if (dma_ok && g.M > 16) hipLaunchKernelGGL(gemm_skinny_dma_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
+        if (g.W8 && g.M > 16) hipLaunchKernelGGL(gemm_skinny_w8_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
+        else if (g.W8) hipLaunchKernelGGL(gemm_skinny_w8_kernel<1>, dim3(nb, ks), dim3(256), 0, s, a);
+        else if (dma_ok && g.M > 16) hipLaunchKernelGGL(gemm_skinny_dma_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
         else if (dma_ok) hipLaunchKernelGGL(gemm_skinny_dma_kernel<1>, dim3(nb, ks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
@@ -1463,7 +1609,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
     else if (force >= 1 && force <= 4) cfg = force;
-    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 &&
+    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
                        (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
     // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): its smaller tiles balance better when there are fewer than
     // 4 rounds of 256 x 256 tiles (M = 7680 prefill GEMMs: +28 %); with more tiles the ping-pong kernel with the lean epilogue wins

@@ -532,6 +532,29 @@ extern "C" int eilev_linear(const void *a, const void *w, const void *bias, cons
     return launch_gemm(g, 5, (hipStream_t)stream);
 }
 
+extern "C" size_t eilev_linear_w8_scratch_bytes(int64_t m, int64_t n, int64_t k) {
+    const size_t expand = m > 32 || k % 256 != 0 ? (size_t)n * k * sizeof(bf16) : 0;       // large M: weights expanded to bf16
+    const size_t partials = m <= 32 ? (size_t)64 * 32 * n * sizeof(float) : 0;             // small M: split-K partial sums
+    return expand > partials ? expand : partials;
+}
+
+extern "C" int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_scale, const void *bias, const void *residual, void *c,
+                               int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!a || !w8 || !w_scale || !c || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;
+    GemmArgs g = mk_gemm((const bf16 *)a, k, nullptr, k, bias, (const bf16 *)residual, n, c, n, m, (int)n, (int)k, epilogue);
+    g.out_f32 = out_f32;
+    g.W8 = w8;
+    g.wscale = w_scale;
+    if (m > 32 || k % 256 != 0) {
+        if (!scratch || scratch_bytes < (size_t)n * k * sizeof(bf16)) return EILEV_E_WORKSPACE;
+        g.w8_scratch = (bf16 *)scratch;
+    } else if (scratch) {
+        g.scratch = (float *)scratch;
+        g.scratch_bytes = scratch_bytes;
+    }
+    return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
 extern "C" int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y, int64_t rows, int64_t cols,
                                float eps, void *stream) {
     return launch_layernorm((const bf16 *)x, cols, (const bf16 *)gamma, (const bf16 *)beta, (bf16 *)y, cols, rows, (int)cols,

@@ -147,6 +147,18 @@ int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens, const int6
                         const uint8_t *video_mask, const void *video_feats, int64_t n_rows,
                         int64_t batch, int64_t seq_len, void *inputs_embeds, void *stream);
 
+/* ---- fp8-weight linear (BASELINE configs[4]: "fp8 MFMA weights") ------------------------------------
+ * nn.Linear with the weight matrix stored as OCP e4m3 bytes (torch.float8_e4m3fn) and one fp32 scale per output channel:
+ *     C[m, n] = epilogue((sum_k A[m, k] * dq(Wq[n, k])) * w_scale[n] + bias[n]) (+ residual)
+ * i.e. what F.linear(x, (Wq.float() * w_scale[:, None])) computes with the scale factored out of the sum (every e4m3 value
+ * is exactly a bf16 value, products accumulate in fp32).  The reference has no fp8 path: this is the weight format of the
+ * configs[4] deployment; parity is against the oracle run on the dequantised weights.  M <= 32 (decode) streams the bytes;
+ * larger M expands them to bf16 in `scratch` (eilev_linear_w8_scratch_bytes) and runs the bf16 kernels.  a / bias /
+ * residual / c as in eilev_linear; epilogue 0 none, 1 erf-GELU, 2 ReLU. */
+size_t eilev_linear_w8_scratch_bytes(int64_t m, int64_t n, int64_t k);
+int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_scale, const void *bias, const void *residual, void *c, int64_t m,
+                    int64_t n, int64_t k, int epilogue, int out_f32, void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- stage 0: frames -> pixel_values (device-side process()) -------------------------------------------
  * Replaces the image half of process() (ref:eilev/model/utils.py:5-26: frames flattened into the HF image batch,
  * Blip2Processor -> BlipImageProcessor: PIL BICUBIC resize to size x size on uint8, x * (1/255), (x - mean) / std

@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""GPU probe: decode-step (M = 8) linear layers: achieved weight-streaming bandwidth."""
+"""GPU probe: decode-step linear layers (M rows): achieved weight-streaming bandwidth, bf16 weights and fp8 (e4m3) weights.
+
+    python tools/skinny_probe.py [M]
+"""
 import ctypes as C
 import os
 import sys
@@ -30,4 +33,17 @@ for name, n, k in [("qkv", 7680, 2560), ("out", 2560, 2560), ("fc1", 10240, 2560
             lib.eilev_linear(P(a), P(w), P(b), None, P(o), M, n, k, 0, 0, st())
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * copies)
-    print(f"{name:8s} N={n:6d} K={k:6d}: {us:7.1f} us  {n*k*2/us/1e6:6.2f} TB/s", flush=True)
+    # fp8 weights (eilev_linear_w8): half the bytes
+    from eilev_amd import quant
+    qs = [quant.quantize_e4m3_per_channel(w) for w in ws]
+    nb = lib.eilev_linear_w8_scratch_bytes(M, n, k)
+    scr = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+    for q, sc in qs:
+        lib.eilev_linear_w8(P(a), P(q), P(sc), P(b), None, P(o), M, n, k, 0, 0, P(scr), nb, st())
+    e0.record()
+    for _ in range(reps):
+        for q, sc in qs:
+            lib.eilev_linear_w8(P(a), P(q), P(sc), P(b), None, P(o), M, n, k, 0, 0, P(scr), nb, st())
+    e1.record(); torch.cuda.synchronize()
+    us8 = e0.elapsed_time(e1) * 1e3 / (reps * copies)
+    print(f"{name:8s} N={n:6d} K={k:6d}: bf16 {us:7.1f} us  {n*k*2/us/1e6:6.2f} TB/s | fp8 {us8:7.1f} us  {n*k/us8/1e6:6.2f} TB/s  ({us/us8:.2f}x)", flush=True)
