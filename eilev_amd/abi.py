@@ -56,9 +56,13 @@ class QfWeights(C.Structure):
     _fields_ = [("query_tokens", vp), ("ln_w", vp), ("ln_b", vp), ("layers", C.POINTER(QfLayer))]
 
 
+class OptLayerW8(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_w8", "qkv_scale", "o_w8", "o_scale", "fc1_w8", "fc1_scale", "fc2_w8", "fc2_scale")]
+
+
 class OptWeights(C.Structure):
     _fields_ = [("embed_tokens", vp), ("embed_positions", vp), ("final_ln_w", vp), ("final_ln_b", vp),
-                ("layers", C.POINTER(OptLayer))]
+                ("layers", C.POINTER(OptLayer)), ("layers_w8", C.POINTER(OptLayerW8)), ("w8_expand", vp), ("w8_expand_bytes", C.c_size_t)]
 
 
 class T5Dims(C.Structure):
@@ -208,7 +212,7 @@ class WeightPack:
                 addr("language_model.model.decoder.embed_positions.weight"),
                 addr("language_model.model.decoder.final_layer_norm.weight"),
                 addr("language_model.model.decoder.final_layer_norm.bias"),
-                C.cast(self._opt_layers, C.POINTER(OptLayer)))
+                C.cast(self._opt_layers, C.POINTER(OptLayer)), None, None, 0)
             self.embed_tokens = self.opt.embed_tokens
         else:
             self._t5_layers = {}
@@ -243,6 +247,19 @@ EXPORTS = [
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8",
 ]
+
+
+def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int):
+    """Point ``pack.opt`` at fp8 (e4m3) linears: per_layer = [{"qkv": (bytes_ptr, scale_ptr), "o": ..., "fc1": ..., "fc2": ...}, ...]."""
+    arr = (OptLayerW8 * len(per_layer))()
+    for i, d in enumerate(per_layer):
+        for name in ("qkv", "o", "fc1", "fc2"):
+            setattr(arr[i], f"{name}_w8", d[name][0])
+            setattr(arr[i], f"{name}_scale", d[name][1])
+    pack._opt_layers_w8 = arr
+    pack.opt.layers_w8 = C.cast(arr, C.POINTER(OptLayerW8))
+    pack.opt.w8_expand = expand_ptr
+    pack.opt.w8_expand_bytes = expand_bytes
 
 
 def bind(lib: C.CDLL) -> C.CDLL:
@@ -313,7 +330,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 1:
+    if lib.eilev_abi_version() != 2:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

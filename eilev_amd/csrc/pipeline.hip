@@ -351,13 +351,34 @@ bool carve_opt(const EilevDims *d, int64_t M, void *ws, size_t bytes, OptBufs &b
     return cv.ok();
 }
 
+// fp8 form of a linear (EilevOptLayerW8): bytes + per-channel scales; large-M calls expand into w->w8_expand
+int use_w8(GemmArgs &g, const EilevOptWeights *w, const uint8_t *w8, const float *sc) {
+    if (!w8 || !sc) return EILEV_E_BADARG;
+    if (g.M > 32 || g.K % 256 != 0) {
+        if (!w->w8_expand || w->w8_expand_bytes < (size_t)g.N * g.K * sizeof(bf16)) return EILEV_E_WORKSPACE;
+        g.w8_scratch = (bf16 *)w->w8_expand;
+    }
+    g.W8 = w8;
+    g.wscale = sc;
+    g.ldw = g.K;
+    return EILEV_OK;
+}
+
 // q|k|v projection of x into b.qkv (q pre-scaled by head_dim^-0.5, hf modeling_opt.py:151)
-int opt_qkv(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_t M, hipStream_t s) {
+int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
     const int D = d->t_hidden;
     const float scaling = 1.0f / sqrtf((float)(D / d->t_heads));
     const bf16 *qw = (const bf16 *)L->q_w;
-    const bool fused = (const bf16 *)L->k_w == qw + (size_t)D * D && (const bf16 *)L->v_w == qw + 2 * (size_t)D * D &&
-                       (const bf16 *)L->k_b == (const bf16 *)L->q_b + D && (const bf16 *)L->v_b == (const bf16 *)L->q_b + 2 * D;
+    const bool bias_fused = (const bf16 *)L->k_b == (const bf16 *)L->q_b + D && (const bf16 *)L->v_b == (const bf16 *)L->q_b + 2 * D;
+    if (w->layers_w8) {
+        if (!bias_fused && (L->q_b || L->k_b || L->v_b)) return EILEV_E_UNSUPPORTED;  // fp8 q|k|v is one matrix: one bias vector
+        GemmArgs g = mk_gemm(b.x, D, nullptr, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
+        g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+        RC(use_w8(g, w, w->layers_w8[l].qkv_w8, w->layers_w8[l].qkv_scale));
+        return launch_gemm(g, 5, s);
+    }
+    const bool fused = (const bf16 *)L->k_w == qw + (size_t)D * D && (const bf16 *)L->v_w == qw + 2 * (size_t)D * D && bias_fused;
     if (fused) {
         GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
         g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
@@ -375,17 +396,22 @@ int opt_qkv(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_
 }
 
 // out_proj + residual, LN, fc1 + ReLU, fc2 + residual (hf modeling_opt.py:178-179, 226-247)
-int opt_tail(const EilevDims *d, const EilevOptLayer *L, const OptBufs &b, int64_t M, hipStream_t s) {
+int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
+    const EilevOptLayerW8 *Q = w->layers_w8 ? &w->layers_w8[l] : nullptr;
     const int D = d->t_hidden, Ft = d->t_ffn;
     GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale));
     RC(launch_gemm(g, 5, s));
     RC(launch_layernorm(b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, b.x, D, M, D, d->t_eps, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale));
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (Q) RC(use_w8(g, w, Q->fc2_w8, Q->fc2_scale));
     return launch_gemm(g, 5, s);
 }
 
@@ -410,7 +436,7 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, M, D, d->t_eps, s));
-        RC(opt_qkv(d, L, b, M, s));
+        RC(opt_qkv(d, w, l, b, M, s));
         RC(launch_kv_write(b.qkv, kc, vc, (int)batch, (int)seq_len, H, hd, (int)kv_capacity, (int)seq_len, nullptr, s));
         AttnArgs a;
         a.q = b.qkv; a.k = b.qkv + D; a.v = b.qkv + 2 * D; a.o = b.att;
@@ -420,7 +446,7 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         a.batch = (int)batch; a.heads = H; a.sq = (int)seq_len; a.skv = (int)seq_len; a.hd = hd; a.scale = 1.0f; a.causal = 1;
         a.key_mask = attn_mask; a.mask_ld = seq_len;
         RC(launch_attention(a, s));
-        RC(opt_tail(d, L, b, M, s));
+        RC(opt_tail(d, w, l, b, M, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, M, D, d->t_eps, s));
     if (logits_all) {
@@ -459,7 +485,7 @@ extern "C" int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, co
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, M, D, d->t_eps, s));
-        RC(opt_qkv(d, L, b, M, s));
+        RC(opt_qkv(d, w, l, b, M, s));
         RC(launch_kv_write(b.qkv, kc, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)total, nullptr, s, (int)past_len));
         // queries: the new rows (in the q|k|v buffer); keys / values: the cache, slots [0, total)
         AttnArgs a;
@@ -471,7 +497,7 @@ extern "C" int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, co
         a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
         a.key_mask = attn_mask; a.mask_ld = total; a.dbg = 0;
         RC(launch_attention(a, s));
-        RC(opt_tail(d, L, b, M, s));
+        RC(opt_tail(d, w, l, b, M, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, M, D, d->t_eps, s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits_all, d->vocab, M, d->vocab, D, 0);
@@ -508,11 +534,11 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
-        RC(opt_qkv(d, L, b, batch, s));
+        RC(opt_qkv(d, w, l, b, batch, s));
         RC(launch_kv_write(b.qkv, kc, vc, (int)batch, 1, H, hd, (int)kv_capacity, (int)seq_len, state, s));
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
                               b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s));
-        RC(opt_tail(d, L, b, batch, s));
+        RC(opt_tail(d, w, l, b, batch, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, batch, D, d->t_eps, s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);

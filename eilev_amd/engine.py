@@ -20,7 +20,7 @@ def _ptr(t):
 class HipEngine:
     """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
 
-    def __init__(self, config, named_tensors: dict, device=None, parts=None):
+    def __init__(self, config, named_tensors: dict, device=None, parts=None, lm_weights: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = abi.load_hip()
@@ -39,7 +39,14 @@ class HipEngine:
         self._decode_warm = False
         self._dec_cache = None  # most recent captured decode step + the buffers it is bound to
         self.parts = tuple(parts)
+        if lm_weights not in ("bf16", "fp8"):
+            raise ValueError("lm_weights must be 'bf16' or 'fp8'")
+        if lm_weights == "fp8" and (self.is_t5 or "opt" not in self.parts):
+            raise NotImplementedError("fp8 weights are built for the OPT language model")
+        self.lm_weights = lm_weights
         self._load(named_tensors)
+        if lm_weights == "fp8":
+            self._quantize_opt()
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
     # ---- weights ------------------------------------------------------------------------------------
@@ -101,6 +108,29 @@ class HipEngine:
         t5d = self.t5dims if (self.is_t5 and "t5" in self.parts) else None
         self.pack = abi.WeightPack(d, addr_t5 if t5d is not None else addr, t5d)
         self._keep = store
+
+    def _quantize_opt(self):
+        """fp8 (e4m3) weights for the OPT linears (BASELINE configs[4]): per output channel absmax / 448 scales
+        (eilev_amd/quant.py); q|k|v as one [3 D, D] matrix.  Embeddings / lm_head, LayerNorms and biases stay bf16."""
+        from .quant import quantize_e4m3_per_channel
+
+        d = self.dims
+        per_layer, keep = [], []
+        for i in range(d.t_layers):
+            p = abi.OPT_PREFIX.format(i)
+            w = lambda k: self._keep[p + k]
+            mats = {"qkv": torch.cat([w("self_attn.q_proj.weight"), w("self_attn.k_proj.weight"), w("self_attn.v_proj.weight")], 0),
+                    "o": w("self_attn.out_proj.weight"), "fc1": w("fc1.weight"), "fc2": w("fc2.weight")}
+            entry = {}
+            for name, m in mats.items():
+                q, sc = quantize_e4m3_per_channel(m)
+                keep += [q, sc]
+                entry[name] = (q.data_ptr(), sc.data_ptr())
+            per_layer.append(entry)
+        nb = max(d.t_ffn, 3 * d.t_hidden) * d.t_hidden * 2
+        expand = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        self._w8_keep = (keep, expand)
+        abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb)
 
     # ---- workspaces ----------------------------------------------------------------------------------
     def _workspace(self, tag, nbytes):

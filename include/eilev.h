@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 1
+#define EILEV_ABI_VERSION 2
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -102,11 +102,26 @@ typedef struct EilevOptLayer {
     const void *fc1_w, *fc1_b, *fc2_w, *fc2_b;           /* [Ft,Dt], [Dt,Ft] */
 } EilevOptLayer;
 
+/* Optional fp8 (OCP e4m3) form of the four linears of a block (eilev_linear_w8: one fp32 scale per output channel).  q|k|v are
+ * one [3 Dt, Dt] matrix (rows q, k, v).  The biases stay the bf16 ones of EilevOptLayer. */
+typedef struct EilevOptLayerW8 {
+    const uint8_t *qkv_w8; const float *qkv_scale;   /* [3 Dt, Dt], [3 Dt] */
+    const uint8_t *o_w8;   const float *o_scale;     /* [Dt, Dt] */
+    const uint8_t *fc1_w8; const float *fc1_scale;   /* [Ft, Dt] */
+    const uint8_t *fc2_w8; const float *fc2_scale;   /* [Dt, Ft] */
+} EilevOptLayerW8;
+
 typedef struct EilevOptWeights {
     const void *embed_tokens;      /* [vocab, Dt]; also the tied lm_head */
     const void *embed_positions;   /* [max_pos + 2, Dt] */
     const void *final_ln_w, *final_ln_b;
     const EilevOptLayer *layers;   /* host array, t_layers entries */
+    /* NULL: bf16 weights.  Else a host array of t_layers entries: the q/k/v/out_proj/fc1/fc2 WEIGHT pointers of `layers` are
+     * ignored (they may be NULL) and the fp8 matrices are used (decode streams the bytes; prefill expands one matrix at a time
+     * into w8_expand, at least max(Ft, 3 Dt) * Dt * 2 bytes of device memory).  ABI version 2. */
+    const EilevOptLayerW8 *layers_w8;
+    void *w8_expand;
+    size_t w8_expand_bytes;
 } EilevOptWeights;
 
 int eilev_abi_version(void);
