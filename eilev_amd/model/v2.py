@@ -250,12 +250,13 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
     def engine(self):
         """bf16 device copy of the weights + the HIP library; rebuilt when a parameter changed (optimizer step,
         load_state_dict, .to())."""
-        key = _params_key(self)
+        lm_weights = getattr(self, "hip_lm_weights", "bf16")  # "fp8": e4m3 weight-only OPT linears (set the attribute before use)
+        key = (_params_key(self), lm_weights)
         if self._hip is None or self._hip[0] != key:
             from ..engine import HipEngine
 
             _require_gpu(self.query_tokens, type(self).__name__)
-            self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device))
+            self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device, lm_weights=lm_weights))
         return self._hip[1]
 
     def _encode(self, pixel_values, input_ids, video_input_mask):

@@ -145,3 +145,22 @@ def test_opt_pipeline_with_fp8_weights_matches_oracle_on_dequantised_weights(gol
     assert alive.sum() >= 1
     ids_g = eng.greedy_decode(emb, am, meta["new_tokens"], eos_id=-1, use_graph=True)  # and under the captured graph
     assert torch.equal(ids_g, ids)
+
+
+@pytest.mark.gpu
+def test_model_class_switches_to_fp8_weights(golden_dir):
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from hip_utils import load_case
+
+    g, meta, px = load_case(golden_dir, "tiny_b2")
+    torch.manual_seed(0)
+    model = VideoBlipForConditionalGeneration(blip2_config(meta["config"])).to(torch.bfloat16).cuda().eval()
+    kw = dict(input_ids=torch.from_numpy(g["input_ids"]).cuda(), attention_mask=torch.from_numpy(g["attention_mask"]).cuda(),
+              pixel_values=torch.from_numpy(px).cuda().to(torch.bfloat16), video_input_mask=torch.from_numpy(g["video_input_mask"]).cuda())
+    ref = model(**kw).logits.float()
+    model.hip_lm_weights = "fp8"
+    got = model(**kw).logits.float()
+    assert model.engine().lm_weights == "fp8"
+    rel = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert 0 < rel < 0.2  # e4m3 weights (3 mantissa bits) perturb the logits, they do not scramble them
