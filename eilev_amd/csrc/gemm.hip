@@ -1280,7 +1280,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs a) {
 // reads of 16 rows x 512-byte stride are bank-conflict-free.
 // MB = 1: M <= 16; MB = 2: M <= 32 (two 16-row activation tiles share every weight fragment: the weight stream, which
 // bounds the kernel, is read once for twice the rows)
-template <int MB>
+// PRE: a wave has at most 3 K-tiles (every decode shape): ALL its activation fragments are loaded up front (one exposed L2 round trip
+// instead of one per tile: the per-tile loads were 40 % of the kernel) and the tile loop is three static iterations.  Same summation
+// order as the rolled form.
+template <int MB, bool PRE>
 __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     __shared__ __attribute__((aligned(16))) char wbuf[4][2][8192];
@@ -1321,27 +1324,61 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
         ap[mb] = g.A + (int64_t)(arow[mb] ? r : 0) * g.lda + lg * 8;
         acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (beg < end) stage_in(0, beg);
-    for (int t = beg; t < end; ++t) {
-        const int cur = (t - beg) & 1;
-        bf16x8 av[MB][8];
+    if constexpr (PRE) {
+        bf16x8 av[MB][24];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int tt = 0; tt < 3; ++tt)
+            if (beg + tt < end) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
-        if (t + 1 < end) {
-            stage_in(cur ^ 1, t + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile t (older than the 8 just issued)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        av[mb][tt * 8 + u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + (beg + tt) * 256 + u * 32) : zero8();
+            }
+        if (beg < end) stage_in(0, beg);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int t = beg + tt;
+            if (t < end) {
+                if (t + 1 < end) {
+                    stage_in((tt & 1) ^ 1, t + 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile t and every activation fragment (older) have landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const char *wb = &wbuf[wid][tt & 1][0] + l15 * 512;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][tt * 8 + u], wv, acc[mb], 0, 0, 0);
+                }
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        const char *wb = &wbuf[wid][cur][0] + l15 * 512;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
+    } else {
+    if (beg < end) stage_in(0, beg);
+        for (int t = beg; t < end; ++t) {
+            const int cur = (t - beg) & 1;
+            bf16x8 av[MB][8];
+    #pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
+            if (t + 1 < end) {
+                stage_in(cur ^ 1, t + 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 pieces of tile t (older than the 8 just issued)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const char *wb = &wbuf[wid][cur][0] + l15 * 512;
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
+    #pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -1369,7 +1406,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
 // 4 KiB (half the bytes of the bound stream).  Piece i = rows 4i .. 4i+3 x 256 B; 16-byte chunk c of row r is stored at chunk
 // c ^ (r & 15).  A lane's 8 weights of an MFMA k-step are 8 bytes: v_cvt_pk_f32_fp8 + one v_perm_b32 per pair make the bf16
 // fragment (every e4m3 value is exactly a bf16 value); the per-channel scale is applied to the fp32 sum in the epilogue.
-template <int MB>
+template <int MB, bool PRE>
 __global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     __shared__ __attribute__((aligned(16))) char wbuf[4][2][4096];
@@ -1408,40 +1445,85 @@ __global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a)
         ap[mb] = g.A + (int64_t)(arow[mb] ? r : 0) * g.lda + lg * 8;
         acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (beg < end) stage_in(0, beg);
-    for (int t = beg; t < end; ++t) {
-        const int cur = (t - beg) & 1;
-        bf16x8 av[MB][8];
+    if constexpr (PRE) {
+        bf16x8 av[MB][24];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int tt = 0; tt < 3; ++tt)
+            if (beg + tt < end) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
-        if (t + 1 < end) {
-            stage_in(cur ^ 1, t + 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the 4 pieces of tile t (older than the 4 just issued)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const char *wb = &wbuf[wid][cur][0] + l15 * 256 + (lg & 1) * 8;
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            const u32x2_t q = *reinterpret_cast<const u32x2_t *>(wb + (((u * 2 + (lg >> 1)) ^ l15) << 4));
-            u32x4_t wbits;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // (element reads through float variables: __builtin_bit_cast of a vector subscript picks element 0 twice here)
-                const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
-                const float l0 = lo.x, l1 = lo.y, h0 = hi2.x, h1 = hi2.y;
-                // bf16 pair = high halves of the two floats (exact)
-                wbits[2 * h] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-                wbits[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
+                    for (int u = 0; u < 8; ++u)
+                        av[mb][tt * 8 + u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + (beg + tt) * 256 + u * 32) : zero8();
             }
-            const bf16x8 wv = __builtin_bit_cast(bf16x8, wbits);
+        if (beg < end) stage_in(0, beg);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
+        for (int tt = 0; tt < 3; ++tt) {
+            const int t = beg + tt;
+            if (t < end) {
+                if (t + 1 < end) {
+                    stage_in((tt & 1) ^ 1, t + 1);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const char *wb = &wbuf[wid][tt & 1][0] + l15 * 256 + (lg & 1) * 8;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                    const u32x2_t q = *reinterpret_cast<const u32x2_t *>(wb + (((u * 2 + (lg >> 1)) ^ l15) << 4));
+                    u32x4_t wbits;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
+                        const float l0 = lo.x, l1 = lo.y, h0 = hi2.x, h1 = hi2.y;
+                        wbits[2 * h] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+                        wbits[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
+                    }
+                    const bf16x8 wv = __builtin_bit_cast(bf16x8, wbits);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][tt * 8 + u], wv, acc[mb], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+    if (beg < end) stage_in(0, beg);
+        for (int t = beg; t < end; ++t) {
+            const int cur = (t - beg) & 1;
+            bf16x8 av[MB][8];
+    #pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) av[mb][u] = arow[mb] ? *reinterpret_cast<const bf16x8 *>(ap[mb] + t * 256 + u * 32) : zero8();
+            if (t + 1 < end) {
+                stage_in(cur ^ 1, t + 1);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the 4 pieces of tile t (older than the 4 just issued)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const char *wb = &wbuf[wid][cur][0] + l15 * 256 + (lg & 1) * 8;
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                const u32x2_t q = *reinterpret_cast<const u32x2_t *>(wb + (((u * 2 + (lg >> 1)) ^ l15) << 4));
+                u32x4_t wbits;
+    #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // (element reads through float variables: __builtin_bit_cast of a vector subscript picks element 0 twice here)
+                    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
+                    const float l0 = lo.x, l1 = lo.y, h0 = hi2.x, h1 = hi2.y;
+                    // bf16 pair = high halves of the two floats (exact)
+                    wbits[2 * h] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+                    wbits[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
+                }
+                const bf16x8 wv = __builtin_bit_cast(bf16x8, wbits);
+    #pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv, acc[mb], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -1565,10 +1647,22 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         if (ks > 1 && (!g.scratch || (size_t)ks * a.mr * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
         a.ks = ks;
         a.part = g.scratch;
-        if (g.W8 && g.M > 16) hipLaunchKernelGGL(gemm_skinny_w8_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
-        else if (g.W8) hipLaunchKernelGGL(gemm_skinny_w8_kernel<1>, dim3(nb, ks), dim3(256), 0, s, a);
-        else if (dma_ok && g.M > 16) hipLaunchKernelGGL(gemm_skinny_dma_kernel<2>, dim3(nb, ks), dim3(256), 0, s, a);
-        else if (dma_ok) hipLaunchKernelGGL(gemm_skinny_dma_kernel<1>, dim3(nb, ks), dim3(256), 0, s, a);
+        // tiles of 256 per wave: ceil(ceil(K / 256 / ks) / 4); up to 3 (every decode shape) the activations are preloaded
+        const int per_w = ((g.K / 256 + ks - 1) / ks + 3) / 4;
+        const bool pre = per_w <= 3 && !(g.dbg & 128);
+        if (g.W8 && g.M > 16) {
+            if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        } else if (g.W8) {
+            if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        } else if (dma_ok && g.M > 16) {
+            if (pre) hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        } else if (dma_ok) {
+            if (pre) hipLaunchKernelGGL((gemm_skinny_dma_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_dma_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        }
         else hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
         if (ks > 1) {
