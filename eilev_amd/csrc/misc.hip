@@ -654,6 +654,47 @@ __global__ void resample_h_kernel(const uint8_t *__restrict__ src, uint8_t *__re
     *reinterpret_cast<unsigned *>(dst + row * w_out + x0) = packed;
 }
 
+// Horizontal pass, tiled: a workgroup stages 32 consecutive input rows (one contiguous block of the plane-major tensor, read
+// with coalesced 16-byte loads) in LDS; thread xx owns output column xx of all 32 rows: each tap's coefficient is read once and
+// applied to the 32 row accumulators (byte reads from LDS), the 32 x w_out result tile leaves through LDS as coalesced stores.
+__global__ __launch_bounds__(256) void resample_h_tile_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                              const int32_t *__restrict__ coef, const int32_t *__restrict__ bounds, int ksize,
+                                                              int64_t rows, int w_in, int w_out) {
+    constexpr int R = 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t rs_smem[];
+    uint8_t *in = rs_smem;                                    // [R][w_in]
+    uint8_t *outp = rs_smem + (((size_t)R * w_in + 15) & ~(size_t)15);  // [R][w_out]
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
+    const int64_t nbytes = (int64_t)nrow * w_in;
+    const uint8_t *base = src + row0 * w_in;                  // 16-byte aligned: R * w_in is a multiple of 32
+    for (int64_t i = (int64_t)threadIdx.x * 16; i < nbytes; i += 256 * 16) {
+        if (i + 16 <= nbytes) *reinterpret_cast<uint4 *>(in + i) = *reinterpret_cast<const uint4 *>(base + i);
+        else for (int64_t j = i; j < nbytes; ++j) in[j] = base[j];
+    }
+    __syncthreads();
+    for (int xx = threadIdx.x; xx < w_out; xx += 256) {
+        const int xmin = bounds[xx * 2], n = bounds[xx * 2 + 1];
+        const int32_t *k = coef + (int64_t)xx * ksize;
+        int acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 1 << (kResampleBits - 1);
+        for (int x = 0; x < n; ++x) {
+            const int c = k[x];
+            const uint8_t *s = in + xmin + x;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += (int)s[r * w_in] * c;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) outp[r * w_out + xx] = (uint8_t)clip8(acc[r]);
+    }
+    __syncthreads();
+    const int64_t obytes = (int64_t)nrow * w_out;             // contiguous in dst too; w_out % 4 == 0
+    uint8_t *obase = dst + row0 * w_out;
+    for (int64_t i = (int64_t)threadIdx.x * 4; i < obytes; i += 256 * 4)
+        *reinterpret_cast<unsigned *>(obase + i) = *reinterpret_cast<const unsigned *>(outp + i);
+}
+
 // 4 adjacent columns per thread: 4-byte loads per tap, one 16-byte (fp32) / 8-byte (bf16) store; w % 4 == 0
 template <typename OutT>
 __global__ void resample_v_lut_kernel(const uint8_t *__restrict__ src, OutT *__restrict__ dst, const int32_t *__restrict__ coef,
@@ -713,8 +754,13 @@ extern "C" int eilev_process_frames(const uint8_t *video, int64_t batch, int64_t
     if (coef_h) {
         if (!workspace || workspace_bytes < eilev_process_workspace_bytes(batch, frames, h_in, w_out)) return EILEV_E_WORKSPACE;
         const int64_t rows = planes * h_in, total = rows * (w_out / 4);
-        hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, (uint8_t *)workspace, coef_h,
-                           bounds_h, ksize_h, rows, (int)w_in, (int)w_out);
+        const size_t tile_lds = (((size_t)32 * w_in + 15) & ~(size_t)15) + (size_t)32 * w_out;
+        if (tile_lds <= 64 * 1024 && ((uintptr_t)video & 15) == 0 && ((uintptr_t)workspace & 3) == 0)
+            hipLaunchKernelGGL(resample_h_tile_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), tile_lds, s, video, (uint8_t *)workspace, coef_h,
+                               bounds_h, ksize_h, rows, (int)w_in, (int)w_out);
+        else
+            hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, (uint8_t *)workspace, coef_h,
+                               bounds_h, ksize_h, rows, (int)w_in, (int)w_out);
         EILEV_LAUNCH_CHECK();
         mid = (const uint8_t *)workspace;
     }
