@@ -245,7 +245,8 @@ EXPORTS = [
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
-    "eilev_linear_w8_scratch_bytes", "eilev_linear_w8",
+    "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
+    "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss",
 ]
 
 
@@ -306,6 +307,18 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_layernorm.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.eilev_attention.restype = i32
     lib.eilev_attention.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
+    lib.eilev_attention_bwd.restype = i32
+    lib.eilev_attention_bwd.argtypes = [vp] * 9 + [i64] * 11 + [f32, i32, vp, vp]
+    lib.eilev_layernorm_bwd.restype = i32
+    lib.eilev_layernorm_bwd.argtypes = [vp] * 7 + [i64, i64, f32, vp]
+    lib.eilev_colsum.restype = i32
+    lib.eilev_colsum.argtypes = [vp, vp, i64, i64, vp]
+    lib.eilev_act_fwd.restype = i32
+    lib.eilev_act_fwd.argtypes = [vp, vp, i64, i32, vp]
+    lib.eilev_act_bwd.restype = i32
+    lib.eilev_act_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.eilev_ce_loss.restype = i32
+    lib.eilev_ce_loss.argtypes = [vp, vp, f32, vp, vp, i64, i64, vp]
     TP = C.POINTER(T5Dims)
     lib.eilev_t5_workspace_bytes.restype = sz
     lib.eilev_t5_workspace_bytes.argtypes = [TP, i64, i64, i64]
@@ -330,7 +343,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 2:
+    if lib.eilev_abi_version() != 3:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

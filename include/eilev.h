@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 2
+#define EILEV_ABI_VERSION 3
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -308,6 +308,34 @@ int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y,
 int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads,
                     int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
                     float scale, int causal, const int32_t *key_mask, void *stream);
+
+/* ---- gradient building blocks of the train_v2 path -------------------------------------------------
+ * ref:scripts/general/train_v2.py:124-130,207-217: `loss = model(**batch).loss; accelerator.backward(loss)` with the
+ * ViT and the language model frozen (gradients flow *through* the LM to the Q-Former, language projection and query
+ * tokens).  These are what torch.autograd runs for the modules on the path; a linear layer's dX = dY . W and
+ * dW = dY^T . X are eilev_linear calls on transposed operands (eilev_amd/autograd.py).  bf16 tensors (HIP) / f32 (oracle).
+ *
+ * eilev_attention_bwd: gradients of eilev_attention (same layout arguments; o and d_o are (batch, sq, heads*head_dim);
+ *   dq/dk/dv rows have strides lddq/lddk/lddv with head h at column h*head_dim).  P is recomputed from q, k and the row
+ *   log-sum-exp; lse_delta is a (2, batch, heads, sq) f32 workspace (out: lse, then delta = sum_d o * d_o).
+ * eilev_layernorm_bwd: dx of nn.LayerNorm (hf modeling_opt.py:215,226,387; modeling_blip_2.py:619,675,913); when dgamma
+ *   and dbeta (f32, cols) are given their gradients are ACCUMULATED into them, with stats a (rows, 2) f32 workspace.
+ * eilev_colsum: out[c] += sum_r dy[r, c] (bias gradient; f32, accumulated).
+ * eilev_act_fwd / eilev_act_bwd: y = act(pre) / dx = dy * act'(pre); kind 1 erf-GELU, 2 ReLU.
+ * eilev_ce_loss: hf loss_utils.ForCausalLMLoss per row: row_loss[r] = logsumexp(logits[r]) - logits[r, target[r]],
+ *   dlogits[r] = (softmax(logits[r]) - onehot(target[r])) * grad_scale; rows with target < 0 (ignore_index -100) get 0. */
+int eilev_attention_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq,
+                        void *dk, void *dv, float *lse_delta, int64_t batch, int64_t heads, int64_t sq,
+                        int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq,
+                        int64_t lddk, int64_t lddv, float scale, int causal, const int32_t *key_mask,
+                        void *stream);
+int eilev_layernorm_bwd(const void *x, const void *gamma, const void *dy, void *dx, float *dgamma, float *dbeta,
+                        float *stats, int64_t rows, int64_t cols, float eps, void *stream);
+int eilev_colsum(const void *dy, float *out, int64_t rows, int64_t cols, void *stream);
+int eilev_act_fwd(const void *pre, void *y, int64_t n, int kind, void *stream);
+int eilev_act_bwd(const void *pre, const void *dy, void *dx, int64_t n, int kind, void *stream);
+int eilev_ce_loss(const float *logits, const int64_t *targets, float grad_scale, float *row_loss, void *dlogits,
+                  int64_t rows, int64_t vocab, void *stream);
 
 /* ---- kernel profiler (HIP library; no-ops returning 0 in the oracle) ----------------------------
  * When enabled, the dominant GEMM launches are bracketed with hipEvents on the launch stream.
