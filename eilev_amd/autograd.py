@@ -1,0 +1,263 @@
+"""torch.autograd bindings of the HIP kernels for the train_v2 path.
+
+ref:scripts/general/train_v2.py:124-130 freezes the ViT and the language model and trains the Q-Former, the query
+tokens and the language projection; `accelerator.backward(loss)` therefore needs parameter gradients for ~107 M
+parameters and *activation* gradients through the whole frozen LM.  Autograd is kept as the bookkeeping (graph,
+gradient accumulation into `.grad`), every gradient itself is computed by libeilev_hip.so:
+
+  linear      y = x W^T + b (+ residual)     dX = dY . W         eilev_linear(dY, W^T)
+                                             dW = dY^T . X       eilev_linear(dY^T, X^T) -> f32
+                                             db = colsum(dY)     eilev_colsum
+  layer_norm                                 eilev_layernorm_bwd (dx; dgamma/dbeta when trainable)
+  attention   softmax(scale q k^T + mask) v  eilev_attention_bwd (P recomputed)
+  act         GELU(erf) / ReLU               eilev_act_fwd / eilev_act_bwd
+  lm_head_ce  mean CE of rows . E^T          eilev_linear (f32 logits) + eilev_ce_loss, dRows = dLogits . E
+
+All activations are bf16; a trainable parameter may be an fp32 master copy (cast to bf16 for the kernels, gradient returned
+in the parameter's dtype).  No fallback: tensors must live on the GPU and the HIP library must load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import abi
+
+_BF = torch.bfloat16
+_tcache: dict = {}      # per-step transposes of activations shared by several linears (cleared by new_step())
+_frozen_t: dict = {}    # transposes of frozen weights, kept for the life of the process
+
+
+def new_step() -> None:
+    _tcache.clear()
+
+
+def _lib():
+    return abi.load_hip()
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the training path runs on the GPU only (got a {t.device} tensor)")
+    if t.dtype != _BF:
+        raise TypeError(f"{what}: expected bf16 activations, got {t.dtype}")
+    return t.contiguous()
+
+
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    return (t if t.dtype == _BF else t.to(_BF)).contiguous()
+
+
+def _padded_t(x2d: torch.Tensor, cache: bool) -> torch.Tensor:
+    """(M, C) -> (C, ceil64(M)) with zero columns: the K-contiguous operand of a product contracting over rows."""
+    key = (x2d.data_ptr(), x2d._version, tuple(x2d.shape))
+    if cache and key in _tcache:
+        return _tcache[key]
+    M, Cc = x2d.shape
+    Mp = (M + 63) // 64 * 64
+    out = torch.zeros((Cc, Mp), dtype=_BF, device=x2d.device) if Mp != M else torch.empty((Cc, Mp), dtype=_BF, device=x2d.device)
+    out[:, :M].copy_(x2d.t())
+    if cache:
+        _tcache[key] = out
+    return out
+
+
+def _weight_t(weight: torch.Tensor, w16: torch.Tensor) -> torch.Tensor:
+    """W^T (K, N) contiguous.  Frozen weights are transposed once."""
+    if weight.requires_grad:
+        return w16.t().contiguous()
+    key = (weight.data_ptr(), tuple(weight.shape))
+    hit = _frozen_t.get(key)
+    if hit is None:
+        hit = _frozen_t[key] = w16.t().contiguous()
+    return hit
+
+
+def _gemm(a, w, bias, resid, m, n, k, out_f32=False):
+    out = torch.empty((m, n), dtype=torch.float32 if out_f32 else _BF, device=a.device)
+    abi.check(_lib().eilev_linear(_p(a), _p(w), _p(bias), _p(resid), _p(out), m, n, k, 0, int(out_f32), _s()), "eilev_linear")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        x2 = _need(x, "linear").reshape(-1, x.shape[-1])
+        w16 = _bf(weight)
+        N, K = w16.shape
+        M = x2.shape[0]
+        r2 = None if residual is None else _need(residual, "linear residual").reshape(M, N)
+        y = _gemm(x2, w16, None if bias is None else _bf(bias), r2, M, N, K)
+        ctx.save_for_backward(x2, weight, w16 if weight.requires_grad else None)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.has_resid = residual is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, w16 = ctx.saved_tensors
+        if w16 is None:
+            w16 = _bf(weight)
+        N, K = w16.shape
+        dy2 = _need(dy, "linear grad").reshape(-1, N)
+        M = dy2.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(dy2, _weight_t(weight, w16), None, None, M, K, N).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dyt = _padded_t(dy2, cache=False)
+            xt = _padded_t(x2, cache=True)
+            dw = _gemm(dyt, xt, None, None, N, K, dyt.shape[1], out_f32=True).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            acc = torch.zeros(N, dtype=torch.float32, device=dy2.device)
+            abi.check(_lib().eilev_colsum(_p(dy2), _p(acc), M, N, _s()), "eilev_colsum")
+            db = acc.to(ctx.bias_dtype)
+        return dx, dw, db, (dy if ctx.has_resid else None)
+
+
+def linear(x, weight, bias=None, residual=None):
+    return _Linear.apply(x, weight, bias, residual)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = _need(x, "layer_norm").reshape(-1, x.shape[-1])
+        g16, b16 = _bf(gamma), _bf(beta)
+        y = torch.empty_like(x2)
+        abi.check(_lib().eilev_layernorm(_p(x2), _p(g16), _p(b16), _p(y), x2.shape[0], x2.shape[1], float(eps), _s()), "eilev_layernorm")
+        ctx.save_for_backward(x2, g16)
+        ctx.eps = float(eps)
+        ctx.pdtype = (gamma.dtype, beta.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g16 = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = _need(dy, "layer_norm grad").reshape(rows, cols)
+        dx = torch.empty_like(x2)
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = db = st = None
+        if want:
+            dg = torch.zeros(cols, dtype=torch.float32, device=x2.device)
+            db = torch.zeros_like(dg)
+            st = torch.empty((rows, 2), dtype=torch.float32, device=x2.device)
+        abi.check(_lib().eilev_layernorm_bwd(_p(x2), _p(g16), _p(dy2), _p(dx), _p(dg), _p(db), _p(st), rows, cols, ctx.eps, _s()),
+                  "eilev_layernorm_bwd")
+        return (dx.view(dy.shape), dg.to(ctx.pdtype[0]) if ctx.needs_input_grad[1] else None,
+                db.to(ctx.pdtype[1]) if ctx.needs_input_grad[2] else None, None)
+
+
+def layer_norm(x, gamma, beta, eps):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, causal, key_mask):
+        q, k, v = _need(q, "attention q"), _need(k, "attention k"), _need(v, "attention v")
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        hd = D // heads
+        km = None if key_mask is None else key_mask.to(torch.int32).contiguous()
+        o = torch.empty_like(q)
+        abi.check(_lib().eilev_attention(_p(q), _p(k), _p(v), _p(o), B, heads, Sq, Skv, hd, D, D, D, float(scale), int(causal), _p(km), _s()),
+                  "eilev_attention")
+        ctx.save_for_backward(q, k, v, o, km)
+        ctx.cfg = (heads, float(scale), int(causal))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, km = ctx.saved_tensors
+        heads, scale, causal = ctx.cfg
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        hd = D // heads
+        d_o = _need(d_o, "attention grad")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty((2, B, heads, Sq), dtype=torch.float32, device=q.device)
+        abi.check(_lib().eilev_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, Sq, Skv, hd,
+                                             D, D, D, D, D, D, scale, causal, _p(km), _s()), "eilev_attention_bwd")
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, heads, scale, causal=False, key_mask=None):
+    """q (B, Sq, heads*hd), k / v (B, Skv, heads*hd) -> (B, Sq, heads*hd); causal: key <= query + (Skv - Sq)."""
+    return _Attention.apply(q, k, v, heads, scale, causal, key_mask)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, kind):
+        pre = _need(pre, "act")
+        y = torch.empty_like(pre)
+        abi.check(_lib().eilev_act_fwd(_p(pre), _p(y), pre.numel(), kind, _s()), "eilev_act_fwd")
+        ctx.save_for_backward(pre)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pre,) = ctx.saved_tensors
+        dy = _need(dy, "act grad")
+        dx = torch.empty_like(pre)
+        abi.check(_lib().eilev_act_bwd(_p(pre), _p(dy), _p(dx), pre.numel(), ctx.kind, _s()), "eilev_act_bwd")
+        return dx, None
+
+
+def gelu(pre):
+    return _Act.apply(pre, 1)
+
+
+def relu(pre):
+    return _Act.apply(pre, 2)
+
+
+class _LMHeadCE(torch.autograd.Function):
+    """mean_r CE(rows[r] . E^T, targets[r]) over the rows with target >= 0 (hf loss_utils.ForCausalLMLoss after the shift)."""
+
+    @staticmethod
+    def forward(ctx, rows, embed, targets):
+        rows = _need(rows, "lm_head_ce")
+        e16 = _bf(embed)
+        R, D = rows.shape
+        V = e16.shape[0]
+        tg = targets.to(rows.device, torch.int64).contiguous()
+        n_valid = int((tg >= 0).sum().item())
+        if n_valid == 0:
+            raise ValueError("labels contain no supervised position")
+        logits = _gemm(rows, e16, None, None, R, V, D, out_f32=True)
+        row_loss = torch.empty(R, dtype=torch.float32, device=rows.device)
+        dlogits = torch.empty((R, V), dtype=_BF, device=rows.device)
+        abi.check(_lib().eilev_ce_loss(_p(logits), _p(tg), 1.0 / n_valid, _p(row_loss), _p(dlogits), R, V, _s()), "eilev_ce_loss")
+        ctx.save_for_backward(dlogits, embed, e16 if embed.requires_grad else None)
+        return row_loss.sum() / n_valid
+
+    @staticmethod
+    def backward(ctx, g):
+        dlogits, embed, e16 = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("the token embedding / lm_head is frozen on the train_v2 path")
+        if e16 is None:
+            e16 = _bf(embed)
+        R, V = dlogits.shape
+        D = e16.shape[1]
+        drows = _gemm(dlogits, _weight_t(embed, e16), None, None, R, D, V)
+        return drows * g.to(_BF), None, None
+
+
+def lm_head_ce(rows, embed, targets):
+    return _LMHeadCE.apply(rows, embed, targets)

@@ -273,12 +273,39 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         return emb, vision, qf
 
     # ---- API ---------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, input_ids, attention_mask=None, pixel_values=None, video_input_mask=None, decoder_input_ids=None,
                 decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         """pixel_values: (num_videos, C, T, H, W); video_input_mask: (batch, seq_len)  [ref:eilev/model/v2.py:132-252].
 
-        NOTE: runs without autograd — training through the HIP path (Q-Former backward) is not built yet."""
+        With ``labels``, autograd enabled and at least one trainable parameter (the train_v2 setting:
+        ref:scripts/general/train_v2.py:124-130, 207-217) the call returns a loss with a gradient, computed by the training
+        graph of eilev_amd/train.py (logits are not materialised on that route).  Otherwise it runs without autograd."""
+        if labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict)
+        return self._forward_eval(input_ids, attention_mask, pixel_values, video_input_mask, decoder_input_ids, decoder_attention_mask,
+                                  output_attentions, output_hidden_states, labels, return_dict)
+
+    def _forward_train(self, input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict):
+        from ..engine import HipEngine
+        from ..train import TrainGraph
+
+        named = dict(self.named_parameters())
+        params = {k: p for k, p in named.items() if p.requires_grad}
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in named.values() if not p.requires_grad)
+        cached = getattr(self, "_hip_train", None)
+        if cached is None or cached[0] != key:  # frozen weights -> bf16 device copies, once (trainable ones are read live)
+            _require_gpu(self.query_tokens, type(self).__name__)
+            cached = self._hip_train = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device))
+        loss = TrainGraph(cached[1], params).loss(input_ids, attention_mask, pixel_values, video_input_mask, labels)
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if not return_dict:
+            return (loss,)
+        return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=None, vision_outputs=None, qformer_outputs=None,
+                                                        language_model_outputs=CausalLMOutputWithPast(loss=loss, logits=None))
+
+    @torch.no_grad()
+    def _forward_eval(self, input_ids, attention_mask=None, pixel_values=None, video_input_mask=None, decoder_input_ids=None,
+                      decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         if pixel_values is not None:
             assert video_input_mask is not None
         if output_attentions or output_hidden_states:

@@ -1,0 +1,132 @@
+"""Training-mode forward of the hot path: `model(**batch).loss` with a gradient.
+
+ref:scripts/general/train_v2.py:124-130 — the ViT and the language model are frozen, the Q-Former (+ query tokens +
+language projection) trains; ref:eilev/model/v2.py:132-252 is the forward whose loss this reproduces:
+
+    frames -> ViT (frozen: the inference kernels, no graph) -> Q-Former -> language_projection -> scatter into the token
+    embeddings -> OPT decoder (frozen weights, activation gradients) -> shifted token cross-entropy
+
+Everything after the ViT is composed from the autograd-wrapped HIP kernels of eilev_amd/autograd.py, so
+`loss.backward()` runs the gradient kernels of eilev_amd/csrc/backward.hip and leaves `.grad` on the trainable
+parameters exactly as the reference's `accelerator.backward(loss)` does.  Dropout (0.1 in the Q-Former / OPT configs
+while `model.train()`) is NOT applied: the graph is the deterministic eval-mode function, documented in DESIGN.md §5h.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import abi
+from . import autograd as ag
+
+
+class _EmbedScatter(torch.autograd.Function):
+    """inputs_embeds = embed_tokens[input_ids] with the video positions replaced by the projected query tokens
+    [ref:eilev/model/v2.py:316]; the gradient of the video rows is the gather of those positions."""
+
+    @staticmethod
+    def forward(ctx, feats, engine, input_ids, video_mask):
+        vm = (video_mask.to(feats.device) != 0)
+        ctx.save_for_backward(vm)
+        return engine.embed_scatter(input_ids, vm, feats)
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        (vm,) = ctx.saved_tensors
+        return d_emb[vm].contiguous(), None, None, None
+
+
+class TrainGraph:
+    """Loss of one batch on the HIP kernels.  ``params``: trainable tensors by state-dict key (fp32 masters or bf16);
+    every other weight is read from the engine's frozen bf16 copies."""
+
+    def __init__(self, engine, params: dict):
+        if engine.is_t5:
+            raise NotImplementedError("training through the encoder-decoder (T5) language model is not built")
+        self.eng = engine
+        self.params = dict(params)
+        ok = ("qformer.", "query_tokens", "language_projection.")
+        bad = [k for k in self.params if not k.startswith(ok)]
+        if bad:
+            raise NotImplementedError(f"only the Q-Former, query tokens and language projection train on this path (train_v2 freezes the rest): {bad[:3]}")
+
+    def W(self, key):
+        p = self.params.get(key)
+        return p if p is not None else self.eng._keep[key]
+
+    # ---- Q-Former (hf modeling_blip_2.py Blip2QFormerModel: post-LN BERT layers, cross-attention every q_cross_freq) ----
+    def qformer(self, image_embeds: torch.Tensor) -> torch.Tensor:
+        d = self.eng.dims
+        N, kv, Dv = image_embeds.shape
+        D, H, nq = d.q_hidden, d.q_heads, d.num_query
+        scale = (D // H) ** -0.5
+        img = image_embeds.reshape(N * kv, Dv)
+        qt = self.W("query_tokens").reshape(nq, D)
+        q0 = ag.layer_norm(qt.to(torch.bfloat16), self.W("qformer.layernorm.weight"), self.W("qformer.layernorm.bias"), d.q_eps)
+        h = q0.unsqueeze(0).expand(N, nq, D).reshape(N * nq, D)
+        for l in range(d.q_layers):
+            cross = l % d.q_cross_freq == 0
+            k = abi.qf_layer_keys(l, cross)
+            w = lambda f: self.W(k[f])
+            q = ag.linear(h, w("sq_w"), w("sq_b")).view(N, nq, D)
+            kk = ag.linear(h, w("sk_w"), w("sk_b")).view(N, nq, D)
+            v = ag.linear(h, w("sv_w"), w("sv_b")).view(N, nq, D)
+            ctx = ag.attention(q, kk, v, H, scale).view(N * nq, D)
+            h = ag.layer_norm(ag.linear(ctx, w("so_w"), w("so_b"), residual=h), w("sln_w"), w("sln_b"), d.q_eps)
+            if cross:
+                q = ag.linear(h, w("cq_w"), w("cq_b")).view(N, nq, D)
+                kk = ag.linear(img, w("ck_w"), w("ck_b")).view(N, kv, D)
+                v = ag.linear(img, w("cv_w"), w("cv_b")).view(N, kv, D)
+                ctx = ag.attention(q, kk, v, H, scale).view(N * nq, D)
+                h = ag.layer_norm(ag.linear(ctx, w("co_w"), w("co_b"), residual=h), w("cln_w"), w("cln_b"), d.q_eps)
+            f = ag.gelu(ag.linear(h, w("fi_w"), w("fi_b")))
+            h = ag.layer_norm(ag.linear(f, w("fo_w"), w("fo_b"), residual=h), w("fln_w"), w("fln_b"), d.q_eps)
+        return h  # (N * nq, D)
+
+    # ---- OPT decoder with frozen weights (hf modeling_opt.py OPTDecoder: pre-LN, ReLU FFN, learned positions + 2) ----
+    def opt_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        d = self.eng.dims
+        B, L, D = inputs_embeds.shape
+        H = d.t_heads
+        scale = (D // H) ** -0.5
+        am = attention_mask.to(inputs_embeds.device, torch.int64)
+        pos = (torch.cumsum(am, 1) * am - 1 + 2).clamp_(min=0)  # hf OPTLearnedPositionalEmbedding (offset 2)
+        pe = self.W("language_model.model.decoder.embed_positions.weight")
+        h = (inputs_embeds + pe[pos]).reshape(B * L, D)
+        km = am.to(torch.int32)
+        for l in range(d.t_layers):
+            k = abi.opt_layer_keys(l)
+            w = lambda f: self.W(k[f])
+            x = ag.layer_norm(h, w("ln1_w"), w("ln1_b"), d.t_eps)
+            q = ag.linear(x, w("q_w"), w("q_b")).view(B, L, D)
+            kk = ag.linear(x, w("k_w"), w("k_b")).view(B, L, D)
+            v = ag.linear(x, w("v_w"), w("v_b")).view(B, L, D)
+            ctx = ag.attention(q, kk, v, H, scale, causal=True, key_mask=km).view(B * L, D)
+            h = ag.linear(ctx, w("o_w"), w("o_b"), residual=h)
+            x = ag.layer_norm(h, w("ln2_w"), w("ln2_b"), d.t_eps)
+            f = ag.relu(ag.linear(x, w("fc1_w"), w("fc1_b")))
+            h = ag.linear(f, w("fc2_w"), w("fc2_b"), residual=h)
+        return ag.layer_norm(h, self.W("language_model.model.decoder.final_layer_norm.weight"),
+                             self.W("language_model.model.decoder.final_layer_norm.bias"), d.t_eps).view(B, L, D)
+
+    def loss(self, input_ids, attention_mask, pixel_values, video_input_mask, labels) -> torch.Tensor:
+        """Shifted causal-LM cross-entropy (ignore_index -100), differentiable w.r.t. ``params``."""
+        eng = self.eng
+        ag.new_step()
+        dev = eng.device
+        input_ids = input_ids.to(dev)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if pixel_values is not None:
+            if video_input_mask is None:
+                raise ValueError("video_input_mask is required with pixel_values")
+            with torch.no_grad():
+                img = eng.vit(pixel_values)  # frozen: inference kernels, nothing saved
+            feats = ag.linear(self.qformer(img), self.W("language_projection.weight"), self.W("language_projection.bias"))
+            emb = _EmbedScatter.apply(feats, eng, input_ids, video_input_mask)
+        else:
+            emb = eng.embed_scatter(input_ids, None, None)
+        hid = self.opt_hidden(emb, attention_mask)
+        tgt = labels.to(dev)[:, 1:]
+        sel = tgt >= 0  # position t predicts labels[t + 1]
+        rows = hid[:, :-1][sel]
+        return ag.lm_head_ce(rows.contiguous(), self.W("language_model.model.decoder.embed_tokens.weight"), tgt[sel])
