@@ -130,3 +130,44 @@ class TrainGraph:
         sel = tgt >= 0  # position t predicts labels[t + 1]
         rows = hid[:, :-1][sel]
         return ag.lm_head_ce(rows.contiguous(), self.W("language_model.model.decoder.embed_tokens.weight"), tgt[sel])
+
+
+def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20) -> None:
+    """Average ``.grad`` of the trainable parameters over the data-parallel ranks (what DDP / `accelerator.backward`
+    does for ref:scripts/general/train_v2.py under torchrun): gradients are packed into flat fp32 buckets and each bucket
+    is ONE all-reduce (RCCL over xGMI on the GPU box: 107 M parameters = 428 MB -> 7 buckets of 64 MiB, large enough to
+    run at link bandwidth on the ring, small enough to start while later buckets are still being packed).
+    ``params``: iterable of tensors or a dict; parameters without a gradient contribute zeros (a rank whose batch has no
+    video still takes part in every collective)."""
+    import torch.distributed as dist
+
+    ps = [p for p in (params.values() if isinstance(params, dict) else params) if p.requires_grad]
+    if not ps or not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    bucket, size = [], 0
+    buckets = []
+    for p in ps:
+        nb = p.numel() * 4
+        if bucket and size + nb > bucket_bytes:
+            buckets.append(bucket)
+            bucket, size = [], 0
+        bucket.append(p)
+        size += nb
+    if bucket:
+        buckets.append(bucket)
+    for bk in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bk])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for p in bk:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n

@@ -60,3 +60,33 @@ def test_deal_and_sample_split_cover_everything():
 def test_single_process_gather_is_identity():
     x = torch.randn(8, 3)
     assert gather_clip_tokens(x, 2, 4) is x
+
+
+def _grad_worker(rank, world, port, ret):
+    from eilev_amd.train import allreduce_gradients
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = {f"p{i}": torch.zeros(shape, requires_grad=True) for i, shape in enumerate([(5, 7), (300,), (64, 33), (1, 4, 8)])}
+        params["frozen"] = torch.zeros(3)  # not trainable: skipped
+        for i, (k, p) in enumerate(params.items()):
+            if p.requires_grad and not (rank == 1 and k == "p1"):  # rank 1 has no gradient for p1 (e.g. an unused branch)
+                p.grad = torch.full_like(p, float(rank + 1)) * (i + 1)
+        allreduce_gradients(params, bucket_bytes=1024)  # several buckets
+        ret[rank] = {k: p.grad.clone() for k, p in params.items() if p.requires_grad}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks():
+    """train_v2 under torchrun: every rank ends with the mean gradient (ref:scripts/general/train_v2.py via accelerate DDP)."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
+    for i, k in enumerate(["p0", "p1", "p2", "p3"]):
+        expect = (1.0 * (i + 1) + (0.0 if k == "p1" else 2.0 * (i + 1))) / 2
+        for r in range(world):
+            assert torch.allclose(ret[r][k], torch.full_like(ret[r][k], expect)), (k, r)

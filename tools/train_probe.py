@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Time one train_v2 step (loss + backward) of the HIP training graph at the headline configuration.
+
+    python tools/train_probe.py [--samples 1] [--steps 3] [--profile]
+
+Random-init weights of Salesforce/blip2-opt-2.7b's architecture, 16-shot samples of bench.py's shape (17 clips x 8 frames,
+960 tokens per sample), labels on the text positions; ViT and LM frozen, Q-Former + query tokens + projection (107 M
+parameters, fp32 masters) trainable as ref:scripts/general/train_v2.py:124-130 sets them.  Prints per-stage times
+(ViT forward / graph forward / backward) and the peak memory.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from eilev_amd.configs import blip2_config  # noqa: E402
+from eilev_amd.engine import HipEngine  # noqa: E402
+from eilev_amd.train import TrainGraph  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--config", default="opt27")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = blip2_config(args.config)
+    w = bench.random_weights(cfg, dev)
+    eng = HipEngine(cfg, w, device=dev)
+    params = {k: v.float().requires_grad_(True) for k, v in w.items() if k.startswith(("qformer.", "query_tokens", "language_projection."))}
+    n_par = sum(p.numel() for p in params.values())
+    px, ids, vm, am = bench.build_inputs(cfg, args.samples, dev)
+    labels = torch.where(vm == 0, ids, torch.full_like(ids, -100))
+    graph = TrainGraph(eng, params)
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-5)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for step in range(args.steps + 1):
+        torch.cuda.reset_peak_memory_stats()
+        e = [ev() for _ in range(5)]
+        e[0].record()
+        with torch.no_grad():
+            eng.vit(px)  # timed alone; loss() below runs it again
+        e[1].record()
+        loss = graph.loss(ids, am, px, vm, labels)
+        e[2].record()
+        loss.backward()
+        e[3].record()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        e[4].record()
+        torch.cuda.synchronize()
+        vit, fwd, bwd, ost = (e[i].elapsed_time(e[i + 1]) for i in range(4))
+        tag = "warm-up" if step == 0 else f"step {step}"
+        print(f"{tag}: loss {float(loss.detach()):.4f}  vit {vit:.1f} ms  forward(vit+graph) {fwd:.1f} ms  backward {bwd:.1f} ms  adamw {ost:.1f} ms  "
+              f"step {fwd + bwd + ost:.1f} ms  peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB  ({n_par / 1e6:.1f} M trainable, "
+              f"{args.samples * 17} clips, {ids.shape[1]} tokens/sample)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
