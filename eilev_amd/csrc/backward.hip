@@ -45,6 +45,44 @@ __device__ __forceinline__ void load_tile(const bf16 *src, int64_t ld, int row0,
     }
 }
 
+// the same tile in two steps, so that the global loads of tile t+1 are in flight while tile t is consumed: each thread
+// holds DP/32 16-byte chunks
+template <int DP>
+struct TileRegs {
+    bf16x8 v[DP / 32];
+};
+template <int DP>
+__device__ __forceinline__ void fetch_tile(TileRegs<DP> &t, const bf16 *src, int64_t ld, int row0, int nrows, int hd, int tid) {
+    constexpr int CH = DP / 8;
+#pragma unroll
+    for (int j = 0; j < DP / 32; ++j) {
+        const int i = tid + j * 256, r = i / CH, c = i - r * CH, gr = row0 + r;
+        t.v[j] = (gr < nrows && c * 8 < hd) ? *reinterpret_cast<const bf16x8 *>(src + (int64_t)gr * ld + c * 8) : zero8();
+    }
+}
+template <int DP>
+__device__ __forceinline__ void store_tile(const TileRegs<DP> &t, bf16 *rm, bf16 *tr, int tid) {
+    constexpr int LDR = DP + 8, CH = DP / 8;
+#pragma unroll
+    for (int j = 0; j < DP / 32; ++j) {
+        const int i = tid + j * 256, r = i / CH, c = i - r * CH;
+        *reinterpret_cast<bf16x8 *>(rm + r * LDR + c * 8) = t.v[j];
+        if (tr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * LDT + r] = t.v[j][e];
+        }
+    }
+}
+__device__ __forceinline__ int fetch_key_mask(const AttnBwdArgs &a, int b, int kv0, int tid) {
+    int ok = 0;
+    if (tid < 64) {
+        const int gk = kv0 + tid;
+        ok = gk < a.skv;
+        if (ok && a.key_mask) ok = a.key_mask[(int64_t)b * a.skv + gk] != 0;
+    }
+    return ok;
+}
+
 // C[i][j] += sum_k A[i][k] * B[j][k] for a 32x32 block; A, B rows are K-contiguous in LDS.  Lane l holds column j = l % 32,
 // rows i = (r & 3) + 8 * (r >> 2) + 4 * (l / 32).
 __device__ __forceinline__ void mma_nt(f32x16 &c, const bf16 *A, int lda, const bf16 *B, int ldb, int K, int lane) {
@@ -117,10 +155,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         const int kb = wid & 1, qb = wid >> 1;
         const int qrow = q0 + qb * 32 + l31;
         float m_run = -1e30f, l_run = 0.0f;
+        TileRegs<DP> kr;
+        fetch_tile<DP>(kr, kp, a.ldk, 0, a.skv, a.hd, tid);
+        int mr = fetch_key_mask(a, b, 0, tid);
         for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
             __syncthreads();
-            load_tile<DP>(kp, a.ldk, kv0, a.skv, a.hd, Ks, nullptr, tid);
-            load_key_mask(a, b, kv0, mk, tid);
+            store_tile<DP>(kr, Ks, nullptr, tid);
+            if (tid < 64) mk[tid] = mr;
+            if (kv0 + 64 < kv_end) {
+                fetch_tile<DP>(kr, kp, a.ldk, kv0 + 64, a.skv, a.hd, tid);
+                mr = fetch_key_mask(a, b, kv0 + 64, tid);
+            }
             __syncthreads();
             f32x16 s = zero16();
             mma_nt(s, Ks + kb * 32 * LDR, LDR, Qs + qb * 32 * LDR, LDR, DP, lane);
@@ -170,11 +215,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     f32x16 acc[DBH];
 #pragma unroll
     for (int i = 0; i < DBH; ++i) acc[i] = zero16();
+    TileRegs<DP> kr, vr;
+    fetch_tile<DP>(kr, kp, a.ldk, 0, a.skv, a.hd, tid);
+    fetch_tile<DP>(vr, vp, a.ldv, 0, a.skv, a.hd, tid);
+    int mr = fetch_key_mask(a, b, 0, tid);
     for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
         __syncthreads();
-        load_tile<DP>(kp, a.ldk, kv0, a.skv, a.hd, Ks, Kt, tid);
-        load_tile<DP>(vp, a.ldv, kv0, a.skv, a.hd, Vs, nullptr, tid);
-        load_key_mask(a, b, kv0, mk, tid);
+        store_tile<DP>(kr, Ks, Kt, tid);
+        store_tile<DP>(vr, Vs, nullptr, tid);
+        if (tid < 64) mk[tid] = mr;
+        if (kv0 + 64 < kv_end) {
+            fetch_tile<DP>(kr, kp, a.ldk, kv0 + 64, a.skv, a.hd, tid);
+            fetch_tile<DP>(vr, vp, a.ldv, kv0 + 64, a.skv, a.hd, tid);
+            mr = fetch_key_mask(a, b, kv0 + 64, tid);
+        }
         __syncthreads();
         {
             const int qb2 = wid >> 1, kb2 = wid & 1;
@@ -242,15 +296,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     for (int i = 0; i < DB; ++i) acc[i] = zero16();
     int q_begin = 0;
     if (a.causal) q_begin = max(0, kv0 - off) & ~63;  // queries below kv0 - off see none of these keys
+    TileRegs<DP> qr, gr;
+    float lr = 0.0f, dr = 0.0f;
+    auto fetch_q = [&](int q0) {
+        fetch_tile<DP>(qr, qp, a.ldq, q0, a.sq, a.hd, tid);
+        fetch_tile<DP>(gr, dop, a.ldo, q0, a.sq, a.hd, tid);
+        const bool ok = tid < 64 && q0 + tid < a.sq;
+        lr = ok ? lsep[q0 + tid] : 0.0f;
+        dr = ok ? deltap[q0 + tid] : 0.0f;
+    };
+    if (q_begin < a.sq) fetch_q(q_begin);
     for (int q0 = q_begin; q0 < a.sq; q0 += 64) {
         __syncthreads();
-        load_tile<DP>(qp, a.ldq, q0, a.sq, a.hd, Qs, Qt, tid);
-        load_tile<DP>(dop, a.ldo, q0, a.sq, a.hd, dOs, dOt, tid);
+        store_tile<DP>(qr, Qs, Qt, tid);
+        store_tile<DP>(gr, dOs, dOt, tid);
         if (tid < 64) {
-            const bool ok = q0 + tid < a.sq;
-            lse_s[tid] = ok ? lsep[q0 + tid] : 0.0f;
-            delta_s[tid] = ok ? deltap[q0 + tid] : 0.0f;
+            lse_s[tid] = lr;
+            delta_s[tid] = dr;
         }
+        if (q0 + 64 < a.sq) fetch_q(q0 + 64);
         __syncthreads();
         {
             const int kb2 = wid & 1, qb2 = wid >> 1;

@@ -277,10 +277,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                 decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         """pixel_values: (num_videos, C, T, H, W); video_input_mask: (batch, seq_len)  [ref:eilev/model/v2.py:132-252].
 
-        With ``labels``, autograd enabled and at least one trainable parameter (the train_v2 setting:
+        In ``train()`` mode with ``labels``, autograd enabled and at least one trainable parameter (what `Trainer` does for train_v2:
         ref:scripts/general/train_v2.py:124-130, 207-217) the call returns a loss with a gradient, computed by the training
         graph of eilev_amd/train.py (logits are not materialised on that route).  Otherwise it runs without autograd."""
-        if labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict)
         return self._forward_eval(input_ids, attention_mask, pixel_values, video_input_mask, decoder_input_ids, decoder_attention_mask,
                                   output_attentions, output_hidden_states, labels, return_dict)

@@ -103,7 +103,7 @@ def test_model_forward_returns_trainable_loss():
     model = VideoBlipForConditionalGeneration(cfg)
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}
     model.load_state_dict(sd, strict=False)
-    model = model.cuda()
+    model = model.cuda().train()
     for p in model.vision_model.parameters():
         p.requires_grad = False
     for p in model.language_model.parameters():
@@ -125,6 +125,7 @@ def test_model_forward_returns_trainable_loss():
         opt.step()
         opt.zero_grad()
     assert float(out.loss) < l0, (l0, float(out.loss))  # the step descends on the batch it was computed on
+    model.eval()
     with torch.no_grad():
         ev = model(**batch)  # inference route still works and sees the updated weights
     assert ev.logits is not None and abs(float(ev.loss) - float(out.loss)) < 0.5
