@@ -94,6 +94,25 @@ __device__ __forceinline__ void mma_nt(f32x16 &c, const bf16 *A, int lda, const 
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c, 0, 0, 0);
     }
 }
+// the same with one operand's fragments held in registers (the tile a workgroup owns for its whole life)
+template <int KD>
+__device__ __forceinline__ void load_frags(bf16x8 (&f)[KD], const bf16 *T, int ld, int lane) {
+    const bf16 *p = T + (lane & 31) * ld + (lane >> 5) * 8;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) f[kd] = *reinterpret_cast<const bf16x8 *>(p + kd * 16);
+}
+template <int KD>
+__device__ __forceinline__ void mma_ra(f32x16 &c, const bf16x8 (&af)[KD], const bf16 *B, int ldb, int lane) {
+    const bf16 *bp = B + (lane & 31) * ldb + (lane >> 5) * 8;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kd], *reinterpret_cast<const bf16x8 *>(bp + kd * 16), c, 0, 0, 0);
+}
+template <int KD>
+__device__ __forceinline__ void mma_rb(f32x16 &c, const bf16 *A, int lda, const bf16x8 (&bfr)[KD], int lane) {
+    const bf16 *ap = A + (lane & 31) * lda + (lane >> 5) * 8;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ap + kd * 16), bfr[kd], c, 0, 0, 0);
+}
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -113,11 +132,12 @@ __device__ __forceinline__ void load_key_mask(const AttnBwdArgs &a, int b, int k
 
 // ---- dQ (+ lse, delta) -------------------------------------------------------------------------------------------------------
 template <int DB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     constexpr int DP = DB * 32, LDR = DP + 8, DBH = (DB + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16 *Qs = reinterpret_cast<bf16 *>(smem), *dOs = Qs + 64 * LDR, *Ks = dOs + 64 * LDR, *Vs = Ks + 64 * LDR;
-    bf16 *Kt = Vs + 64 * LDR, *dSs = Kt + DP * LDT;
+    // Q / dO are staged once, turned into MFMA fragments held in registers, and their LDS is reused for the K / V tiles
+    bf16 *Qs = reinterpret_cast<bf16 *>(smem), *dOs = Qs + 64 * LDR, *Ks = Qs, *Vs = dOs;
+    bf16 *Kt = dOs + 64 * LDR, *dSs = Kt + DP * LDT;
     float *lse_s = reinterpret_cast<float *>(dSs + 64 * LDT), *delta_s = lse_s + 64, *red = delta_s + 64;  // red[2][64][2]
     int *mk = reinterpret_cast<int *>(red + 256);
 
@@ -150,6 +170,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         }
     }
 
+    constexpr int KD = DP / 16;
+    bf16x8 qf[KD], gf[KD];  // rows (wid >> 1) * 32.. of Q and dO: B operand of pass 1, A operands of pass 2
+    load_frags<KD>(qf, Qs + (wid >> 1) * 32 * LDR, LDR, lane);
+    load_frags<KD>(gf, dOs + (wid >> 1) * 32 * LDR, LDR, lane);
+
     // pass 1: lse of every query row.  Wave (kb, qb) = (wid & 1, wid >> 1) scores keys kb*32.. against queries qb*32..
     {
         const int kb = wid & 1, qb = wid >> 1;
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
             }
             __syncthreads();
             f32x16 s = zero16();
-            mma_nt(s, Ks + kb * 32 * LDR, LDR, Qs + qb * 32 * LDR, LDR, DP, lane);
+            mma_rb<KD>(s, Ks + kb * 32 * LDR, LDR, qf, lane);
             float mx = -1e30f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -233,8 +258,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         {
             const int qb2 = wid >> 1, kb2 = wid & 1;
             f32x16 s = zero16(), dp = zero16();
-            mma_nt(s, Qs + qb2 * 32 * LDR, LDR, Ks + kb2 * 32 * LDR, LDR, DP, lane);
-            mma_nt(dp, dOs + qb2 * 32 * LDR, LDR, Vs + kb2 * 32 * LDR, LDR, DP, lane);
+            mma_ra<KD>(s, qf, Ks + kb2 * 32 * LDR, LDR, lane);
+            mma_ra<KD>(dp, gf, Vs + kb2 * 32 * LDR, LDR, lane);
             const int kl = kb2 * 32 + l31;
             const bool kok = mk[kl] != 0;
 #pragma unroll
@@ -268,11 +293,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 
 // ---- dK, dV ------------------------------------------------------------------------------------------------------------------
 template <int DB>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     constexpr int DP = DB * 32, LDR = DP + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16 *Ks = reinterpret_cast<bf16 *>(smem), *Vs = Ks + 64 * LDR, *Qs = Vs + 64 * LDR, *dOs = Qs + 64 * LDR;
-    bf16 *Qt = dOs + 64 * LDR, *dOt = Qt + DP * LDT, *Pt = dOt + DP * LDT, *dSt = Pt + 64 * LDT;
+    // K / V are staged once, turned into MFMA fragments held in registers, and their LDS is reused for the Q / dO tiles
+    bf16 *Ks = reinterpret_cast<bf16 *>(smem), *Vs = Ks + 64 * LDR, *Qs = Ks, *dOs = Vs;
+    bf16 *Qt = Vs + 64 * LDR, *dOt = Qt + DP * LDT, *Pt = dOt + DP * LDT, *dSt = Pt + 64 * LDT;
     float *lse_s = reinterpret_cast<float *>(dSt + 64 * LDT), *delta_s = lse_s + 64;
     int *mk = reinterpret_cast<int *>(delta_s + 64);
 
@@ -288,6 +314,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     load_tile<DP>(kp, a.ldk, kv0, a.skv, a.hd, Ks, nullptr, tid);
     load_tile<DP>(vp, a.ldv, kv0, a.skv, a.hd, Vs, nullptr, tid);
     load_key_mask(a, b, kv0, mk, tid);
+    __syncthreads();
+    constexpr int KD = DP / 16;
+    bf16x8 kf[KD], vf[KD];  // keys (wid & 1) * 32.. : A operands of the score and dP products
+    load_frags<KD>(kf, Ks + (wid & 1) * 32 * LDR, LDR, lane);
+    load_frags<KD>(vf, Vs + (wid & 1) * 32 * LDR, LDR, lane);
 
     // wave (kb, half): key block kb; blocks t = half * DB + i: t < DB -> dV block t, else dK block t - DB
     const int kb = wid & 1, half = wid >> 1;
@@ -319,8 +350,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
         {
             const int kb2 = wid & 1, qb2 = wid >> 1;
             f32x16 s = zero16(), dp = zero16();
-            mma_nt(s, Ks + kb2 * 32 * LDR, LDR, Qs + qb2 * 32 * LDR, LDR, DP, lane);
-            mma_nt(dp, Vs + kb2 * 32 * LDR, LDR, dOs + qb2 * 32 * LDR, LDR, DP, lane);
+            mma_ra<KD>(s, kf, Qs + qb2 * 32 * LDR, LDR, lane);
+            mma_ra<KD>(dp, vf, dOs + qb2 * 32 * LDR, LDR, lane);
             const int ql = qb2 * 32 + l31;
             const bool qok = q0 + ql < a.sq;
             const float lse = lse_s[ql], dl = delta_s[ql];
@@ -363,8 +394,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 template <int DB>
 int launch_attn_bwd(const AttnBwdArgs &a, hipStream_t s) {
     constexpr int DP = DB * 32, LDR = DP + 8;
-    const size_t smem_q = (size_t)(4 * 64 * LDR + DP * LDT + 64 * LDT) * 2 + (64 + 64 + 256) * 4 + 64 * 4;
-    const size_t smem_kv = (size_t)(4 * 64 * LDR + 2 * DP * LDT + 2 * 64 * LDT) * 2 + (64 + 64) * 4 + 64 * 4;
+    const size_t smem_q = (size_t)(2 * 64 * LDR + DP * LDT + 64 * LDT) * 2 + (64 + 64 + 256) * 4 + 64 * 4;
+    const size_t smem_kv = (size_t)(2 * 64 * LDR + 2 * DP * LDT + 2 * 64 * LDT) * 2 + (64 + 64) * 4 + 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q));
