@@ -1702,6 +1702,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     bool wide_tiles = false;
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
+    if (force == 13 || force == 14) cfg = 4;  // probe: 64x128 / 128x128 tiles
     else if (force >= 1 && force <= 4) cfg = force;
     const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
                        (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
@@ -1718,6 +1719,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
     else if (cfg == 2) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
+    else if ((force == 0 || force == 13) && cfg == 4 && (force == 13 || ceil_div64(g.M, 128) * ceil_div64(g.N, 128) < 96) && g.M > 64 && !(g.dbg & 4))
+        rc = launch_tiled<64, 128, 1, 2, 2, 3>(g, s);  // a handful of 128x128 tiles (Q-Former graph: 544 rows): 64x128, 2 waves, 3 WG/CU (+13 % at 544 x 768 x 768; slower from ~160 tiles on)
     else rc = launch_tiled<128, 128, 2, 2, 2, 2>(g, s);
     if (prof_kind >= 0) prof_end(s);
     return rc;

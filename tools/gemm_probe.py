@@ -5,7 +5,7 @@
 
 flags (eilev_debug_gemm_flags): 4 register-staged reference kernel; 8 old skinny kernel; (n << 4) force tile config n
 (1: 256x256 per-tile kernel, 2: 256x128 two stages, 3: 256x128 one stage x 2 workgroups/CU, 4: 128x128, 9: persistent ping-pong
-kernel pp4, 12: one-wave-per-SIMD kernel w6); 1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0
+kernel pp4, 12: one-wave-per-SIMD kernel w6, 13: 64x128 two-wave tiles, 14: 128x128); 1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0
 (cache-resident operand — also changes the MFMA data statistics and with them the clock: not a memory-system measurement);
 131072 alias all output rows onto row 0; 524288 no half-tile path; 1048576 per-tile kernel for N = 1408; 2097152 never pick w6;
 16777216 pp4 without the lean epilogue / second pre-staged K-step; (n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
@@ -29,7 +29,7 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        "proj": (34952, 1408, 1408, 0, True), "opt_fc1": (7680, 10240, 2560, 2, False), "opt_qkv": (7680, 7680, 2560, 0, False),
        "qf_kv": (34952, 1536, 1408, 0, False), "opt_fc2": (7680, 2560, 10240, 0, True),
        "fc2_k6208": (34952, 1408, 6208, 0, True), "fc2_k6080": (34952, 1408, 6080, 0, True), "fc1_k1472": (34952, 6144, 1472, 0, False),
-       "opt_out": (7680, 2560, 2560, 0, True),
+       "opt_out": (7680, 2560, 2560, 0, True), "qf_dense": (544, 768, 768, 0, True), "qf_fi": (544, 3072, 768, 0, False),
        "fc1_noact": (34952, 6144, 1408, 0, False), "fc1_relu": (34952, 6144, 1408, 2, False)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
