@@ -241,8 +241,16 @@ class _LMHeadCE(torch.autograd.Function):
             raise ValueError("labels contain no supervised position")
         logits = _gemm(rows, e16, None, None, R, V, D, out_f32=True)
         row_loss = torch.empty(R, dtype=torch.float32, device=rows.device)
-        dlogits = torch.empty((R, V), dtype=_BF, device=rows.device)
-        abi.check(_lib().eilev_ce_loss(_p(logits), _p(tg), 1.0 / n_valid, _p(row_loss), _p(dlogits), R, V, _s()), "eilev_ce_loss")
+        # dlogits is the A operand of dRows = dlogits . E: its row length is padded to a multiple of 256 (zero columns, matched by
+        # zero rows of the transposed embedding) so that product takes the DMA kernels instead of the K-tail kernel
+        Vp = (V + 255) // 256 * 256
+        dlogits = torch.zeros((R, Vp), dtype=_BF, device=rows.device) if Vp != V else torch.empty((R, V), dtype=_BF, device=rows.device)
+        if Vp != V:  # the kernel writes rows of length V: run it on a dense (R, V) buffer, then place it
+            dense = torch.empty((R, V), dtype=_BF, device=rows.device)
+            abi.check(_lib().eilev_ce_loss(_p(logits), _p(tg), 1.0 / n_valid, _p(row_loss), _p(dense), R, V, _s()), "eilev_ce_loss")
+            dlogits[:, :V].copy_(dense)
+        else:
+            abi.check(_lib().eilev_ce_loss(_p(logits), _p(tg), 1.0 / n_valid, _p(row_loss), _p(dlogits), R, V, _s()), "eilev_ce_loss")
         ctx.save_for_backward(dlogits, embed, e16 if embed.requires_grad else None)
         return row_loss.sum() / n_valid
 
@@ -253,9 +261,14 @@ class _LMHeadCE(torch.autograd.Function):
             raise NotImplementedError("the token embedding / lm_head is frozen on the train_v2 path")
         if e16 is None:
             e16 = _bf(embed)
-        R, V = dlogits.shape
-        D = e16.shape[1]
-        drows = _gemm(dlogits, _weight_t(embed, e16), None, None, R, D, V)
+        R, Vp = dlogits.shape
+        V, D = e16.shape
+        key = ("embed_t", embed.data_ptr(), V, D)
+        et = _frozen_t.get(key)
+        if et is None:  # E^T (D, Vp), zero beyond V; the embedding is frozen on this path
+            et = _frozen_t[key] = torch.zeros((D, Vp), dtype=_BF, device=e16.device)
+            et[:, :V].copy_(e16.t())
+        drows = _gemm(dlogits, et, None, None, R, D, Vp)
         return drows * g.to(_BF), None, None
 
 

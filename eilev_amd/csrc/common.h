@@ -125,6 +125,7 @@ struct GemmArgs {
     const float *wscale = nullptr;  // [N] or null
     const uint8_t *W8 = nullptr;    // [N, K] e4m3 bytes (ldw = K) when the weights are still quantised (skinny kernel)
     bf16 *w8_scratch = nullptr;     // [N, K] bf16: where a large-M call expands W8 to (exact: every e4m3 value is a bf16 value)
+    int k_slice = 0;                // > 0: split-K launch (gridDim.y slices of k_slice K-steps, f32 output accumulated atomically)
 };
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);

@@ -97,7 +97,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
                             if (EPI == 1) v = gelu_erf(v);
                             else if (EPI == 2) v = fmaxf(v, 0.0f);
                             if (g.resid) v += (float)g.resid[(int64_t)row * g.ldr + col + e];
-                            if (col + e < g.N) dst[e] = v;
+                            if (col + e < g.N) {
+                                if (g.k_slice > 0) atomicAdd(dst + e, v);
+                                else dst[e] = v;
+                            }
                         }
                     }
                 }
@@ -387,7 +390,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / NWN, wn = wid % NWN;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nk = g.K / BK;
+    // split-K (weight gradients: few output tiles, tens of thousands of rows to contract): slice blockIdx.y owns K-steps
+    // [kbase, kbase + nk) and adds its partial sums to the zero-initialised f32 output
+    const int kbase = g.k_slice > 0 ? (int)blockIdx.y * g.k_slice : 0;
+    const int nk = g.k_slice > 0 ? min(g.k_slice, g.K / BK - kbase) : g.K / BK;
 
     // per-lane byte offsets of this wave's pieces; the LDS-DMA goes through buffer descriptors (one s_mov m0 +
     // one buffer_load ... lds per piece, K advance in the scalar offset: no 64-bit VALU address arithmetic)
@@ -412,10 +418,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
         char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
 #pragma unroll
         for (int i = 0; i < A_PC; ++i)
-            lds_dma16(g.A, sa + i * 1024, pa[i], kt * (BK * 2));
+            lds_dma16(g.A, sa + i * 1024, pa[i], (kbase + kt) * (BK * 2));
 #pragma unroll
         for (int i = 0; i < B_PC; ++i)
-            lds_dma16(g.W, sb + i * 1024, pb[i], kt * (BK * 2));
+            lds_dma16(g.W, sb + i * 1024, pb[i], (kbase + kt) * (BK * 2));
     };
 
     f32x16 acc[TM][TN];
@@ -462,10 +468,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
             char *sa = smem + buf * STAGE + (wid * A_PC) * 1024;
             char *sb = smem + buf * STAGE + BM * 128 + (wid * B_PC) * 1024;
 #pragma unroll
-            for (int i = 0; i < A_PC; ++i) lds_dma16(g.A, sa + i * 1024, pa[i], kt * (BK * 2));
+            for (int i = 0; i < A_PC; ++i) lds_dma16(g.A, sa + i * 1024, pa[i], (kbase + kt) * (BK * 2));
             if (wid < NW / 2) {  // W rows 128..255 of the tile are beyond N
 #pragma unroll
-                for (int i = 0; i < B_PC; ++i) lds_dma16(g.W, sb + i * 1024, pb[i], kt * (BK * 2));
+                for (int i = 0; i < B_PC; ++i) lds_dma16(g.W, sb + i * 1024, pb[i], (kbase + kt) * (BK * 2));
             }
         };
         auto compute_half = [&](int buf) {
@@ -1702,7 +1708,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     bool wide_tiles = false;
     if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
-    if (force == 13 || force == 14) cfg = 4;  // probe: 64x128 / 128x128 tiles
+    if (force == 13 || force == 14 || force == 15) cfg = 4;  // probe: 64x128 / 128x128 tiles / split-K
     else if (force >= 1 && force <= 4) cfg = force;
     const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
                        (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
@@ -1719,6 +1725,29 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
     else if (cfg == 2) rc = launch_tiled<256, 128, 4, 2, 2, 2>(g, s);
+    else if (cfg == 4 && g.out_f32 && !g.bias && !g.resid && g.epi == 0 && !g.wscale && g.scale_cols == 0 && g.patch_group == 0 && g.K % BK == 0 &&
+             g.K >= 8192 && ceil_div64(g.M, 128) * ceil_div64(g.N, 128) <= 128 && (force == 0 || force == 15) && !(g.dbg & 4) &&
+             (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll) {
+        // weight-gradient shape (dW = dY^T X: a few output tiles, K = rows of the step): split K over enough slices to fill the CUs
+        const int tiles = (int)(ceil_div64(g.M, 128) * ceil_div64(g.N, 128)), nk = g.K / BK;
+        int slices = 512 / tiles;
+        slices = slices < 2 ? 2 : (slices > 16 ? 16 : slices);
+        if (slices > nk / 8) slices = nk / 8 > 1 ? nk / 8 : 1;
+        GemmArgs gs = g;
+        gs.k_slice = (nk + slices - 1) / slices;
+        slices = (nk + gs.k_slice - 1) / gs.k_slice;
+        static bool attr_set = false;
+        constexpr int smem = 2 * (128 + 128) * 128;
+        if (!attr_set) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds_kernel<128, 128, 2, 2, 0, 2, 2, 0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        EILEV_HIP_CHECK(hipMemsetAsync(g.C, 0, (size_t)g.M * g.ldc * sizeof(float), s));
+        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 0, 2, 2, 0>), dim3(tiles, slices), dim3(256), smem, s, gs);
+        const hipError_t le = hipGetLastError();
+        rc = le == hipSuccess ? EILEV_OK : (int)le;
+    }
     else if ((force == 0 || force == 13) && cfg == 4 && (force == 13 || ceil_div64(g.M, 128) * ceil_div64(g.N, 128) < 96) && g.M > 64 && !(g.dbg & 4))
         rc = launch_tiled<64, 128, 1, 2, 2, 3>(g, s);  // a handful of 128x128 tiles (Q-Former graph: 544 rows): 64x128, 2 waves, 3 WG/CU (+13 % at 544 x 768 x 768; slower from ~160 tiles on)
     else rc = launch_tiled<128, 128, 2, 2, 2, 2>(g, s);

@@ -77,6 +77,12 @@ def test_linear_skinny(hip, m, n, k):
     _lin_case(hip, m, n, k, 2, bias=True, resid=False)
 
 
+def test_linear_split_k_weight_gradient_shape(hip):
+    """dW = dY^T X of the cross-attention K/V projections: few output tiles, K = rows of the step -> split-K with f32 atomics."""
+    _lin_case(hip, 768, 1408, 8768, 0, bias=False, resid=False, out_f32=True)     # 66 tiles x 7 slices
+    _lin_case(hip, 200, 264, 16448, 0, bias=False, resid=False, out_f32=True, seed=3)   # ragged tiles, 16 slices
+
+
 def test_linear_f32_logits(hip):
     _lin_case(hip, 300, 1000, 160, 0, bias=False, resid=False, out_f32=True)
     _lin_case(hip, 4, 50272, 2560, 0, bias=False, resid=False, out_f32=True)
