@@ -268,8 +268,9 @@ class _LMHeadCE(torch.autograd.Function):
         if et is None:  # E^T (D, Vp), zero beyond V; the embedding is frozen on this path
             et = _frozen_t[key] = torch.zeros((D, Vp), dtype=_BF, device=e16.device)
             et[:, :V].copy_(e16.t())
-        drows = _gemm(dlogits, et, None, None, R, D, Vp)
-        return drows * g.to(_BF), None, None
+        # f32 output: few output tiles and K = 50 432 -> the split-K launch (include/eilev.h eilev_linear)
+        drows = _gemm(dlogits, et, None, None, R, D, Vp, out_f32=True)
+        return (drows * g.float()).to(_BF), None, None
 
 
 def lm_head_ce(rows, embed, targets):
