@@ -199,6 +199,47 @@ def attention(q, k, v, heads, scale, causal=False, key_mask=None):
     return _Attention.apply(q, k, v, heads, scale, causal, key_mask)
 
 
+class _AttentionPacked(torch.autograd.Function):
+    """Self-attention on a packed q|k|v projection (B, S, 3 D): the kernels read the three thirds in place (row stride 3 D) and
+    the backward writes dq|dk|dv into one (B, S, 3 D) tensor — the gradient of the fused projection, no slicing copies."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, causal, key_mask):
+        qkv = _need(qkv, "attention qkv")
+        B, S, D3 = qkv.shape
+        D = D3 // 3
+        hd = D // heads
+        km = None if key_mask is None else key_mask.to(torch.int32).contiguous()
+        o = torch.empty((B, S, D), dtype=_BF, device=qkv.device)
+        base = qkv.data_ptr()
+        abi.check(_lib().eilev_attention(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), B, heads, S, S, hd,
+                                         D3, D3, D3, float(scale), int(causal), _p(km), _s()), "eilev_attention")
+        ctx.save_for_backward(qkv, o, km)
+        ctx.cfg = (heads, float(scale), int(causal))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, km = ctx.saved_tensors
+        heads, scale, causal = ctx.cfg
+        B, S, D3 = qkv.shape
+        D = D3 // 3
+        hd = D // heads
+        d_o = _need(d_o, "attention grad")
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty((2, B, heads, S), dtype=torch.float32, device=qkv.device)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        abi.check(_lib().eilev_attention_bwd(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), _p(d_o),
+                                             C.c_void_p(dbase), C.c_void_p(dbase + 2 * D), C.c_void_p(dbase + 4 * D), _p(ws), B, heads, S, S, hd,
+                                             D3, D3, D3, D3, D3, D3, scale, causal, _p(km), _s()), "eilev_attention_bwd")
+        return dqkv, None, None, None, None
+
+
+def attention_packed(qkv, heads, scale, causal=False, key_mask=None):
+    """qkv (B, S, 3 * heads * hd) = [q | k | v] per row -> (B, S, heads * hd)."""
+    return _AttentionPacked.apply(qkv, heads, scale, causal, key_mask)
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pre, kind):

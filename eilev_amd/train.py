@@ -82,6 +82,18 @@ class TrainGraph:
             h = ag.layer_norm(ag.linear(f, w("fo_w"), w("fo_b"), residual=h), w("fln_w"), w("fln_b"), d.q_eps)
         return h  # (N * nq, D)
 
+    def _opt_qkv(self, l, k):
+        """q|k|v projection of frozen OPT layer l as one [3 D, D] matrix (built once per engine)."""
+        cache = self.eng.__dict__.setdefault("_train_fused_qkv", {})
+        hit = cache.get(l)
+        if hit is None:
+            ws = [self.W(k[f]) for f in ("q_w", "k_w", "v_w")]
+            bs = [self.W(k[f]) for f in ("q_b", "k_b", "v_b")]
+            if any(t.requires_grad for t in ws + bs):
+                raise NotImplementedError("the language model is frozen on the train_v2 path")
+            hit = cache[l] = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous())
+        return hit
+
     # ---- OPT decoder with frozen weights (hf modeling_opt.py OPTDecoder: pre-LN, ReLU FFN, learned positions + 2) ----
     def opt_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         d = self.eng.dims
@@ -97,10 +109,9 @@ class TrainGraph:
             k = abi.opt_layer_keys(l)
             w = lambda f: self.W(k[f])
             x = ag.layer_norm(h, w("ln1_w"), w("ln1_b"), d.t_eps)
-            q = ag.linear(x, w("q_w"), w("q_b")).view(B, L, D)
-            kk = ag.linear(x, w("k_w"), w("k_b")).view(B, L, D)
-            v = ag.linear(x, w("v_w"), w("v_b")).view(B, L, D)
-            ctx = ag.attention(q, kk, v, H, scale, causal=True, key_mask=km).view(B * L, D)
+            wqkv, bqkv = self._opt_qkv(l, k)
+            qkv = ag.linear(x, wqkv, bqkv).view(B, L, 3 * D)  # one GEMM of N = 3 D instead of three of N = D (160 tiles each at L = 960)
+            ctx = ag.attention_packed(qkv, H, scale, causal=True, key_mask=km).view(B * L, D)
             h = ag.linear(ctx, w("o_w"), w("o_b"), residual=h)
             x = ag.layer_norm(h, w("ln2_w"), w("ln2_b"), d.t_eps)
             f = ag.relu(ag.linear(x, w("fc1_w"), w("fc1_b")))
