@@ -1706,12 +1706,16 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     else if (tm256 * ceil_div64(g.N, 128) >= 192) cfg = 2;                   // 256x128, 2 stages
     else cfg = 4;                                                            // 128x128
     bool wide_tiles = false;
-    if (cfg == 3 && tm256 * ceil_div64(g.N, 256) >= 2048 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }  // many row tiles: 256x256 wins despite N padding
+    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
+                       (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
+    // N = 1408 / 1536 with >= 512 column-half tiles: the persistent kernels win at every row count measured (fc2 at 34 952 rows:
+    // per-tile 696 us, ping-pong 641, one-wave-per-SIMD 582; at 279 616 rows the ping-pong kernel despite its N padding).  With
+    // fewer tiles (192-511 halves: 17-34 frames) the one-wave-per-SIMD kernel alone wins (fc2 at 4369 rows: 104 -> 77 us; pp4 124)
+    if (cfg == 3 && g.K % BK == 0 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }
+    if (cfg == 2 && w6_ok && force == 0 && !(g.dbg & (16384 | 2097152 | 4))) { cfg = 1; wide_tiles = true; }
     if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
     if (force == 13 || force == 14 || force == 15) cfg = 4;  // probe: 64x128 / 128x128 tiles / split-K
     else if (force >= 1 && force <= 4) cfg = force;
-    const bool w6_ok = g.K % 64 == 0 && g.K >= 256 && g.N % 128 == 0 && (!g.resid || (g.epi == 0 && (g.ldr & 7) == 0)) && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
-                       (int64_t)g.M * g.lda * 2 < 0x7fff0000ll && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && (g.ldc & 7) == 0;
     // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): its smaller tiles balance better when there are fewer than
     // 4 rounds of 256 x 256 tiles (M = 7680 prefill GEMMs: +28 %); with more tiles the ping-pong kernel with the lean epilogue wins
     // (qkv +5 %, OPT out_proj +3 %)
