@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
                                                                 const int32_t *__restrict__ attn_mask,
                                                                 const int32_t *__restrict__ state, int seq_len, int cap,
                                                                 int heads, int hd, int64_t ldq, const float *__restrict__ rel_tab,
-                                                                int64_t rel_hs, int rel_off) {
+                                                                int64_t rel_hs, int rel_off, int fuse_new) {
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float sc[DEC_KEYS];
     __shared__ float red[DEC_KEYS * 17];  // per-key chunk partials (stride 17), later the p.V partials (nks * hd <= 2048)
@@ -280,6 +280,15 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     const bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd;
     const bf16 *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
+    // fuse_new: the newest key / value (slot kv_total - 1) is still only in the q|k|v row of this step.  The split that owns the
+    // slot reads it from there and stores it into the cache (what a separate kv_write launch did before the attention).
+    const int slot_new = fuse_new ? kv_total - 1 : -1;
+    const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
+    if (slot_new >= k0 && slot_new < k1 && tid < 2 * nch) {
+        const int which = tid / nch, cc = tid - which * nch;
+        bf16 *dst = const_cast<bf16 *>(which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8;
+        *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
+    }
     __syncthreads();
 
     // scores: thread = (key subset ks, d chunk c) so that consecutive lanes read consecutive 16-byte chunks (a K row is
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
 #pragma unroll 4
         for (int jj = ks; jj < nkeys; jj += nks) {
             float kv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>(kbase + (int64_t)(k0 + jj) * hd + c * 8), kv);
+            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? knew : kbase + (int64_t)(k0 + jj) * hd) + c * 8), kv);
             red[jj * 17 + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
         }
     }
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
 #pragma unroll 4
         for (int jj = ks; jj < nkeys; jj += nks) {
             float vv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>(vbase + (int64_t)(k0 + jj) * hd + c * 8), vv);
+            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? vnew : vbase + (int64_t)(k0 + jj) * hd) + c * 8), vv);
             const float pj = sc[jj];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
@@ -598,13 +607,13 @@ size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
 }
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
-                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0) {
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0) {
     if (ldq == 0) ldq = 3 * (int64_t)heads * hd;  // q | k | v rows
     if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
     const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
     if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap)) return EILEV_E_WORKSPACE;
     hipLaunchKernelGGL(attn_decode_split_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, kc, vc, scratch, attn_mask, state,
-                       seq_len, cap, heads, hd, ldq, rel_tab, rel_hs, rel_off);
+                       seq_len, cap, heads, hd, ldq, rel_tab, rel_hs, rel_off, fuse_new);
     EILEV_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, nsplit);
     EILEV_LAUNCH_CHECK();

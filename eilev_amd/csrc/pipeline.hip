@@ -20,7 +20,7 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
                     const int32_t *state, hipStream_t s, int slot0 = 0);
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
-                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0);
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0);
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
@@ -535,9 +535,9 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
         RC(opt_qkv(d, w, l, b, batch, s));
-        RC(launch_kv_write(b.qkv, kc, vc, (int)batch, 1, H, hd, (int)kv_capacity, (int)seq_len, state, s));
+        // the new token's K / V go into the cache inside the attention kernel (fuse_new): one launch less per layer
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
-                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s));
+                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
         RC(opt_tail(d, w, l, b, batch, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, batch, D, d->t_eps, s));
