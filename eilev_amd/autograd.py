@@ -26,11 +26,15 @@ from . import abi
 
 _BF = torch.bfloat16
 _tcache: dict = {}      # per-step transposes of activations shared by several linears (cleared by new_step())
-_frozen_t: dict = {}    # transposes of frozen weights, kept for the life of the process
+_cur = {"frozen": {}}   # transposes of FROZEN weights: a dict owned by whoever owns those weights (the engine), see new_step()
 
 
-def new_step() -> None:
+def new_step(frozen_cache: dict | None = None) -> None:
+    """Start a step.  ``frozen_cache`` holds the transposed copies of frozen weights; it must live and die with the tensors it
+    mirrors (TrainGraph keeps it on its engine), because a freed weight's address can be reused by different values.  Every
+    Function captures the dict at forward time, so interleaved graphs of different models cannot see each other's copies."""
     _tcache.clear()
+    _cur["frozen"] = frozen_cache if frozen_cache is not None else {}
 
 
 def _lib():
@@ -71,14 +75,14 @@ def _padded_t(x2d: torch.Tensor, cache: bool) -> torch.Tensor:
     return out
 
 
-def _weight_t(weight: torch.Tensor, w16: torch.Tensor) -> torch.Tensor:
-    """W^T (K, N) contiguous.  Frozen weights are transposed once."""
+def _weight_t(weight: torch.Tensor, w16: torch.Tensor, frozen: dict) -> torch.Tensor:
+    """W^T (K, N) contiguous.  Frozen weights are transposed once per owner of ``frozen``."""
     if weight.requires_grad:
         return w16.t().contiguous()
-    key = (weight.data_ptr(), tuple(weight.shape))
-    hit = _frozen_t.get(key)
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = frozen.get(key)
     if hit is None:
-        hit = _frozen_t[key] = w16.t().contiguous()
+        hit = frozen[key] = w16.t().contiguous()
     return hit
 
 
@@ -102,6 +106,7 @@ class _Linear(torch.autograd.Function):
         ctx.bias_dtype = None if bias is None else bias.dtype
         ctx.has_resid = residual is not None
         ctx.xshape = x.shape
+        ctx.frozen = _cur["frozen"]
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -114,7 +119,7 @@ class _Linear(torch.autograd.Function):
         M = dy2.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(dy2, _weight_t(weight, w16), None, None, M, K, N).view(ctx.xshape)
+            dx = _gemm(dy2, _weight_t(weight, w16, ctx.frozen), None, None, M, K, N).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dyt = _padded_t(dy2, cache=False)
             xt = _padded_t(x2, cache=True)
@@ -293,6 +298,7 @@ class _LMHeadCE(torch.autograd.Function):
         else:
             abi.check(_lib().eilev_ce_loss(_p(logits), _p(tg), 1.0 / n_valid, _p(row_loss), _p(dlogits), R, V, _s()), "eilev_ce_loss")
         ctx.save_for_backward(dlogits, embed, e16 if embed.requires_grad else None)
+        ctx.frozen = _cur["frozen"]
         return row_loss.sum() / n_valid
 
     @staticmethod
@@ -304,10 +310,10 @@ class _LMHeadCE(torch.autograd.Function):
             e16 = _bf(embed)
         R, Vp = dlogits.shape
         V, D = e16.shape
-        key = ("embed_t", embed.data_ptr(), V, D)
-        et = _frozen_t.get(key)
+        key = ("embed_t", embed.data_ptr(), embed._version, V, D)
+        et = ctx.frozen.get(key)
         if et is None:  # E^T (D, Vp), zero beyond V; the embedding is frozen on this path
-            et = _frozen_t[key] = torch.zeros((D, Vp), dtype=_BF, device=e16.device)
+            et = ctx.frozen[key] = torch.zeros((D, Vp), dtype=_BF, device=e16.device)
             et[:, :V].copy_(e16.t())
         # f32 output: few output tiles and K = 50 432 -> the split-K launch (include/eilev.h eilev_linear)
         drows = _gemm(dlogits, et, None, None, R, D, Vp, out_f32=True)

@@ -122,7 +122,7 @@ class TrainGraph:
     def loss(self, input_ids, attention_mask, pixel_values, video_input_mask, labels) -> torch.Tensor:
         """Shifted causal-LM cross-entropy (ignore_index -100), differentiable w.r.t. ``params``."""
         eng = self.eng
-        ag.new_step()
+        ag.new_step(eng.__dict__.setdefault("_train_frozen_t", {}))  # transposed frozen weights live and die with the engine
         dev = eng.device
         input_ids = input_ids.to(dev)
         if attention_mask is None:

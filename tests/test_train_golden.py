@@ -129,3 +129,23 @@ def test_model_forward_returns_trainable_loss():
     with torch.no_grad():
         ev = model(**batch)  # inference route still works and sees the updated weights
     assert ev.logits is not None and abs(float(ev.loss) - float(out.loss)) < 0.5
+    # a frozen weight changed in place (e.g. load_state_dict of another LM): the bf16 copies, the fused q|k|v matrices and the
+    # transposed copies used by the backward are rebuilt with the engine, never reused by address
+    model.train()
+    before = float(model(**batch).loss)
+    with torch.no_grad():
+        for p in model.language_model.parameters():
+            if p.dim() == 2 and p.shape[0] == p.shape[1]:
+                p.mul_(0.5)  # q / k / v / out projections
+    after = model(**batch)
+    after.loss.backward()
+    assert abs(float(after.loss) - before) > 1e-3
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad}
+    opt.zero_grad()
+    model._hip_train = None  # cold rebuild: must give the same loss and gradients as the incremental one
+    again = model(**batch)
+    again.loss.backward()
+    assert float(again.loss) == float(after.loss)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p.grad, g1[k], rtol=1e-3, atol=1e-6 + 1e-3 * float(g1[k].abs().max())), k
