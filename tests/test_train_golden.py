@@ -45,10 +45,18 @@ def _batch(meta):
     nclips = sum(sum(clips) for clips, _ in meta["rows"])
     pixels = synth_pixels(nclips, meta["frames"], image)
     labels = np.where((attn == 1) & (vmask == 0), input_ids, -100)
+    if meta.get("pad", "left") == "right":  # what the training collator produces
+        def right(a, fill):
+            out = np.full_like(a, fill)
+            for b in range(B):
+                n = int(attn[b].sum())
+                out[b, :n] = a[b, L - n:]
+            return out
+        input_ids, vmask, labels, attn = right(input_ids, 1), right(vmask, 0), right(labels, -100), right(attn, 0)
     return pixels, input_ids, attn, vmask, labels
 
 
-@pytest.mark.parametrize("case", ["tiny_b2", "mid_b2"])
+@pytest.mark.parametrize("case", ["tiny_b2", "mid_b2", "mid_b2_right"])
 def test_train_step_matches_reference_autograd(case):
     from eilev_amd.train import TrainGraph
     from hip_utils import models

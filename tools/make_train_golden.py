@@ -28,9 +28,11 @@ from make_goldens import RefModel, build_inputs, load_det_weights  # noqa: E402
 from eilev_amd.configs import blip2_config  # noqa: E402
 
 CASES = {
-    # name: (config, frames, rows)
-    "tiny_b2": ("tiny", 1, [([1, 1], [4, 6]), ([2], [3])]),
-    "mid_b2": ("mid", 2, [([1, 1], [6, 7]), ([1, 1], [3, 3])]),
+    # name: (config, frames, rows, padding side)
+    "tiny_b2": ("tiny", 1, [([1, 1], [4, 6]), ([2], [3])], "left"),
+    "mid_b2": ("mid", 2, [([1, 1], [6, 7]), ([1, 1], [3, 3])], "left"),
+    # the training collator pads on the RIGHT (ref:eilev/data/utils.py:35-66 with the OPT tokenizer's default padding side)
+    "mid_b2_right": ("mid", 2, [([1, 1], [6, 7]), ([1], [3])], "right"),
 }
 FULL = ["query_tokens", "language_projection.weight", "language_projection.bias", "qformer.layernorm.weight",
         "qformer.encoder.layer.0.crossattention.attention.key.weight", "qformer.encoder.layer.0.crossattention.attention.value.bias",
@@ -38,8 +40,17 @@ FULL = ["query_tokens", "language_projection.weight", "language_projection.bias"
         "qformer.encoder.layer.1.output_query.LayerNorm.weight", "qformer.encoder.layer.1.output_query.LayerNorm.bias"]
 
 
+def right_pad(a, attn, fill):
+    """Move the left padding of build_inputs to the right of every row."""
+    out = np.full_like(a, fill)
+    for b in range(a.shape[0]):
+        n = int(attn[b].sum())
+        out[b, :n] = a[b, a.shape[1] - n:]
+    return out
+
+
 def run(name):
-    cfg_name, frames, rows = CASES[name]
+    cfg_name, frames, rows, side = CASES[name]
     cfg = blip2_config(cfg_name)
     torch.manual_seed(0)
     model = RefModel(cfg).eval()
@@ -50,6 +61,8 @@ def run(name):
         p.requires_grad = False
     model.enable_input_require_grads()
     pixels, input_ids, attn, vmask, labels = build_inputs(cfg_name, frames, rows)
+    if side == "right":
+        input_ids, attn, vmask, labels = (right_pad(a, attn, fill) for a, fill in ((input_ids, 1), (attn, 0), (vmask, 0), (labels, -100)))
     t = lambda a: torch.from_numpy(a)
     out = model(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels), video_input_mask=t(vmask), labels=t(labels),
                 return_dict=True)
@@ -57,7 +70,7 @@ def run(name):
     grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
     unused = [k for k, p in model.named_parameters() if p.requires_grad and p.grad is None]
     save = {"loss": np.asarray(float(out.loss), np.float64),
-            "meta": json.dumps({"config": cfg_name, "frames": frames, "rows": rows, "unused": unused}),
+            "meta": json.dumps({"config": cfg_name, "frames": frames, "rows": rows, "unused": unused, "pad": side}),
             "norm_keys": np.array(sorted(grads)), "norms": np.array([float(np.linalg.norm(grads[k])) for k in sorted(grads)], np.float64)}
     for k in FULL:
         if k in grads:
