@@ -5,7 +5,8 @@
 //   * softmax attention backward (hf modeling_opt.py OPTAttention, modeling_blip_2.py Blip2QFormerMultiHeadAttention):
 //     flash-style — P is recomputed from q.k and the row log-sum-exp, never stored.  Two kernels, no atomics:
 //     `attn_bwd_dq_kernel` owns 64 query rows (pass 1: lse and delta = sum(o * d_o); pass 2: dQ), `attn_bwd_dkv_kernel`
-//     owns 64 keys (dK, dV).  Every product is a 32x32x16 bf16 MFMA of two K-contiguous LDS operands.
+//     owns 64 keys (dK, dV).  Every product is a 32x32x16 bf16 MFMA; the owned tile lives in registers as fragments, the
+//     streamed tiles are staged row-major once and read either along their rows or through the transposing LDS read.
 //   * LayerNorm backward (dx; dgamma / dbeta by a column-reduction kernel), erf-GELU / ReLU backward, bias gradients
 //     (column sums), and the token cross-entropy with its logit gradient (hf loss_utils.ForCausalLMLoss).
 // Linear layers need no new kernel: dX = dY . W and dW = dY^T . X are eilev_linear calls on transposed operands
@@ -28,7 +29,7 @@ struct AttnBwdArgs {
 constexpr int LDT = 72;  // row stride (elements) of the 64-wide transposed / score tiles
 
 // rows [row0, row0 + 64) x [0, hd) of a strided bf16 matrix into LDS: row-major [64][DP + 8] (zero beyond hd / nrows) and,
-// when tr != null, transposed [DP][LDT]
+// when tr != null, transposed [DP][LDT] (kept for probes; the kernels use the transposing read instead)
 template <int DP>
 __device__ __forceinline__ void load_tile(const bf16 *src, int64_t ld, int row0, int nrows, int hd, bf16 *rm, bf16 *tr, int tid) {
     constexpr int LDR = DP + 8, CH = DP / 8;
@@ -83,18 +84,9 @@ __device__ __forceinline__ int fetch_key_mask(const AttnBwdArgs &a, int b, int k
     return ok;
 }
 
-// C[i][j] += sum_k A[i][k] * B[j][k] for a 32x32 block; A, B rows are K-contiguous in LDS.  Lane l holds column j = l % 32,
-// rows i = (r & 3) + 8 * (r >> 2) + 4 * (l / 32).
-__device__ __forceinline__ void mma_nt(f32x16 &c, const bf16 *A, int lda, const bf16 *B, int ldb, int K, int lane) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    const bf16 *ap = A + l31 * lda + hi * 8, *bp = B + l31 * ldb + hi * 8;
-    for (int k = 0; k < K; k += 16) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(ap + k);
-        const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(bp + k);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c, 0, 0, 0);
-    }
-}
-// the same with one operand's fragments held in registers (the tile a workgroup owns for its whole life)
+// MFMA layout used throughout (32x32x16 bf16): C[i][j] += sum_k A[i][k] * B[j][k]; lane l holds column j = l % 32 and rows
+// i = (r & 3) + 8 * (r >> 2) + 4 * (l / 32) of the 32x32 block; an operand fragment of lane l is row l % 32, 8 k values of group l / 32.
+// One operand's fragments are held in registers for the tile a workgroup owns for its whole life:
 template <int KD>
 __device__ __forceinline__ void load_frags(bf16x8 (&f)[KD], const bf16 *T, int ld, int lane) {
     const bf16 *p = T + (lane & 31) * ld + (lane >> 5) * 8;
@@ -112,6 +104,25 @@ __device__ __forceinline__ void mma_rb(f32x16 &c, const bf16 *A, int lda, const 
     const bf16 *ap = A + (lane & 31) * lda + (lane >> 5) * 8;
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ap + kd * 16), bfr[kd], c, 0, 0, 0);
+}
+// C[i][j] += sum_k A[i][k] * T[k][j] over k = 0..63: A is [32][lda] with k contiguous, T is a ROW-MAJOR [64][ldt] tile (k = its
+// rows, e.g. the q rows of dO when contracting over queries).  T's MFMA fragment comes from the transposing LDS read
+// (`ds_read_b64_tr_b16`): no transposed copy of the streamed tiles is ever written.  The hardware hands lane (l % 32, l / 32) the
+// k-slots (hi, jj) <-> k = 16 s + (jj < 4 ? 4 hi + jj : 8 + 4 hi + jj - 4) of step s; A is read in the same order (two 8-byte reads).
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+__device__ __forceinline__ void mma_at(f32x16 &c, const bf16 *A, int lda, const bf16 *T, int ldt, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5, g16 = lane >> 4, i16 = lane & 15;
+    const bf16 *ap = A + l31 * lda + 4 * hi;
+    const bf16 *tp = T + (4 * (g16 >> 1) + (i16 >> 2)) * ldt + 16 * (g16 & 1) + (i16 & 3) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x4 a0 = *reinterpret_cast<const bf16x4 *>(ap + 16 * s), a1 = *reinterpret_cast<const bf16x4 *>(ap + 16 * s + 8);
+        const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tp + 16 * s * ldt));
+        const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tp + (16 * s + 8) * ldt));
+        const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const bf16x8 tf = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tf, c, 0, 0, 0);
+    }
 }
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ f32x16 zero16() {
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Q / dO are staged once, turned into MFMA fragments held in registers, and their LDS is reused for the K / V tiles
     bf16 *Qs = reinterpret_cast<bf16 *>(smem), *dOs = Qs + 64 * LDR, *Ks = Qs, *Vs = dOs;
-    bf16 *Kt = dOs + 64 * LDR, *dSs = Kt + DP * LDT;
+    bf16 *dSs = dOs + 64 * LDR;
     float *lse_s = reinterpret_cast<float *>(dSs + 64 * LDT), *delta_s = lse_s + 64, *red = delta_s + 64;  // red[2][64][2]
     int *mk = reinterpret_cast<int *>(red + 256);
 
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     int mr = fetch_key_mask(a, b, 0, tid);
     for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
         __syncthreads();
-        store_tile<DP>(kr, Ks, Kt, tid);
+        store_tile<DP>(kr, Ks, nullptr, tid);
         store_tile<DP>(vr, Vs, nullptr, tid);
         if (tid < 64) mk[tid] = mr;
         if (kv0 + 64 < kv_end) {
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 #pragma unroll
         for (int i = 0; i < DBH; ++i) {
             const int db = half * DBH + i;
-            if (db < DB) mma_nt(acc[i], dSs + qb * 32 * LDT, LDT, Kt + db * 32 * LDT, LDT, 64, lane);
+            if (db < DB) mma_at(acc[i], dSs + qb * 32 * LDT, LDT, Ks + db * 32, LDR, lane);
         }
     }
     bf16 *dqp = a.dq + (int64_t)b * a.sq * a.lddq + (int64_t)h * a.hd;
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // K / V are staged once, turned into MFMA fragments held in registers, and their LDS is reused for the Q / dO tiles
     bf16 *Ks = reinterpret_cast<bf16 *>(smem), *Vs = Ks + 64 * LDR, *Qs = Ks, *dOs = Vs;
-    bf16 *Qt = Vs + 64 * LDR, *dOt = Qt + DP * LDT, *Pt = dOt + DP * LDT, *dSt = Pt + 64 * LDT;
+    bf16 *Pt = Vs + 64 * LDR, *dSt = Pt + 64 * LDT;
     float *lse_s = reinterpret_cast<float *>(dSt + 64 * LDT), *delta_s = lse_s + 64;
     int *mk = reinterpret_cast<int *>(delta_s + 64);
 
@@ -339,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     if (q_begin < a.sq) fetch_q(q_begin);
     for (int q0 = q_begin; q0 < a.sq; q0 += 64) {
         __syncthreads();
-        store_tile<DP>(qr, Qs, Qt, tid);
-        store_tile<DP>(gr, dOs, dOt, tid);
+        store_tile<DP>(qr, Qs, nullptr, tid);
+        store_tile<DP>(gr, dOs, nullptr, tid);
         if (tid < 64) {
             lse_s[tid] = lr;
             delta_s[tid] = dr;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
             const int t = half * DB + i;
             const bool is_k = t >= DB;
             const int db = is_k ? t - DB : t;
-            mma_nt(acc[i], (is_k ? dSt : Pt) + kb * 32 * LDT, LDT, (is_k ? Qt : dOt) + db * 32 * LDT, LDT, 64, lane);
+            mma_at(acc[i], (is_k ? dSt : Pt) + kb * 32 * LDT, LDT, (is_k ? Qs : dOs) + db * 32, LDR, lane);
         }
     }
 #pragma unroll
@@ -394,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 template <int DB>
 int launch_attn_bwd(const AttnBwdArgs &a, hipStream_t s) {
     constexpr int DP = DB * 32, LDR = DP + 8;
-    const size_t smem_q = (size_t)(2 * 64 * LDR + DP * LDT + 64 * LDT) * 2 + (64 + 64 + 256) * 4 + 64 * 4;
-    const size_t smem_kv = (size_t)(2 * 64 * LDR + 2 * DP * LDT + 2 * 64 * LDT) * 2 + (64 + 64) * 4 + 64 * 4;
+    const size_t smem_q = (size_t)(2 * 64 * LDR + 64 * LDT) * 2 + (64 + 64 + 256) * 4 + 64 * 4;
+    const size_t smem_kv = (size_t)(2 * 64 * LDR + 2 * 64 * LDT) * 2 + (64 + 64) * 4 + 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q));
