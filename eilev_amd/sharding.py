@@ -46,3 +46,23 @@ def my_samples(num_samples: int, world: int, rank: int):
     """Contiguous block of samples whose language-model pass runs on `rank`."""
     per = (num_samples + world - 1) // world
     return list(range(rank * per, min(num_samples, (rank + 1) * per)))
+
+
+def gather_token_ids(local_ids: torch.Tensor, num_samples: int, pad_id: int = 1, group=None) -> torch.Tensor:
+    """Generated token ids of every sample of the global step, in sample order, on every rank — the analogue of the
+    reference's `accelerator.gather_for_metrics(generated_ids)` (ref:scripts/general/generate_narration_texts.py:124-127).
+
+    local_ids: (n_local, T) int ids of the samples of my_samples(num_samples, world, rank), in that order.  One all-gather of
+    (per, T) int64 per rank, per = ceil(num_samples / world) (ranks with fewer samples send pad rows that are cut off).
+    world == 1 (or no process group): identity."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_ids
+    world = dist.get_world_size(group)
+    per = (num_samples + world - 1) // world
+    T = local_ids.shape[1]
+    send = local_ids.new_full((per, T), pad_id)
+    send[: local_ids.shape[0]] = local_ids
+    recv = local_ids.new_empty((world * per, T))
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv[:num_samples] if num_samples == world * per else torch.cat(
+        [recv[r * per: r * per + len(my_samples(num_samples, world, r))] for r in range(world)])

@@ -90,3 +90,27 @@ def test_gradient_allreduce_averages_over_ranks():
         expect = (1.0 * (i + 1) + (0.0 if k == "p1" else 2.0 * (i + 1))) / 2
         for r in range(world):
             assert torch.allclose(ret[r][k], torch.full_like(ret[r][k], expect)), (k, r)
+
+
+def _ids_worker(rank, world, port, num_samples, ret):
+    from eilev_amd.sharding import gather_token_ids
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = my_samples(num_samples, world, rank)
+        local = torch.tensor([[s * 10 + t for t in range(5)] for s in mine], dtype=torch.int64).reshape(len(mine), 5)
+        ret[rank] = gather_token_ids(local, num_samples)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_samples", [8, 5, 1])
+def test_gather_generated_ids_in_sample_order(num_samples):
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_ids_worker, args=(world, port, num_samples, ret), nprocs=world, join=True)
+    expect = torch.tensor([[s * 10 + t for t in range(5)] for s in range(num_samples)], dtype=torch.int64)
+    for r in range(world):
+        assert torch.equal(ret[r], expect), (r, ret[r])
