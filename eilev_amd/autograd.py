@@ -131,6 +131,42 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.has_resid else None)
 
 
+class _LinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) with the activation in the GEMM epilogue.  The output doubles as the saved activation: relu'(pre) = (y > 0),
+    so no pre-activation tensor is written (GELU cannot do this and keeps the separate act kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _need(x, "linear_relu").reshape(-1, x.shape[-1])
+        w16 = _bf(weight)
+        N, K = w16.shape
+        M = x2.shape[0]
+        y = torch.empty((M, N), dtype=_BF, device=x2.device)
+        abi.check(_lib().eilev_linear(_p(x2), _p(w16), _p(None if bias is None else _bf(bias)), None, _p(y), M, N, K, 2, 0, _s()), "eilev_linear")
+        ctx.save_for_backward(y)
+        ctx.inner = (x2, weight, w16 if weight.requires_grad else None, bias, x.shape, _cur["frozen"])
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        x2, weight, w16, bias, xshape, frozen = ctx.inner
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("linear_relu is used for frozen layers (the OPT feed-forward); trainable layers use linear + relu")
+        if w16 is None:
+            w16 = _bf(weight)
+        N, K = w16.shape
+        dy2 = _need(dy, "linear_relu grad").reshape(-1, N)
+        dpre = torch.empty_like(dy2)
+        abi.check(_lib().eilev_act_bwd(_p(y), _p(dy2), _p(dpre), dy2.numel(), 2, _s()), "eilev_act_bwd")
+        dx = _gemm(dpre, _weight_t(weight, w16, frozen), None, None, dy2.shape[0], K, N).view(xshape)
+        return dx, None, None
+
+
+def linear_relu(x, weight, bias=None):
+    return _LinearReLU.apply(x, weight, bias)
+
+
 def linear(x, weight, bias=None, residual=None):
     return _Linear.apply(x, weight, bias, residual)
 

@@ -114,7 +114,7 @@ class TrainGraph:
             ctx = ag.attention_packed(qkv, H, scale, causal=True, key_mask=km).view(B * L, D)
             h = ag.linear(ctx, w("o_w"), w("o_b"), residual=h)
             x = ag.layer_norm(h, w("ln2_w"), w("ln2_b"), d.t_eps)
-            f = ag.relu(ag.linear(x, w("fc1_w"), w("fc1_b")))
+            f = ag.linear_relu(x, w("fc1_w"), w("fc1_b"))  # frozen layer: ReLU in the GEMM epilogue, the output is the saved activation
             h = ag.linear(f, w("fc2_w"), w("fc2_b"), residual=h)
         return ag.layer_norm(h, self.W("language_model.model.decoder.final_layer_norm.weight"),
                              self.W("language_model.model.decoder.final_layer_norm.bias"), d.t_eps).view(B, L, D)
