@@ -246,7 +246,8 @@ EXPORTS = [
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
-    "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss",
+    "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
+    "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd",
 ]
 
 
@@ -319,6 +320,18 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_act_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.eilev_ce_loss.restype = i32
     lib.eilev_ce_loss.argtypes = [vp, vp, f32, vp, vp, i64, i64, vp]
+    lib.eilev_attention_rel.restype = i32
+    lib.eilev_attention_rel.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, i64, i64, vp]
+    lib.eilev_attention_rel_bwd.restype = i32
+    lib.eilev_attention_rel_bwd.argtypes = [vp] * 9 + [i64] * 11 + [f32, i32, vp, vp, i64, i64, i64, vp]
+    lib.eilev_rmsnorm.restype = i32
+    lib.eilev_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, vp]
+    lib.eilev_rmsnorm_bwd.restype = i32
+    lib.eilev_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
+    lib.eilev_gated_gelu.restype = i32
+    lib.eilev_gated_gelu.argtypes = [vp, vp, i64, i64, vp]
+    lib.eilev_gated_gelu_bwd.restype = i32
+    lib.eilev_gated_gelu_bwd.argtypes = [vp, vp, vp, i64, i64, vp]
     TP = C.POINTER(T5Dims)
     lib.eilev_t5_workspace_bytes.restype = sz
     lib.eilev_t5_workspace_bytes.argtypes = [TP, i64, i64, i64]
@@ -343,7 +356,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 3:
+    if lib.eilev_abi_version() != 4:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

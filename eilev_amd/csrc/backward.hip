@@ -24,7 +24,16 @@ struct AttnBwdArgs {
     float scale;
     int causal;
     const int32_t *key_mask;  // (batch, skv) or null
+    // T5 relative position bias (frozen, additive before the softmax): rel_tab[h * rel_hs + clamp((key - query - (skv - sq)) + rel_off)]
+    const float *rel_tab = nullptr;
+    int64_t rel_hs = 0;
+    int rel_off = 0, rel_n = 0;
 };
+__device__ __forceinline__ float rel_bias(const AttnBwdArgs &a, int h, int key, int qpos) {
+    int ri = key - qpos + a.rel_off;
+    ri = ri < 0 ? 0 : (ri >= a.rel_n ? a.rel_n - 1 : ri);
+    return a.rel_tab[(int64_t)h * a.rel_hs + ri];
+}
 
 constexpr int LDT = 72;  // row stride (elements) of the 64-wide transposed / score tiles
 
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
             for (int r = 0; r < 16; ++r) {
                 const int kl = kb * 32 + crow(r, hi);
                 const bool ok = mk[kl] != 0 && (!a.causal || kv0 + kl <= qrow + off);
-                s[r] = ok ? s[r] * a.scale : -1e30f;
+                s[r] = ok ? s[r] * a.scale + (a.rel_tab ? rel_bias(a, h, kv0 + kl, qrow + off) : 0.0f) : -1e30f;
                 mx = fmaxf(mx, s[r]);
             }
             const float m_new = fmaxf(m_run, mx);
@@ -277,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
             for (int r = 0; r < 16; ++r) {
                 const int ql = qb2 * 32 + crow(r, hi);
                 const bool ok = kok && q0 + ql < a.sq && (!a.causal || kv0 + kl <= q0 + ql + off);
-                const float p = ok ? __expf(s[r] * a.scale - lse_s[ql]) : 0.0f;
+                const float bias = (ok && a.rel_tab) ? rel_bias(a, h, kv0 + kl, q0 + ql + off) : 0.0f;
+                const float p = ok ? __expf(s[r] * a.scale + bias - lse_s[ql]) : 0.0f;
                 dSs[ql * LDT + kl] = (bf16)(p * (dp[r] - delta_s[ql]));
             }
         }
@@ -370,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
             for (int r = 0; r < 16; ++r) {
                 const int kl = kb2 * 32 + crow(r, hi);
                 const bool ok = qok && mk[kl] != 0 && (!a.causal || kv0 + kl <= q0 + ql + off);
-                const float p = ok ? __expf(s[r] * a.scale - lse) : 0.0f;
+                const float bias = (ok && a.rel_tab) ? rel_bias(a, h, kv0 + kl, q0 + ql + off) : 0.0f;
+                const float p = ok ? __expf(s[r] * a.scale + bias - lse) : 0.0f;
                 Pt[kl * LDT + ql] = (bf16)p;
                 dSt[kl * LDT + ql] = (bf16)(p * (dp[r] - dl));
             }
@@ -555,6 +566,83 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16 *__restrict__ p
     *reinterpret_cast<bf16x8 *>(y + i * 8) = pack8(o);
 }
 
+// ---- T5LayerNorm (RMS, no bias; hf modeling_t5.py:50-72) backward: dx = rstd * (g - xhat * mean(g * xhat)), g = dy * gamma, xhat = x * rstd ----
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16 *__restrict__ x, const bf16 *__restrict__ gamma, const bf16 *__restrict__ dy,
+                                                          bf16 *__restrict__ dx, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;
+    const bf16 *xr = x + row * cols, *gr = dy + row * cols;
+    float v[MAXC][8], g[MAXC][8];
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            unpack8(*reinterpret_cast<const bf16x8 *>(xr + c * 8), v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sq += v[i][e] * v[i][e];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)cols + eps);
+    float s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            float gm[8];
+            unpack8(*reinterpret_cast<const bf16x8 *>(gr + c * 8), g[i]);
+            unpack8(*reinterpret_cast<const bf16x8 *>(gamma + c * 8), gm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] *= rstd;
+                g[i][e] *= gm[e];
+                s2 += g[i][e] * v[i][e];
+            }
+        }
+    }
+    s2 = wave_sum(s2) / (float)cols;
+    bf16 *dr = dx + row * cols;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - v[i][e] * s2);
+            *reinterpret_cast<bf16x8 *>(dr + c * 8) = pack8(o);
+        }
+    }
+}
+
+// ---- gated activation backward (T5DenseGatedActDense, hf modeling_t5.py:97-124): y = gelu_new(a) * b ----
+__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const bf16 *__restrict__ ab, const bf16 *__restrict__ dy, bf16 *__restrict__ dab,
+                                                             int64_t rows, int F) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = F >> 3;
+    if (idx >= rows * ch) return;
+    const int64_t r = idx / ch;
+    const int c = (int)(idx - r * ch);
+    float a[8], b[8], g[8], da[8], db[8];
+    unpack8(*reinterpret_cast<const bf16x8 *>(ab + r * 2 * F + c * 8), a);
+    unpack8(*reinterpret_cast<const bf16x8 *>(ab + r * 2 * F + F + c * 8), b);
+    unpack8(*reinterpret_cast<const bf16x8 *>(dy + r * F + c * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = a[e];
+        const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+        const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+        const float act = 0.5f * x * (1.0f + t);
+        const float dact = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286535588f * (1.0f + 3.0f * 0.044715f * x * x);
+        da[e] = g[e] * b[e] * dact;
+        db[e] = g[e] * act;
+    }
+    *reinterpret_cast<bf16x8 *>(dab + r * 2 * F + c * 8) = pack8(da);
+    *reinterpret_cast<bf16x8 *>(dab + r * 2 * F + F + c * 8) = pack8(db);
+}
+
 // ---- token cross-entropy: row_loss = lse - logit[target]; dlogits = (softmax - onehot) * grad_scale (0 for ignored rows) ---------
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets, float grad_scale,
                                                       float *__restrict__ row_loss, bf16 *__restrict__ dlogits, int vocab) {
@@ -592,10 +680,24 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
 
 }  // namespace
 
+extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
+                                       float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
+                                       int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                       void *stream);
 extern "C" int eilev_attention_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
                                    float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
                                    int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
                                    const int32_t *key_mask, void *stream) {
+    return eilev_attention_rel_bwd(q, k, v, o, d_o, dq, dk, dv, lse_delta, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, lddq, lddk, lddv, scale,
+                                   causal, key_mask, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
+                                       float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
+                                       int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                       void *stream) {
     if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse_delta || batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return EILEV_E_BADARG;
     if (head_dim % 8 != 0 || head_dim > 128 || ((ldq | ldk | ldv | lddq | lddk | lddv) & 7)) return EILEV_E_UNSUPPORTED;
     AttnBwdArgs a;
@@ -605,6 +707,8 @@ extern "C" int eilev_attention_bwd(const void *q, const void *k, const void *v, 
     a.batch = (int)batch; a.heads = (int)heads; a.sq = (int)sq; a.skv = (int)skv; a.hd = (int)head_dim;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = heads * head_dim; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.scale = scale; a.causal = causal; a.key_mask = key_mask;
+    if (rel_tab && (rel_n <= 0 || rel_stride < rel_n)) return EILEV_E_BADARG;
+    a.rel_tab = rel_tab; a.rel_hs = rel_stride; a.rel_off = (int)rel_off; a.rel_n = (int)rel_n;
     hipStream_t s = (hipStream_t)stream;
     if (head_dim <= 64) return launch_attn_bwd<2>(a, s);
     if (head_dim <= 96) return launch_attn_bwd<3>(a, s);
@@ -662,6 +766,59 @@ extern "C" int eilev_ce_loss(const float *logits, const int64_t *targets, float 
     if (!logits || !targets || !row_loss || !dlogits || rows <= 0 || vocab <= 0) return EILEV_E_BADARG;
     hipLaunchKernelGGL(ce_loss_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, targets, grad_scale, row_loss, (bf16 *)dlogits,
                        (int)vocab);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
+// ---- encoder-decoder (T5) language model: forward building blocks the training graph composes, and their gradients ----------------
+int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F, hipStream_t s);
+
+extern "C" int eilev_attention_rel(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq, int64_t skv,
+                                   int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal, const int32_t *key_mask,
+                                   const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n, void *stream) {
+    if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return EILEV_E_BADARG;
+    if (rel_tab && (rel_n <= 0 || rel_stride < rel_n)) return EILEV_E_BADARG;
+    AttnArgs a;
+    a.q = (const bf16 *)q; a.k = (const bf16 *)k; a.v = (const bf16 *)v; a.o = (bf16 *)o;
+    a.q_bs = sq * ldq; a.k_bs = skv * ldk; a.v_bs = skv * ldv; a.o_bs = sq * heads * head_dim;
+    a.q_hs = a.k_hs = a.v_hs = a.o_hs = head_dim;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = heads * head_dim;
+    a.batch = (int)batch; a.heads = (int)heads; a.sq = (int)sq; a.skv = (int)skv; a.hd = (int)head_dim; a.scale = scale;
+    a.causal = causal; a.key_mask = key_mask; a.mask_ld = skv; a.dbg = 0;
+    a.rel_tab = rel_tab; a.rel_hs = rel_stride; a.rel_off = (int)rel_off; a.rel_n = (int)rel_n;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int eilev_rmsnorm(const void *x, const void *gamma, void *y, int64_t rows, int64_t cols, float eps, void *stream) {
+    if (!x || !gamma || !y || rows <= 0 || cols <= 0) return EILEV_E_BADARG;
+    if (cols % 8 != 0 || cols > 4096) return EILEV_E_UNSUPPORTED;
+    return launch_rmsnorm((const bf16 *)x, cols, (const bf16 *)gamma, (bf16 *)y, cols, rows, (int)cols, eps, (hipStream_t)stream);
+}
+
+extern "C" int eilev_rmsnorm_bwd(const void *x, const void *gamma, const void *dy, void *dx, int64_t rows, int64_t cols, float eps, void *stream) {
+    if (!x || !gamma || !dy || !dx || rows <= 0 || cols <= 0) return EILEV_E_BADARG;
+    if (cols % 8 != 0 || cols > 4096) return EILEV_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const bf16 *xp = (const bf16 *)x, *gp = (const bf16 *)gamma, *dyp = (const bf16 *)dy;
+    if (cols <= 1536) hipLaunchKernelGGL(rmsnorm_bwd_kernel<3>, grid, dim3(256), 0, s, xp, gp, dyp, (bf16 *)dx, rows, (int)cols, eps);
+    else if (cols <= 2560) hipLaunchKernelGGL(rmsnorm_bwd_kernel<5>, grid, dim3(256), 0, s, xp, gp, dyp, (bf16 *)dx, rows, (int)cols, eps);
+    else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(256), 0, s, xp, gp, dyp, (bf16 *)dx, rows, (int)cols, eps);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
+extern "C" int eilev_gated_gelu(const void *ab, void *out, int64_t rows, int64_t f, void *stream) {
+    if (!ab || !out || rows <= 0 || f <= 0) return EILEV_E_BADARG;
+    return launch_gated_gelu((const bf16 *)ab, 2 * f, (bf16 *)out, rows, (int)f, (hipStream_t)stream);
+}
+
+extern "C" int eilev_gated_gelu_bwd(const void *ab, const void *dy, void *dab, int64_t rows, int64_t f, void *stream) {
+    if (!ab || !dy || !dab || rows <= 0 || f <= 0) return EILEV_E_BADARG;
+    if (f % 8 != 0) return EILEV_E_UNSUPPORTED;
+    const int64_t total = rows * (f >> 3);
+    hipLaunchKernelGGL(gated_gelu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)ab,
+                       (const bf16 *)dy, (bf16 *)dab, rows, (int)f);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

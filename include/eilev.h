@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 3
+#define EILEV_ABI_VERSION 4
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -336,6 +336,29 @@ int eilev_act_fwd(const void *pre, void *y, int64_t n, int kind, void *stream);
 int eilev_act_bwd(const void *pre, const void *dy, void *dx, int64_t n, int kind, void *stream);
 int eilev_ce_loss(const float *logits, const int64_t *targets, float grad_scale, float *row_loss, void *dlogits,
                   int64_t rows, int64_t vocab, void *stream);
+
+/* ---- encoder-decoder (T5) building blocks for the training graph (hf models/t5/modeling_t5.py) ---------------------------
+ * eilev_attention_rel / eilev_attention_rel_bwd: eilev_attention / eilev_attention_bwd with T5's additive relative position bias
+ *   (T5Attention :176-369, frozen on the train_v2 path: no gradient for it):
+ *   score(h, i, j) = scale * q_i . k_j + rel_tab[h * rel_stride + clamp((j - i - (skv - sq)) + rel_off, 0, rel_n - 1)];
+ *   rel_tab (f32, heads x rel_stride) holds the bias per relative distance; null = no bias.
+ * eilev_rmsnorm / eilev_rmsnorm_bwd: T5LayerNorm :50-72 (y = gamma * x * rsqrt(mean(x^2) + eps)) and its dx.
+ * eilev_gated_gelu / eilev_gated_gelu_bwd: T5DenseGatedActDense :97-124 on ab = [a | b] rows of 2 f columns:
+ *   out = gelu_new(a) * b (tanh form, hf activations NewGELUActivation); dab = [dy * b * gelu_new'(a) | dy * gelu_new(a)]. */
+int eilev_attention_rel(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq,
+                        int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal,
+                        const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off,
+                        int64_t rel_n, void *stream);
+int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq,
+                            void *dk, void *dv, float *lse_delta, int64_t batch, int64_t heads, int64_t sq,
+                            int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq,
+                            int64_t lddk, int64_t lddv, float scale, int causal, const int32_t *key_mask,
+                            const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n, void *stream);
+int eilev_rmsnorm(const void *x, const void *gamma, void *y, int64_t rows, int64_t cols, float eps, void *stream);
+int eilev_rmsnorm_bwd(const void *x, const void *gamma, const void *dy, void *dx, int64_t rows, int64_t cols, float eps,
+                      void *stream);
+int eilev_gated_gelu(const void *ab, void *out, int64_t rows, int64_t f, void *stream);
+int eilev_gated_gelu_bwd(const void *ab, const void *dy, void *dab, int64_t rows, int64_t f, void *stream);
 
 /* ---- kernel profiler (HIP library; no-ops returning 0 in the oracle) ----------------------------
  * When enabled, the dominant GEMM launches are bracketed with hipEvents on the launch stream.

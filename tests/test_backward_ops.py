@@ -245,3 +245,156 @@ def test_hip_act_and_ce():
     torch.cuda.synchronize()
     np.testing.assert_allclose(host(grl), rl, rtol=1e-5, atol=1e-5)
     assert np.abs(host(gdl) - dl).max() <= 8e-3 * np.abs(dl).max()
+
+
+# ---- encoder-decoder (T5) building blocks -------------------------------------------------------------------------------------
+def _rel_table(h, n, seed=5):
+    return (det_normal("rel", (h, n), seed) * 0.7).astype(np.float32)
+
+
+REL_CASES = [
+    # b, h, sq, skv, hd, causal, pad (right padding, as the T5 encoder sees it)
+    (2, 3, 40, 40, 16, 0, 6),    # encoder: bidirectional + key mask + bias
+    (2, 2, 37, 37, 64, 1, 0),    # decoder self-attention: causal + bias (flan-t5 d_kv = 64)
+    (1, 4, 130, 130, 64, 1, 0),  # several tiles
+]
+
+
+def _rel_inputs(b, h, sq, skv, hd, pad):
+    q, k, v, do, _ = _attn_inputs(b, h, sq, skv, hd, seed=7)
+    mask = None
+    if pad:
+        mask = np.ones((b, skv), np.int32)
+        mask[1, skv - pad:] = 0
+    return q, k, v, do, mask
+
+
+@pytest.mark.parametrize("b,h,sq,skv,hd,causal,pad", REL_CASES)
+def test_oracle_attention_rel_vs_autograd(b, h, sq, skv, hd, causal, pad):
+    L = orc.lib()
+    q, k, v, do, mask = _rel_inputs(b, h, sq, skv, hd, pad)
+    n = 2 * skv - 1
+    tab = _rel_table(h, n)
+    W = h * hd
+    o = np.empty((b, sq, W), np.float32)
+    assert L.eilev_attention_rel(pp(q), pp(k), pp(v), pp(o), b, h, sq, skv, hd, W, W, W, 1.0, causal, pp(mask), pp(tab), n, skv - 1, n, None) == 0
+    dq, dk, dv = np.empty_like(q), np.empty_like(k), np.empty_like(v)
+    ws = np.empty((2, b, h, sq), np.float32)
+    assert L.eilev_attention_rel_bwd(pp(q), pp(k), pp(v), pp(o), pp(do), pp(dq), pp(dk), pp(dv), pp(ws), b, h, sq, skv, hd, W, W, W, W, W, W, 1.0,
+                                     causal, pp(mask), pp(tab), n, skv - 1, n, None) == 0
+    tq, tk, tv = (torch.tensor(x, requires_grad=True) for x in (q, k, v))
+    Q, K, V = (t.view(b, -1, h, hd).transpose(1, 2) for t in (tq, tk, tv))
+    i = torch.arange(sq)[:, None]
+    j = torch.arange(skv)[None, :]
+    bias = torch.tensor(tab)[:, (j - i) + skv - 1]  # (h, sq, skv)
+    s = Q @ K.transpose(-1, -2) + bias[None]
+    ok = torch.ones(b, 1, sq, skv, dtype=torch.bool)
+    if causal:
+        ok = ok & (j <= i)
+    if mask is not None:
+        ok = ok & torch.tensor(mask, dtype=torch.bool)[:, None, None, :]
+    p = torch.softmax(s.masked_fill(~ok, float("-inf")), -1)
+    to = (p @ V).transpose(1, 2).reshape(b, sq, W)
+    to.backward(torch.tensor(do))
+    np.testing.assert_allclose(o, to.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for got, ref in ((dq, tq.grad.numpy()), (dk, tk.grad.numpy()), (dv, tv.grad.numpy())):
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_oracle_rmsnorm_gated_gelu_vs_autograd():
+    L = orc.lib()
+    rows, cols, F = 29, 96, 64
+    x = det_normal("x", (rows, cols), 1) * 2 + 0.3
+    g = det_normal("g", (cols,), 1) * 0.2 + 1
+    dy = det_normal("dy", (rows, cols), 1)
+    y, dx = np.empty_like(x), np.empty_like(x)
+    assert L.eilev_rmsnorm(pp(x), pp(g), pp(y), rows, cols, 1e-6, None) == 0
+    assert L.eilev_rmsnorm_bwd(pp(x), pp(g), pp(dy), pp(dx), rows, cols, 1e-6, None) == 0
+    tx = torch.tensor(x, requires_grad=True)
+    ty = torch.tensor(g) * (tx * torch.rsqrt(tx.pow(2).mean(-1, keepdim=True) + 1e-6))  # T5LayerNorm
+    ty.backward(torch.tensor(dy))
+    np.testing.assert_allclose(y, ty.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dx, tx.grad.numpy(), rtol=1e-4, atol=1e-5)
+    ab = det_normal("ab", (rows, 2 * F), 2) * 1.5
+    gy = det_normal("gy", (rows, F), 2)
+    out, dab = np.empty((rows, F), np.float32), np.empty_like(ab)
+    assert L.eilev_gated_gelu(pp(ab), pp(out), rows, F, None) == 0
+    assert L.eilev_gated_gelu_bwd(pp(ab), pp(gy), pp(dab), rows, F, None) == 0
+    tab_ = torch.tensor(ab, requires_grad=True)
+    a, bb = tab_[:, :F], tab_[:, F:]
+    tout = 0.5 * a * (1.0 + torch.tanh(0.7978845608028654 * (a + 0.044715 * a.pow(3)))) * bb  # NewGELUActivation * linear branch
+    tout.backward(torch.tensor(gy))
+    np.testing.assert_allclose(out, tout.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dab, tab_.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,sq,skv,hd,causal,pad", REL_CASES + [(2, 32, 200, 200, 64, 0, 30)])
+def test_hip_attention_rel(b, h, sq, skv, hd, causal, pad):
+    from eilev_amd import abi
+    from hip_utils import P, dev_bf16, host, stream_ptr
+
+    hip = abi.load_hip()
+    L = orc.lib()
+    q, k, v, do, mask = _rel_inputs(b, h, sq, skv, hd, pad)
+    n = 2 * skv - 1
+    tab = _rel_table(h, n)
+    W = h * hd
+    dq_, dk_, dv_, d_o = dev_bf16(q), dev_bf16(k), dev_bf16(v), dev_bf16(do)
+    dm = torch.from_numpy(mask).cuda() if mask is not None else None
+    dtab = torch.from_numpy(tab).cuda()
+    o = torch.empty((b, sq, W), dtype=torch.bfloat16, device="cuda")
+    assert hip.eilev_attention_rel(P(dq_), P(dk_), P(dv_), P(o), b, h, sq, skv, hd, W, W, W, 1.0, causal, P(dm), P(dtab), n, skv - 1, n,
+                                   stream_ptr()) == 0
+    ro = np.empty((b, sq, W), np.float32)
+    assert L.eilev_attention_rel(pp(q), pp(k), pp(v), pp(ro), b, h, sq, skv, hd, W, W, W, 1.0, causal, pp(mask), pp(tab), n, skv - 1, n, None) == 0
+    torch.cuda.synchronize()
+    o_np = host(o)
+    assert np.abs(o_np - ro).max() <= 1e-2 * np.abs(ro).max()
+    rdq, rdk, rdv = np.empty_like(q), np.empty_like(k), np.empty_like(v)
+    ws = np.empty((2, b, h, sq), np.float32)
+    assert L.eilev_attention_rel_bwd(pp(q), pp(k), pp(v), pp(o_np), pp(do), pp(rdq), pp(rdk), pp(rdv), pp(ws), b, h, sq, skv, hd, W, W, W, W, W, W,
+                                     1.0, causal, pp(mask), pp(tab), n, skv - 1, n, None) == 0
+    gq, gk, gv = torch.empty_like(dq_), torch.empty_like(dk_), torch.empty_like(dv_)
+    gws = torch.empty((2, b, h, sq), dtype=torch.float32, device="cuda")
+    assert hip.eilev_attention_rel_bwd(P(dq_), P(dk_), P(dv_), P(o), P(d_o), P(gq), P(gk), P(gv), P(gws), b, h, sq, skv, hd, W, W, W, W, W, W, 1.0,
+                                       causal, P(dm), P(dtab), n, skv - 1, n, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    for name, got, ref in (("dq", gq, rdq), ("dk", gk, rdk), ("dv", gv, rdv)):
+        err = np.abs(host(got) - ref).max()
+        assert err <= 2e-2 * np.abs(ref).max(), (name, err, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,F", [(29, 96, 64), (700, 2048, 5120), (65, 512, 1024)])
+def test_hip_rmsnorm_gated_gelu(rows, cols, F):
+    from eilev_amd import abi
+    from hip_utils import P, dev_bf16, host, stream_ptr
+
+    hip = abi.load_hip()
+    L = orc.lib()
+    x = round_bf16(det_normal("x", (rows, cols), 1) * 2 + 0.3)
+    g = round_bf16(det_normal("g", (cols,), 1) * 0.2 + 1)
+    dy = round_bf16(det_normal("dy", (rows, cols), 1))
+    ry, rdx = np.empty_like(x), np.empty_like(x)
+    assert L.eilev_rmsnorm(pp(x), pp(g), pp(ry), rows, cols, 1e-6, None) == 0
+    assert L.eilev_rmsnorm_bwd(pp(x), pp(g), pp(dy), pp(rdx), rows, cols, 1e-6, None) == 0
+    dx_, dg_, ddy = dev_bf16(x), dev_bf16(g), dev_bf16(dy)
+    y, gdx = torch.empty_like(dx_), torch.empty_like(dx_)
+    assert hip.eilev_rmsnorm(P(dx_), P(dg_), P(y), rows, cols, 1e-6, stream_ptr()) == 0
+    assert hip.eilev_rmsnorm_bwd(P(dx_), P(dg_), P(ddy), P(gdx), rows, cols, 1e-6, stream_ptr()) == 0
+    ab = round_bf16(det_normal("ab", (rows, 2 * F), 2) * 1.5)
+    gy = round_bf16(det_normal("gy", (rows, F), 2))
+    rout, rdab = np.empty((rows, F), np.float32), np.empty_like(ab)
+    assert L.eilev_gated_gelu(pp(ab), pp(rout), rows, F, None) == 0
+    assert L.eilev_gated_gelu_bwd(pp(ab), pp(gy), pp(rdab), rows, F, None) == 0
+    dab_, dgy = dev_bf16(ab), dev_bf16(gy)
+    out = torch.empty((rows, F), dtype=torch.bfloat16, device="cuda")
+    gdab = torch.empty_like(dab_)
+    assert hip.eilev_gated_gelu(P(dab_), P(out), rows, F, stream_ptr()) == 0
+    assert hip.eilev_gated_gelu_bwd(P(dab_), P(dgy), P(gdab), rows, F, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert np.abs(host(y) - ry).max() <= 1e-2 * np.abs(ry).max()
+    assert np.abs(host(gdx) - rdx).max() <= 1e-2 * np.abs(rdx).max()
+    np.testing.assert_allclose(host(out), rout, rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(host(gdab), rdab, rtol=1e-2, atol=2e-3)
