@@ -207,37 +207,50 @@ def layer_norm(x, gamma, beta, eps):
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, causal, key_mask):
+    def forward(ctx, q, k, v, heads, scale, causal, key_mask, rel):
         q, k, v = _need(q, "attention q"), _need(k, "attention k"), _need(v, "attention v")
         B, Sq, D = q.shape
         Skv = k.shape[1]
         hd = D // heads
         km = None if key_mask is None else key_mask.to(torch.int32).contiguous()
         o = torch.empty_like(q)
-        abi.check(_lib().eilev_attention(_p(q), _p(k), _p(v), _p(o), B, heads, Sq, Skv, hd, D, D, D, float(scale), int(causal), _p(km), _s()),
-                  "eilev_attention")
-        ctx.save_for_backward(q, k, v, o, km)
-        ctx.cfg = (heads, float(scale), int(causal))
+        tab, roff = _rel_args(rel, heads)
+        abi.check(_lib().eilev_attention_rel(_p(q), _p(k), _p(v), _p(o), B, heads, Sq, Skv, hd, D, D, D, float(scale), int(causal), _p(km),
+                                             _p(tab), 0 if tab is None else tab.shape[1], roff, 0 if tab is None else tab.shape[1], _s()),
+                  "eilev_attention_rel")
+        ctx.save_for_backward(q, k, v, o, km, tab)
+        ctx.cfg = (heads, float(scale), int(causal), roff)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        q, k, v, o, km = ctx.saved_tensors
-        heads, scale, causal = ctx.cfg
+        q, k, v, o, km, tab = ctx.saved_tensors
+        heads, scale, causal, roff = ctx.cfg
         B, Sq, D = q.shape
         Skv = k.shape[1]
         hd = D // heads
         d_o = _need(d_o, "attention grad")
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty((2, B, heads, Sq), dtype=torch.float32, device=q.device)
-        abi.check(_lib().eilev_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, Sq, Skv, hd,
-                                             D, D, D, D, D, D, scale, causal, _p(km), _s()), "eilev_attention_bwd")
-        return dq, dk, dv, None, None, None, None
+        rn = 0 if tab is None else tab.shape[1]
+        abi.check(_lib().eilev_attention_rel_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, Sq, Skv, hd,
+                                                 D, D, D, D, D, D, scale, causal, _p(km), _p(tab), rn, roff, rn, _s()), "eilev_attention_rel_bwd")
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, heads, scale, causal=False, key_mask=None):
+def _rel_args(rel, heads):
+    """rel = (table, offset): f32 (heads, n) bias per relative distance (key - query) + offset; frozen (no gradient)."""
+    if rel is None:
+        return None, 0
+    tab, off = rel
+    if tab.dtype != torch.float32 or tab.dim() != 2 or tab.shape[0] != heads or not tab.is_contiguous() or tab.requires_grad:
+        raise TypeError("relative position bias: a contiguous frozen f32 (heads, n) table is expected")
+    return tab, int(off)
+
+
+def attention(q, k, v, heads, scale, causal=False, key_mask=None, rel=None):
     """q (B, Sq, heads*hd), k / v (B, Skv, heads*hd) -> (B, Sq, heads*hd); causal: key <= query + (Skv - Sq)."""
-    return _Attention.apply(q, k, v, heads, scale, causal, key_mask)
+    return _Attention.apply(q, k, v, heads, scale, causal, key_mask, rel)
 
 
 class _AttentionPacked(torch.autograd.Function):
@@ -245,7 +258,7 @@ class _AttentionPacked(torch.autograd.Function):
     the backward writes dq|dk|dv into one (B, S, 3 D) tensor — the gradient of the fused projection, no slicing copies."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale, causal, key_mask):
+    def forward(ctx, qkv, heads, scale, causal, key_mask, rel):
         qkv = _need(qkv, "attention qkv")
         B, S, D3 = qkv.shape
         D = D3 // 3
@@ -253,16 +266,18 @@ class _AttentionPacked(torch.autograd.Function):
         km = None if key_mask is None else key_mask.to(torch.int32).contiguous()
         o = torch.empty((B, S, D), dtype=_BF, device=qkv.device)
         base = qkv.data_ptr()
-        abi.check(_lib().eilev_attention(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), B, heads, S, S, hd,
-                                         D3, D3, D3, float(scale), int(causal), _p(km), _s()), "eilev_attention")
-        ctx.save_for_backward(qkv, o, km)
-        ctx.cfg = (heads, float(scale), int(causal))
+        tab, roff = _rel_args(rel, heads)
+        rn = 0 if tab is None else tab.shape[1]
+        abi.check(_lib().eilev_attention_rel(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), B, heads, S, S, hd,
+                                             D3, D3, D3, float(scale), int(causal), _p(km), _p(tab), rn, roff, rn, _s()), "eilev_attention_rel")
+        ctx.save_for_backward(qkv, o, km, tab)
+        ctx.cfg = (heads, float(scale), int(causal), roff)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        qkv, o, km = ctx.saved_tensors
-        heads, scale, causal = ctx.cfg
+        qkv, o, km, tab = ctx.saved_tensors
+        heads, scale, causal, roff = ctx.cfg
         B, S, D3 = qkv.shape
         D = D3 // 3
         hd = D // heads
@@ -270,15 +285,72 @@ class _AttentionPacked(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         ws = torch.empty((2, B, heads, S), dtype=torch.float32, device=qkv.device)
         base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-        abi.check(_lib().eilev_attention_bwd(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), _p(d_o),
-                                             C.c_void_p(dbase), C.c_void_p(dbase + 2 * D), C.c_void_p(dbase + 4 * D), _p(ws), B, heads, S, S, hd,
-                                             D3, D3, D3, D3, D3, D3, scale, causal, _p(km), _s()), "eilev_attention_bwd")
-        return dqkv, None, None, None, None
+        rn = 0 if tab is None else tab.shape[1]
+        abi.check(_lib().eilev_attention_rel_bwd(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), _p(d_o),
+                                                 C.c_void_p(dbase), C.c_void_p(dbase + 2 * D), C.c_void_p(dbase + 4 * D), _p(ws), B, heads, S, S,
+                                                 hd, D3, D3, D3, D3, D3, D3, scale, causal, _p(km), _p(tab), rn, roff, rn, _s()),
+                  "eilev_attention_rel_bwd")
+        return dqkv, None, None, None, None, None
 
 
-def attention_packed(qkv, heads, scale, causal=False, key_mask=None):
+def attention_packed(qkv, heads, scale, causal=False, key_mask=None, rel=None):
     """qkv (B, S, 3 * heads * hd) = [q | k | v] per row -> (B, S, heads * hd)."""
-    return _AttentionPacked.apply(qkv, heads, scale, causal, key_mask)
+    return _AttentionPacked.apply(qkv, heads, scale, causal, key_mask, rel)
+
+
+class _RMSNorm(torch.autograd.Function):
+    """T5LayerNorm with a frozen weight (hf modeling_t5.py:50-72)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, eps):
+        x2 = _need(x, "rms_norm").reshape(-1, x.shape[-1])
+        g16 = _bf(gamma)
+        y = torch.empty_like(x2)
+        abi.check(_lib().eilev_rmsnorm(_p(x2), _p(g16), _p(y), x2.shape[0], x2.shape[1], float(eps), _s()), "eilev_rmsnorm")
+        ctx.save_for_backward(x2, g16)
+        ctx.eps = float(eps)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("the T5 layer-norm weights are frozen on the train_v2 path")
+        x2, g16 = ctx.saved_tensors
+        dy2 = _need(dy, "rms_norm grad").reshape(x2.shape)
+        dx = torch.empty_like(x2)
+        abi.check(_lib().eilev_rmsnorm_bwd(_p(x2), _p(g16), _p(dy2), _p(dx), x2.shape[0], x2.shape[1], ctx.eps, _s()), "eilev_rmsnorm_bwd")
+        return dx.view(dy.shape), None, None
+
+
+def rms_norm(x, gamma, eps):
+    return _RMSNorm.apply(x, gamma, eps)
+
+
+class _GatedGelu(torch.autograd.Function):
+    """gelu_new(a) * b on rows [a | b] (T5DenseGatedActDense, hf modeling_t5.py:97-124)."""
+
+    @staticmethod
+    def forward(ctx, ab):
+        ab2 = _need(ab, "gated_gelu").reshape(-1, ab.shape[-1])
+        F = ab2.shape[1] // 2
+        out = torch.empty((ab2.shape[0], F), dtype=_BF, device=ab2.device)
+        abi.check(_lib().eilev_gated_gelu(_p(ab2), _p(out), ab2.shape[0], F, _s()), "eilev_gated_gelu")
+        ctx.save_for_backward(ab2)
+        ctx.shape = ab.shape
+        return out.view(*ab.shape[:-1], F)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ab2,) = ctx.saved_tensors
+        F = ab2.shape[1] // 2
+        dy2 = _need(dy, "gated_gelu grad").reshape(-1, F)
+        dab = torch.empty_like(ab2)
+        abi.check(_lib().eilev_gated_gelu_bwd(_p(ab2), _p(dy2), _p(dab), ab2.shape[0], F, _s()), "eilev_gated_gelu_bwd")
+        return dab.view(ctx.shape)
+
+
+def gated_gelu(ab):
+    return _GatedGelu.apply(ab)
 
 
 class _Act(torch.autograd.Function):

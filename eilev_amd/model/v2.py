@@ -300,8 +300,14 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         if not return_dict:
             return (loss,)
+        if self._is_t5:
+            from transformers.modeling_outputs import Seq2SeqLMOutput
+
+            lm_out = Seq2SeqLMOutput(loss=loss, logits=None)
+        else:
+            lm_out = CausalLMOutputWithPast(loss=loss, logits=None)
         return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=None, vision_outputs=None, qformer_outputs=None,
-                                                        language_model_outputs=CausalLMOutputWithPast(loss=loss, logits=None))
+                                                        language_model_outputs=lm_out)
 
     @torch.no_grad()
     def _forward_eval(self, input_ids, attention_mask=None, pixel_values=None, video_input_mask=None, decoder_input_ids=None,

@@ -5,6 +5,7 @@ language projection) trains; ref:eilev/model/v2.py:132-252 is the forward whose 
 
     frames -> ViT (frozen: the inference kernels, no graph) -> Q-Former -> language_projection -> scatter into the token
     embeddings -> OPT decoder (frozen weights, activation gradients) -> shifted token cross-entropy
+                | flan-t5 encoder -> decoder on the shifted labels (frozen weights, activation gradients) -> token cross-entropy
 
 Everything after the ViT is composed from the autograd-wrapped HIP kernels of eilev_amd/autograd.py, so
 `loss.backward()` runs the gradient kernels of eilev_amd/csrc/backward.hip and leaves `.grad` on the trainable
@@ -12,6 +13,8 @@ parameters exactly as the reference's `accelerator.backward(loss)` does.  Dropou
 while `model.train()`) is NOT applied: the graph is the deterministic eval-mode function, documented in DESIGN.md §5h.
 """
 from __future__ import annotations
+
+import math
 
 import torch
 
@@ -40,8 +43,6 @@ class TrainGraph:
     every other weight is read from the engine's frozen bf16 copies."""
 
     def __init__(self, engine, params: dict):
-        if engine.is_t5:
-            raise NotImplementedError("training through the encoder-decoder (T5) language model is not built")
         self.eng = engine
         self.params = dict(params)
         ok = ("qformer.", "query_tokens", "language_projection.")
@@ -119,8 +120,100 @@ class TrainGraph:
         return ag.layer_norm(h, self.W("language_model.model.decoder.final_layer_norm.weight"),
                              self.W("language_model.model.decoder.final_layer_norm.bias"), d.t_eps).view(B, L, D)
 
+    # ---- flan-t5 with frozen weights (hf modeling_t5.py: T5Stack encoder + decoder, RMS norms, relative position bias, ----
+    # ---- gated-GELU feed-forward, no 1/sqrt(d) scaling; ref:eilev/model/v2.py:228-238) ------------------------------------
+    def _frozen(self, tag, build):
+        cache = self.eng.__dict__.setdefault("_train_fused_t5", {})
+        hit = cache.get(tag)
+        if hit is None:
+            hit = cache[tag] = build()
+        return hit
+
+    def _t5_cat(self, tag, keys):
+        def build():
+            ws = [self.W(k) for k in keys]
+            if any(t.requires_grad for t in ws):
+                raise NotImplementedError("the language model is frozen on the train_v2 path")
+            return torch.cat(ws, 0).contiguous()
+        return self._frozen(tag, build)
+
+    def _t5_rel(self, stack: str, L: int):
+        """f32 (heads, 2 L - 1) bias over key - query in [-(L-1), L-1] (T5Attention._relative_position_bucket :217-262, float32
+        arithmetic in the same order as the torch ops) and the offset L - 1."""
+        d = self.eng.t5dims
+        bidirectional = stack == "encoder"
+
+        def build():
+            w = self.W(f"language_model.{stack}.block.0.layer.0.SelfAttention.relative_attention_bias.weight")  # (buckets, heads)
+            rp = torch.arange(-(L - 1), L, device=w.device)  # memory position - context position
+            nb = d.rel_buckets
+            ret = torch.zeros_like(rp)
+            if bidirectional:
+                nb //= 2
+                ret = ret + (rp > 0).to(torch.long) * nb
+                rp = rp.abs()
+            else:
+                rp = -torch.min(rp, torch.zeros_like(rp))
+            max_exact = nb // 2
+            large = max_exact + (torch.log(rp.float() / max_exact) / math.log(d.rel_max_dist / max_exact) * (nb - max_exact)).to(torch.long)
+            large = torch.min(large, torch.full_like(large, nb - 1))
+            bucket = ret + torch.where(rp < max_exact, rp, large)
+            return w.float()[bucket].t().contiguous()
+        return self._frozen(("rel", stack, L), build), L - 1
+
+    def _t5_ff(self, h, k, tag):
+        d = self.eng.t5dims
+        x = ag.rms_norm(h, self.W(k["ln_ff"]), d.eps)
+        ab = ag.linear(x, self._t5_cat(tag + ("wi",), [k["wi0_w"], k["wi1_w"]]))
+        return ag.linear(ag.gated_gelu(ab), self.W(k["wo_w"]), residual=h)
+
+    def t5_loss(self, emb: torch.Tensor, enc_mask: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        d = self.eng.t5dims
+        B, Le, D = emb.shape
+        H, I = d.heads, d.heads * d.d_kv
+        km = enc_mask.to(emb.device, torch.int32).contiguous()
+        h = emb.reshape(B * Le, D)
+        rel = self._t5_rel("encoder", Le)
+        for l in range(d.enc_layers):
+            k = abi.t5_layer_keys("encoder", l)
+            x = ag.rms_norm(h, self.W(k["ln_sa"]), d.eps)
+            qkv = ag.linear(x, self._t5_cat(("enc", l, "qkv"), [k["q_w"], k["k_w"], k["v_w"]])).view(B, Le, 3 * I)
+            ctx = ag.attention_packed(qkv, H, 1.0, causal=False, key_mask=km, rel=rel).view(B * Le, I)
+            h = ag.linear(ctx, self.W(k["o_w"]), residual=h)
+            h = self._t5_ff(h, k, ("enc", l))
+        enc = ag.rms_norm(h, self.W("language_model.encoder.final_layer_norm.weight"), d.eps)  # (B * Le, D)
+
+        t = self.eng.config.text_config
+        lab = labels.to(emb.device)
+        Lt = lab.shape[1]
+        start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
+        dec_ids = torch.cat((torch.full_like(lab[:, :1], start), lab[:, :-1]), dim=1)  # T5._shift_right
+        dec_ids = dec_ids.masked_fill(dec_ids == -100, t.pad_token_id)
+        g = self.W("language_model.shared.weight")[dec_ids].reshape(B * Lt, D)  # frozen embedding rows
+        rel = self._t5_rel("decoder", Lt)
+        for l in range(d.dec_layers):
+            k = abi.t5_layer_keys("decoder", l)
+            x = ag.rms_norm(g, self.W(k["ln_sa"]), d.eps)
+            qkv = ag.linear(x, self._t5_cat(("dec", l, "qkv"), [k["q_w"], k["k_w"], k["v_w"]])).view(B, Lt, 3 * I)
+            ctx = ag.attention_packed(qkv, H, 1.0, causal=True, rel=rel).view(B * Lt, I)
+            g = ag.linear(ctx, self.W(k["o_w"]), residual=g)
+            x = ag.rms_norm(g, self.W(k["ln_ca"]), d.eps)
+            q = ag.linear(x, self.W(k["cq_w"])).view(B, Lt, I)
+            kv = ag.linear(enc, self._t5_cat(("dec", l, "ckv"), [k["ck_w"], k["cv_w"]])).view(B, Le, 2, I)
+            ctx = ag.attention(q, kv[:, :, 0], kv[:, :, 1], H, 1.0, causal=False, key_mask=km).view(B * Lt, I)
+            g = ag.linear(ctx, self.W(k["co_w"]), residual=g)
+            g = self._t5_ff(g, k, ("dec", l))
+        out = ag.rms_norm(g, self.W("language_model.decoder.final_layer_norm.weight"), d.eps)
+        if d.scale_decoder_outputs:  # tied embeddings: hf :1037-1041
+            out = out * (D ** -0.5)
+        sel = lab.reshape(-1) >= 0
+        head = self.params.get("language_model.lm_head.weight")
+        if head is None:
+            head = self.eng._keep.get("language_model.lm_head.weight", self.eng._keep["language_model.shared.weight"])
+        return ag.lm_head_ce(out[sel].contiguous(), head, lab.reshape(-1)[sel])
+
     def loss(self, input_ids, attention_mask, pixel_values, video_input_mask, labels) -> torch.Tensor:
-        """Shifted causal-LM cross-entropy (ignore_index -100), differentiable w.r.t. ``params``."""
+        """Token cross-entropy (ignore_index -100; shifted for the decoder-only LM), differentiable w.r.t. ``params``."""
         eng = self.eng
         ag.new_step(eng.__dict__.setdefault("_train_frozen_t", {}))  # transposed frozen weights live and die with the engine
         dev = eng.device
@@ -136,6 +229,8 @@ class TrainGraph:
             emb = _EmbedScatter.apply(feats, eng, input_ids, video_input_mask)
         else:
             emb = eng.embed_scatter(input_ids, None, None)
+        if eng.is_t5:
+            return self.t5_loss(emb, attention_mask, labels)
         hid = self.opt_hidden(emb, attention_mask)
         tgt = labels.to(dev)[:, 1:]
         sel = tgt >= 0  # position t predicts labels[t + 1]

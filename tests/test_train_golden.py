@@ -157,3 +157,42 @@ def test_model_forward_returns_trainable_loss():
     for k, p in model.named_parameters():
         if p.requires_grad:
             assert torch.allclose(p.grad, g1[k], rtol=1e-3, atol=1e-6 + 1e-3 * float(g1[k].abs().max())), k
+
+
+@pytest.mark.parametrize("case", ["tiny_t5_b2", "mid_t5_b2"])
+def test_t5_train_step_matches_reference_autograd(case):
+    """Encoder-decoder language model (flan-t5 family): loss on the decoder targets, gradients through the frozen T5 stacks."""
+    from eilev_amd.train import TrainGraph
+    from hip_utils import models
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, f"train_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, _, eng = models(meta["config"])
+    sd = synth_state_dict(cfg)
+    params = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in sd.items() if k.startswith(TRAINABLE)}
+    pixels, input_ids, attn, vmask, _ = _batch(meta)
+    input_ids = np.where(attn == 1, input_ids, 0)  # T5 pad id
+    t = lambda a: torch.from_numpy(a).cuda()
+    loss = TrainGraph(eng, params).loss(t(input_ids), t(attn), t(pixels), t(vmask), t(g["labels"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(g["loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 2e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
+    norms = dict(zip([str(k) for k in g["norm_keys"]], g["norms"]))
+    assert set(norms) == set(params)
+    floor = 2e-3 * float(max(norms.values()))
+    worst = 0.0
+    for k, ref in norms.items():
+        got = float(params[k].grad.float().norm())
+        if ref > floor:
+            worst = max(worst, abs(got - ref) / ref)
+        assert abs(got - ref) <= 6e-2 * ref + floor, (k, got, ref)
+    for key in g.files:
+        if not key.startswith("grad::"):
+            continue
+        ref = g[key].astype(np.float64).reshape(-1)
+        got = params[key[6:]].grad.float().cpu().numpy().astype(np.float64).reshape(-1)
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+        assert cos >= 0.995, (key, cos)
+    print(f"{case}: loss {float(loss.detach()):.5f} vs {ref_loss:.5f}; worst grad-norm error {worst:.4f}")
