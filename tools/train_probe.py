@@ -37,7 +37,13 @@ def main():
     params = {k: v.float().requires_grad_(True) for k, v in w.items() if k.startswith(("qformer.", "query_tokens", "language_projection."))}
     n_par = sum(p.numel() for p in params.values())
     px, ids, vm, am = bench.build_inputs(cfg, args.samples, dev)
-    labels = torch.where(vm == 0, ids, torch.full_like(ids, -100))
+    if eng.is_t5:  # encoder-decoder LM: the targets are the 14 tokens of the last narration (decoder side), ids stay below the vocabulary
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        ids = ids.clamp(max=cfg.text_config.vocab_size - 1)
+        labels = torch.randint(4, cfg.text_config.vocab_size, (args.samples, 14), device=dev, generator=g)
+    else:
+        labels = torch.where(vm == 0, ids, torch.full_like(ids, -100))
     graph = TrainGraph(eng, params)
     opt = torch.optim.AdamW(list(params.values()), lr=1e-5)
     ev = lambda: torch.cuda.Event(enable_timing=True)
