@@ -247,7 +247,8 @@ EXPORTS = [
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
     "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
-    "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd",
+    "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
+    "eilev_attention_dropout_bwd",
 ]
 
 
@@ -332,6 +333,13 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_gated_gelu.argtypes = [vp, vp, i64, i64, vp]
     lib.eilev_gated_gelu_bwd.restype = i32
     lib.eilev_gated_gelu_bwd.argtypes = [vp, vp, vp, i64, i64, vp]
+    u32 = C.c_uint32
+    lib.eilev_dropout_add.restype = i32
+    lib.eilev_dropout_add.argtypes = [vp, vp, vp, i64, f32, u32, vp]
+    lib.eilev_attention_dropout.restype = i32
+    lib.eilev_attention_dropout.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, i64, i64, f32, u32, vp]
+    lib.eilev_attention_dropout_bwd.restype = i32
+    lib.eilev_attention_dropout_bwd.argtypes = [vp] * 9 + [i64] * 11 + [f32, i32, vp, vp, i64, i64, i64, f32, u32, vp]
     TP = C.POINTER(T5Dims)
     lib.eilev_t5_workspace_bytes.restype = sz
     lib.eilev_t5_workspace_bytes.argtypes = [TP, i64, i64, i64]
@@ -356,7 +364,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 4:
+    if lib.eilev_abi_version() != 5:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

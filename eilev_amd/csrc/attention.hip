@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
                 const float p = okv[ct][r] ? exp2f(st[ct][r] - m_new) : 0.0f;
                 st[ct][r] = p;
                 rs += p;
+                if (a.drop_thr) {  // training: the row sum keeps every probability, the product with V only the kept ones (scaled)
+                    const uint64_t idx = (((uint64_t)b * a.heads + h) * a.sq + qrow) * (uint64_t)a.skv + (kv0 + ct * 16 + lg * 4 + r);
+                    st[ct][r] = eilev_hash32(a.drop_seed, idx) >= a.drop_thr ? p * a.drop_scale : 0.0f;
+                }
             }
         rs += __shfl_xor(rs, 16, 64);
         rs += __shfl_xor(rs, 32, 64);
@@ -768,10 +772,10 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         (a.k_hs & 7) || (a.v_hs & 7) || (a.o_hs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.v_bs & 7) || (a.o_bs & 7))
         return EILEV_E_UNSUPPORTED;
     // whole-frame ViT attention: S = 257 (17 tiles of 16), hd = 88, no mask, q / k / v rows of one fused buffer
-    if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
+    if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && !a.drop_thr && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
         a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll)
         return launch_attn_frame<88, 17>(a, s);
-    if (!g_attn_force_v1 && !a.rel_tab && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
+    if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
         const int qt = (a.sq + 31) / 32;
         if (qt == 9 || qt > 16) return (qt == 9) ? launch_attn_v2<9>(a, s) : launch_attn_v2<8>(a, s);
         if (qt >= 5) return launch_attn_v2<8>(a, s);

@@ -28,7 +28,16 @@ struct AttnBwdArgs {
     const float *rel_tab = nullptr;
     int64_t rel_hs = 0;
     int rel_off = 0, rel_n = 0;
+    // dropout on the probabilities (same mask function as the forward kernel): o = (P * M / (1 - p)) V
+    uint32_t drop_thr = 0, drop_seed = 0;
+    float drop_scale = 1.0f;
 };
+// M(b, h, q, key) / (1 - p): 0 for a dropped probability
+__device__ __forceinline__ float drop_factor(const AttnBwdArgs &a, int b, int h, int q, int key) {
+    if (!a.drop_thr) return 1.0f;
+    const uint64_t idx = (((uint64_t)b * a.heads + h) * a.sq + q) * (uint64_t)a.skv + key;
+    return eilev_hash32(a.drop_seed, idx) >= a.drop_thr ? a.drop_scale : 0.0f;
+}
 __device__ __forceinline__ float rel_bias(const AttnBwdArgs &a, int h, int key, int qpos) {
     int ri = key - qpos + a.rel_off;
     ri = ri < 0 ? 0 : (ri >= a.rel_n ? a.rel_n - 1 : ri);
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
                 const bool ok = kok && q0 + ql < a.sq && (!a.causal || kv0 + kl <= q0 + ql + off);
                 const float bias = (ok && a.rel_tab) ? rel_bias(a, h, kv0 + kl, q0 + ql + off) : 0.0f;
                 const float p = ok ? __expf(s[r] * a.scale + bias - lse_s[ql]) : 0.0f;
-                dSs[ql * LDT + kl] = (bf16)(p * (dp[r] - delta_s[ql]));
+                dSs[ql * LDT + kl] = (bf16)(p * (dp[r] * drop_factor(a, b, h, q0 + ql, kv0 + kl) - delta_s[ql]));
             }
         }
         __syncthreads();
@@ -382,8 +391,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
                 const bool ok = qok && mk[kl] != 0 && (!a.causal || kv0 + kl <= q0 + ql + off);
                 const float bias = (ok && a.rel_tab) ? rel_bias(a, h, kv0 + kl, q0 + ql + off) : 0.0f;
                 const float p = ok ? __expf(s[r] * a.scale + bias - lse) : 0.0f;
-                Pt[kl * LDT + ql] = (bf16)p;
-                dSt[kl * LDT + ql] = (bf16)(p * (dp[r] - dl));
+                const float df = drop_factor(a, b, h, q0 + ql, kv0 + kl);
+                Pt[kl * LDT + ql] = (bf16)(p * df);  // dV sees the dropped, rescaled probabilities
+                dSt[kl * LDT + ql] = (bf16)(p * (dp[r] * df - dl));
             }
         }
         __syncthreads();
@@ -643,6 +653,22 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const bf16 *__restr
     *reinterpret_cast<bf16x8 *>(dab + r * 2 * F + F + c * 8) = pack8(db);
 }
 
+// ---- hidden-state dropout: y = x * M / (1 - p) (+ resid); the backward is the same call on dy without resid ----------------------
+__global__ __launch_bounds__(256) void dropout_add_kernel(const bf16 *__restrict__ x, const bf16 *__restrict__ resid, bf16 *__restrict__ y, int64_t n8,
+                                                          uint32_t thr, uint32_t seed, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], r[8], o[8];
+    unpack8(*reinterpret_cast<const bf16x8 *>(x + i * 8), v);
+    if (resid) unpack8(*reinterpret_cast<const bf16x8 *>(resid + i * 8), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float kept = eilev_hash32(seed, (uint64_t)i * 8 + e) >= thr ? v[e] * scale : 0.0f;
+        o[e] = resid ? (float)(bf16)kept + r[e] : kept;  // rounded like a separate dropout output before the residual add
+    }
+    *reinterpret_cast<bf16x8 *>(y + i * 8) = pack8(o);
+}
+
 // ---- token cross-entropy: row_loss = lse - logit[target]; dlogits = (softmax - onehot) * grad_scale (0 for ignored rows) ---------
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets, float grad_scale,
                                                       float *__restrict__ row_loss, bf16 *__restrict__ dlogits, int vocab) {
@@ -680,24 +706,11 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
 
 }  // namespace
 
-extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
-                                       float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
-                                       int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
-                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
-                                       void *stream);
-extern "C" int eilev_attention_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
-                                   float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
-                                   int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
-                                   const int32_t *key_mask, void *stream) {
-    return eilev_attention_rel_bwd(q, k, v, o, d_o, dq, dk, dv, lse_delta, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, lddq, lddk, lddv, scale,
-                                   causal, key_mask, nullptr, 0, 0, 0, stream);
-}
-
-extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
-                                       float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
-                                       int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
-                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
-                                       void *stream) {
+namespace {
+int attn_bwd_impl(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv, float *lse_delta,
+                  int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq,
+                  int64_t lddk, int64_t lddv, float scale, int causal, const int32_t *key_mask, const float *rel_tab, int64_t rel_stride,
+                  int64_t rel_off, int64_t rel_n, float drop_p, uint32_t drop_seed, void *stream) {
     if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse_delta || batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return EILEV_E_BADARG;
     if (head_dim % 8 != 0 || head_dim > 128 || ((ldq | ldk | ldv | lddq | lddk | lddv) & 7)) return EILEV_E_UNSUPPORTED;
     AttnBwdArgs a;
@@ -709,10 +722,39 @@ extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void 
     a.scale = scale; a.causal = causal; a.key_mask = key_mask;
     if (rel_tab && (rel_n <= 0 || rel_stride < rel_n)) return EILEV_E_BADARG;
     a.rel_tab = rel_tab; a.rel_hs = rel_stride; a.rel_off = (int)rel_off; a.rel_n = (int)rel_n;
+    if (drop_p > 0.0f) {
+        a.drop_thr = eilev_drop_threshold(drop_p); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (head_dim <= 64) return launch_attn_bwd<2>(a, s);
     if (head_dim <= 96) return launch_attn_bwd<3>(a, s);
     return launch_attn_bwd<4>(a, s);
+}
+}  // namespace
+
+extern "C" int eilev_attention_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
+                                   float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
+                                   int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                                   const int32_t *key_mask, void *stream) {
+    return attn_bwd_impl(q, k, v, o, d_o, dq, dk, dv, lse_delta, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, lddq, lddk, lddv, scale, causal,
+                         key_mask, nullptr, 0, 0, 0, 0.0f, 0, stream);
+}
+extern "C" int eilev_attention_rel_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk, void *dv,
+                                       float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq,
+                                       int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                       void *stream) {
+    return attn_bwd_impl(q, k, v, o, d_o, dq, dk, dv, lse_delta, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, lddq, lddk, lddv, scale, causal,
+                         key_mask, rel_tab, rel_stride, rel_off, rel_n, 0.0f, 0, stream);
+}
+extern "C" int eilev_attention_dropout_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq, void *dk,
+                                           void *dv, float *lse_delta, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim,
+                                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
+                                           int causal, const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off,
+                                           int64_t rel_n, float dropout_p, uint32_t seed, void *stream) {
+    if (!(dropout_p >= 0.0f && dropout_p < 1.0f)) return EILEV_E_BADARG;
+    return attn_bwd_impl(q, k, v, o, d_o, dq, dk, dv, lse_delta, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, lddq, lddk, lddv, scale, causal,
+                         key_mask, rel_tab, rel_stride, rel_off, rel_n, dropout_p, seed, stream);
 }
 
 extern "C" int eilev_layernorm_bwd(const void *x, const void *gamma, const void *dy, void *dx, float *dgamma, float *dbeta, float *stats,
@@ -773,10 +815,22 @@ extern "C" int eilev_ce_loss(const float *logits, const int64_t *targets, float 
 // ---- encoder-decoder (T5) language model: forward building blocks the training graph composes, and their gradients ----------------
 int launch_gated_gelu(const bf16 *ab, int64_t ld, bf16 *out, int64_t rows, int F, hipStream_t s);
 
+extern "C" int eilev_attention_dropout(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq,
+                                       int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal,
+                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                       float dropout_p, uint32_t seed, void *stream);
 extern "C" int eilev_attention_rel(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq, int64_t skv,
                                    int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal, const int32_t *key_mask,
                                    const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n, void *stream) {
-    if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return EILEV_E_BADARG;
+    return eilev_attention_dropout(q, k, v, o, batch, heads, sq, skv, head_dim, ldq, ldk, ldv, scale, causal, key_mask, rel_tab, rel_stride, rel_off,
+                                   rel_n, 0.0f, 0, stream);
+}
+
+extern "C" int eilev_attention_dropout(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq,
+                                       int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal,
+                                       const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                       float dropout_p, uint32_t seed, void *stream) {
+    if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0 || !(dropout_p >= 0.0f && dropout_p < 1.0f)) return EILEV_E_BADARG;
     if (rel_tab && (rel_n <= 0 || rel_stride < rel_n)) return EILEV_E_BADARG;
     AttnArgs a;
     a.q = (const bf16 *)q; a.k = (const bf16 *)k; a.v = (const bf16 *)v; a.o = (bf16 *)o;
@@ -786,7 +840,19 @@ extern "C" int eilev_attention_rel(const void *q, const void *k, const void *v, 
     a.batch = (int)batch; a.heads = (int)heads; a.sq = (int)sq; a.skv = (int)skv; a.hd = (int)head_dim; a.scale = scale;
     a.causal = causal; a.key_mask = key_mask; a.mask_ld = skv; a.dbg = 0;
     a.rel_tab = rel_tab; a.rel_hs = rel_stride; a.rel_off = (int)rel_off; a.rel_n = (int)rel_n;
+    if (dropout_p > 0.0f) {
+        a.drop_thr = eilev_drop_threshold(dropout_p); a.drop_seed = seed; a.drop_scale = 1.0f / (1.0f - dropout_p);
+    }
     return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int eilev_dropout_add(const void *x, const void *resid, void *y, int64_t n, float dropout_p, uint32_t seed, void *stream) {
+    if (!x || !y || n <= 0 || !(dropout_p >= 0.0f && dropout_p < 1.0f)) return EILEV_E_BADARG;
+    if (n % 8 != 0) return EILEV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x,
+                       (const bf16 *)resid, (bf16 *)y, n / 8, eilev_drop_threshold(dropout_p), seed, 1.0f / (1.0f - dropout_p));
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
 }
 
 extern "C" int eilev_rmsnorm(const void *x, const void *gamma, void *y, int64_t rows, int64_t cols, float eps, void *stream) {

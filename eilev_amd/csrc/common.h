@@ -24,6 +24,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
         if (_e != hipSuccess) return (int)_e;          \
     } while (0)
 
+// Counter-based dropout mask (splitmix64 finaliser): the same function in the forward and the backward kernels and in the oracle,
+// so a mask is never stored.  keep iff hash >= p * 2^32.
+__host__ __device__ __forceinline__ uint32_t eilev_hash32(uint32_t seed, uint64_t idx) {
+    uint64_t z = idx + 0x9E3779B97F4A7C15ull * ((uint64_t)seed + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+__host__ __forceinline__ uint32_t eilev_drop_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 
@@ -149,6 +163,10 @@ struct AttnArgs {
     const float *rel_tab = nullptr;
     int64_t rel_hs = 0;
     int rel_off = 0, rel_n = 0;
+    // dropout on the attention probabilities (training graph): element (b, h, i, j) is kept iff eilev_hash32(drop_seed, its linear
+    // index) >= drop_thr, kept probabilities are scaled by drop_scale = 1 / (1 - p); drop_thr = 0: none
+    uint32_t drop_thr = 0, drop_seed = 0;
+    float drop_scale = 1.0f;
 };
 int launch_attention(const AttnArgs &a, hipStream_t s);
 int launch_rmsnorm(const bf16 *x, int64_t ldx, const bf16 *g, bf16 *y, int64_t ldy, int64_t rows, int cols, float eps, hipStream_t s);

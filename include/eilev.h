@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 4
+#define EILEV_ABI_VERSION 5
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -359,6 +359,29 @@ int eilev_rmsnorm_bwd(const void *x, const void *gamma, const void *dy, void *dx
                       void *stream);
 int eilev_gated_gelu(const void *ab, void *out, int64_t rows, int64_t f, void *stream);
 int eilev_gated_gelu_bwd(const void *ab, const void *dy, void *dab, int64_t rows, int64_t f, void *stream);
+
+/* ---- dropout of the training graph (`model.train()` under Trainer: hidden_dropout_prob / attention_probs_dropout_prob of the
+ * Q-Former, `dropout` of OPT, `dropout_rate` of T5) ------------------------------------------------------------------------
+ * Masks are a pure function of (seed, element index): keep iff hash(seed, index) >= p * 2^32 with (`eilev_hash32` in csrc/common.h)
+ *   z = index + 0x9E3779B97F4A7C15 * (seed + 1); z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9; z = (z ^ z >> 27) * 0x94D049BB133111EB;
+ *   hash = (z ^ z >> 31) >> 32                                                     (splitmix64 finaliser, 64-bit wrap-around)
+ * so the backward recomputes the mask of the forward and nothing is stored; torch's Philox stream is NOT reproduced (no two
+ * dropout implementations share masks; parity is against the oracle, which restates the same function).
+ * eilev_dropout_add: y = x * M / (1 - p) (+ resid when non-null; the dropped value is rounded to the storage type first); its
+ *   gradient w.r.t. x is the same call on dy with resid = null.  index = element offset.
+ * eilev_attention_dropout(_bwd): eilev_attention_rel(_bwd) with dropout on the probabilities AFTER the softmax normalisation
+ *   (hf Blip2QFormerMultiHeadAttention / T5Attention): o = (softmax(s) * M / (1 - p)) v; index = ((b * heads + h) * sq + i) * skv + j. */
+int eilev_dropout_add(const void *x, const void *resid, void *y, int64_t n, float dropout_p, uint32_t seed, void *stream);
+int eilev_attention_dropout(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads, int64_t sq,
+                            int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, float scale, int causal,
+                            const int32_t *key_mask, const float *rel_tab, int64_t rel_stride, int64_t rel_off,
+                            int64_t rel_n, float dropout_p, uint32_t seed, void *stream);
+int eilev_attention_dropout_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq,
+                                void *dk, void *dv, float *lse_delta, int64_t batch, int64_t heads, int64_t sq,
+                                int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq,
+                                int64_t lddk, int64_t lddv, float scale, int causal, const int32_t *key_mask,
+                                const float *rel_tab, int64_t rel_stride, int64_t rel_off, int64_t rel_n,
+                                float dropout_p, uint32_t seed, void *stream);
 
 /* ---- kernel profiler (HIP library; no-ops returning 0 in the oracle) ----------------------------
  * When enabled, the dominant GEMM launches are bracketed with hipEvents on the launch stream.

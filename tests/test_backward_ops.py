@@ -398,3 +398,101 @@ def test_hip_rmsnorm_gated_gelu(rows, cols, F):
     assert np.abs(host(gdx) - rdx).max() <= 1e-2 * np.abs(rdx).max()
     np.testing.assert_allclose(host(out), rout, rtol=2e-2, atol=2e-3)
     np.testing.assert_allclose(host(gdab), rdab, rtol=1e-2, atol=2e-3)
+
+
+# ---- dropout of the training graph -------------------------------------------------------------------------------------------
+def _hash32(seed, idx):
+    """include/eilev.h: splitmix64 finaliser of (seed, element index) (numpy uint64 wraps like the C code)."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(seed + 1)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(32)).astype(np.uint32)
+
+
+def _keep(seed, idx, p):
+    return _hash32(seed, idx) >= np.uint32(min(int(p * 4294967296.0), 4294967295))
+
+
+def test_oracle_dropout_vs_autograd_with_the_same_mask():
+    L = orc.lib()
+    n, p, seed = 8 * 1201, 0.1, 12345
+    x = det_normal("x", (n,), 4)
+    r = det_normal("r", (n,), 5)
+    y = np.empty_like(x)
+    assert L.eilev_dropout_add(pp(x), pp(r), pp(y), n, p, seed, None) == 0
+    keep = _keep(seed, np.arange(n), p)
+    assert abs(keep.mean() - 0.9) < 0.02
+    np.testing.assert_allclose(y, np.where(keep, x / np.float32(0.9), 0).astype(np.float32) + r, rtol=1e-6, atol=1e-6)
+    # attention: the oracle's gradients = autograd of softmax(s) * M / (1 - p) @ v with M taken from the documented hash
+    b, h, sq, skv, hd, causal = 2, 3, 37, 50, 16, 0
+    q, k, v, do, _ = _attn_inputs(b, h, sq, skv, hd, seed=9)
+    W = h * hd
+    o = np.empty((b, sq, W), np.float32)
+    assert L.eilev_attention_dropout(pp(q), pp(k), pp(v), pp(o), b, h, sq, skv, hd, W, W, W, 0.25, causal, None, None, 0, 0, 0, p, seed, None) == 0
+    dq, dk, dv = np.empty_like(q), np.empty_like(k), np.empty_like(v)
+    ws = np.empty((2, b, h, sq), np.float32)
+    assert L.eilev_attention_dropout_bwd(pp(q), pp(k), pp(v), pp(o), pp(do), pp(dq), pp(dk), pp(dv), pp(ws), b, h, sq, skv, hd, W, W, W, W, W, W,
+                                         0.25, causal, None, None, 0, 0, 0, p, seed, None) == 0
+    idx = np.arange(b * h * sq * skv).reshape(b, h, sq, skv)
+    M = torch.tensor(_keep(seed, idx, p).astype(np.float32) / 0.9)
+    tq, tk, tv = (torch.tensor(a, requires_grad=True) for a in (q, k, v))
+    Q, K, V = (t.view(b, -1, h, hd).transpose(1, 2) for t in (tq, tk, tv))
+    to = ((torch.softmax(Q @ K.transpose(-1, -2) * 0.25, -1) * M) @ V).transpose(1, 2).reshape(b, sq, W)
+    to.backward(torch.tensor(do))
+    np.testing.assert_allclose(o, to.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for got, ref in ((dq, tq.grad.numpy()), (dk, tk.grad.numpy()), (dv, tv.grad.numpy())):
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,sq,skv,hd,causal,rel", [(2, 3, 37, 50, 16, 0, False), (17, 12, 32, 300, 64, 0, False), (2, 4, 70, 70, 64, 1, True)])
+def test_hip_dropout(b, h, sq, skv, hd, causal, rel):
+    from eilev_amd import abi
+    from hip_utils import P, dev_bf16, host, stream_ptr
+
+    hip = abi.load_hip()
+    L = orc.lib()
+    p, seed = 0.1, 777
+    n = 8 * 4099
+    x = round_bf16(det_normal("x", (n,), 4))
+    r = round_bf16(det_normal("r", (n,), 5))
+    ry = np.empty_like(x)
+    assert L.eilev_dropout_add(pp(x), pp(r), pp(ry), n, p, seed, None) == 0
+    dx, dr = dev_bf16(x), dev_bf16(r)
+    y = torch.empty_like(dx)
+    assert hip.eilev_dropout_add(P(dx), P(dr), P(y), n, p, seed, stream_ptr()) == 0
+    y2 = torch.empty_like(dx)
+    assert hip.eilev_dropout_add(P(dx), None, P(y2), n, p, seed, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(y), ry, rtol=1e-2, atol=1e-2)
+    assert np.array_equal(host(y2) == 0, ~_keep(seed, np.arange(n), p) | (x == 0))  # exactly the documented mask
+    q, k, v, do, _ = _attn_inputs(b, h, sq, skv, hd, seed=9)
+    W = h * hd
+    nrel = 2 * skv - 1
+    tab = _rel_table(h, nrel) if rel else None
+    dtab = torch.from_numpy(tab).cuda() if rel else None
+    ra = (pp(tab), nrel, skv - 1, nrel) if rel else (None, 0, 0, 0)
+    ga = (P(dtab), nrel, skv - 1, nrel) if rel else (None, 0, 0, 0)
+    scale = hd ** -0.5
+    dq_, dk_, dv_, d_o = dev_bf16(q), dev_bf16(k), dev_bf16(v), dev_bf16(do)
+    o = torch.empty((b, sq, W), dtype=torch.bfloat16, device="cuda")
+    assert hip.eilev_attention_dropout(P(dq_), P(dk_), P(dv_), P(o), b, h, sq, skv, hd, W, W, W, scale, causal, None, *ga, p, seed, stream_ptr()) == 0
+    ro = np.empty((b, sq, W), np.float32)
+    assert L.eilev_attention_dropout(pp(q), pp(k), pp(v), pp(ro), b, h, sq, skv, hd, W, W, W, scale, causal, None, *ra, p, seed, None) == 0
+    torch.cuda.synchronize()
+    o_np = host(o)
+    assert np.abs(o_np - ro).max() <= 1.5e-2 * np.abs(ro).max()
+    rdq, rdk, rdv = np.empty_like(q), np.empty_like(k), np.empty_like(v)
+    ws = np.empty((2, b, h, sq), np.float32)
+    assert L.eilev_attention_dropout_bwd(pp(q), pp(k), pp(v), pp(o_np), pp(do), pp(rdq), pp(rdk), pp(rdv), pp(ws), b, h, sq, skv, hd, W, W, W, W, W,
+                                         W, scale, causal, None, *ra, p, seed, None) == 0
+    gq, gk, gv = torch.empty_like(dq_), torch.empty_like(dk_), torch.empty_like(dv_)
+    gws = torch.empty((2, b, h, sq), dtype=torch.float32, device="cuda")
+    assert hip.eilev_attention_dropout_bwd(P(dq_), P(dk_), P(dv_), P(o), P(d_o), P(gq), P(gk), P(gv), P(gws), b, h, sq, skv, hd, W, W, W, W, W, W,
+                                           scale, causal, None, *ga, p, seed, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    for name, got, ref in (("dq", gq, rdq), ("dk", gk, rdk), ("dv", gv, rdv)):
+        err = np.abs(host(got) - ref).max()
+        assert err <= 2e-2 * np.abs(ref).max(), (name, err, np.abs(ref).max())
