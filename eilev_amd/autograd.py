@@ -207,7 +207,7 @@ def layer_norm(x, gamma, beta, eps):
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, causal, key_mask, rel):
+    def forward(ctx, q, k, v, heads, scale, causal, key_mask, rel, drop):
         q, k, v = _need(q, "attention q"), _need(k, "attention k"), _need(v, "attention v")
         B, Sq, D = q.shape
         Skv = k.shape[1]
@@ -215,17 +215,18 @@ class _Attention(torch.autograd.Function):
         km = None if key_mask is None else key_mask.to(torch.int32).contiguous()
         o = torch.empty_like(q)
         tab, roff = _rel_args(rel, heads)
-        abi.check(_lib().eilev_attention_rel(_p(q), _p(k), _p(v), _p(o), B, heads, Sq, Skv, hd, D, D, D, float(scale), int(causal), _p(km),
-                                             _p(tab), 0 if tab is None else tab.shape[1], roff, 0 if tab is None else tab.shape[1], _s()),
-                  "eilev_attention_rel")
+        dp, dseed = _drop_args(drop)
+        abi.check(_lib().eilev_attention_dropout(_p(q), _p(k), _p(v), _p(o), B, heads, Sq, Skv, hd, D, D, D, float(scale), int(causal), _p(km),
+                                                 _p(tab), 0 if tab is None else tab.shape[1], roff, 0 if tab is None else tab.shape[1], dp, dseed,
+                                                 _s()), "eilev_attention_dropout")
         ctx.save_for_backward(q, k, v, o, km, tab)
-        ctx.cfg = (heads, float(scale), int(causal), roff)
+        ctx.cfg = (heads, float(scale), int(causal), roff, dp, dseed)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q, k, v, o, km, tab = ctx.saved_tensors
-        heads, scale, causal, roff = ctx.cfg
+        heads, scale, causal, roff, dp, dseed = ctx.cfg
         B, Sq, D = q.shape
         Skv = k.shape[1]
         hd = D // heads
@@ -233,9 +234,10 @@ class _Attention(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty((2, B, heads, Sq), dtype=torch.float32, device=q.device)
         rn = 0 if tab is None else tab.shape[1]
-        abi.check(_lib().eilev_attention_rel_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, Sq, Skv, hd,
-                                                 D, D, D, D, D, D, scale, causal, _p(km), _p(tab), rn, roff, rn, _s()), "eilev_attention_rel_bwd")
-        return dq, dk, dv, None, None, None, None, None
+        abi.check(_lib().eilev_attention_dropout_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, Sq, Skv, hd,
+                                                     D, D, D, D, D, D, scale, causal, _p(km), _p(tab), rn, roff, rn, dp, dseed, _s()),
+                  "eilev_attention_dropout_bwd")
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 def _rel_args(rel, heads):
@@ -248,9 +250,16 @@ def _rel_args(rel, heads):
     return tab, int(off)
 
 
-def attention(q, k, v, heads, scale, causal=False, key_mask=None, rel=None):
+def _drop_args(drop):
+    """drop = (p, seed) or None: dropout on the attention probabilities (include/eilev.h "dropout of the training graph")."""
+    if drop is None or drop[0] <= 0.0:
+        return 0.0, 0
+    return float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+
+
+def attention(q, k, v, heads, scale, causal=False, key_mask=None, rel=None, drop=None):
     """q (B, Sq, heads*hd), k / v (B, Skv, heads*hd) -> (B, Sq, heads*hd); causal: key <= query + (Skv - Sq)."""
-    return _Attention.apply(q, k, v, heads, scale, causal, key_mask, rel)
+    return _Attention.apply(q, k, v, heads, scale, causal, key_mask, rel, drop)
 
 
 class _AttentionPacked(torch.autograd.Function):
@@ -258,7 +267,7 @@ class _AttentionPacked(torch.autograd.Function):
     the backward writes dq|dk|dv into one (B, S, 3 D) tensor — the gradient of the fused projection, no slicing copies."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale, causal, key_mask, rel):
+    def forward(ctx, qkv, heads, scale, causal, key_mask, rel, drop):
         qkv = _need(qkv, "attention qkv")
         B, S, D3 = qkv.shape
         D = D3 // 3
@@ -268,16 +277,18 @@ class _AttentionPacked(torch.autograd.Function):
         base = qkv.data_ptr()
         tab, roff = _rel_args(rel, heads)
         rn = 0 if tab is None else tab.shape[1]
-        abi.check(_lib().eilev_attention_rel(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), B, heads, S, S, hd,
-                                             D3, D3, D3, float(scale), int(causal), _p(km), _p(tab), rn, roff, rn, _s()), "eilev_attention_rel")
+        dp, dseed = _drop_args(drop)
+        abi.check(_lib().eilev_attention_dropout(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), B, heads, S, S, hd,
+                                                 D3, D3, D3, float(scale), int(causal), _p(km), _p(tab), rn, roff, rn, dp, dseed, _s()),
+                  "eilev_attention_dropout")
         ctx.save_for_backward(qkv, o, km, tab)
-        ctx.cfg = (heads, float(scale), int(causal), roff)
+        ctx.cfg = (heads, float(scale), int(causal), roff, dp, dseed)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         qkv, o, km, tab = ctx.saved_tensors
-        heads, scale, causal, roff = ctx.cfg
+        heads, scale, causal, roff, dp, dseed = ctx.cfg
         B, S, D3 = qkv.shape
         D = D3 // 3
         hd = D // heads
@@ -286,16 +297,44 @@ class _AttentionPacked(torch.autograd.Function):
         ws = torch.empty((2, B, heads, S), dtype=torch.float32, device=qkv.device)
         base, dbase = qkv.data_ptr(), dqkv.data_ptr()
         rn = 0 if tab is None else tab.shape[1]
-        abi.check(_lib().eilev_attention_rel_bwd(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), _p(d_o),
-                                                 C.c_void_p(dbase), C.c_void_p(dbase + 2 * D), C.c_void_p(dbase + 4 * D), _p(ws), B, heads, S, S,
-                                                 hd, D3, D3, D3, D3, D3, D3, scale, causal, _p(km), _p(tab), rn, roff, rn, _s()),
-                  "eilev_attention_rel_bwd")
-        return dqkv, None, None, None, None, None
+        abi.check(_lib().eilev_attention_dropout_bwd(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), _p(o), _p(d_o),
+                                                     C.c_void_p(dbase), C.c_void_p(dbase + 2 * D), C.c_void_p(dbase + 4 * D), _p(ws), B, heads, S,
+                                                     S, hd, D3, D3, D3, D3, D3, D3, scale, causal, _p(km), _p(tab), rn, roff, rn, dp, dseed,
+                                                     _s()), "eilev_attention_dropout_bwd")
+        return dqkv, None, None, None, None, None, None
 
 
-def attention_packed(qkv, heads, scale, causal=False, key_mask=None, rel=None):
+def attention_packed(qkv, heads, scale, causal=False, key_mask=None, rel=None, drop=None):
     """qkv (B, S, 3 * heads * hd) = [q | k | v] per row -> (B, S, heads * hd)."""
-    return _AttentionPacked.apply(qkv, heads, scale, causal, key_mask, rel)
+    return _AttentionPacked.apply(qkv, heads, scale, causal, key_mask, rel, drop)
+
+
+class _DropoutAdd(torch.autograd.Function):
+    """x * M / (1 - p) (+ residual): nn.Dropout on a hidden state followed by the residual add, mask recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        x = _need(x, "dropout")
+        r = None if residual is None else _need(residual, "dropout residual")
+        y = torch.empty_like(x)
+        abi.check(_lib().eilev_dropout_add(_p(x), _p(r), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF, _s()), "eilev_dropout_add")
+        ctx.cfg = (float(p), int(seed) & 0xFFFFFFFF, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, has_r = ctx.cfg
+        dy = _need(dy, "dropout grad")
+        dx = torch.empty_like(dy)
+        abi.check(_lib().eilev_dropout_add(_p(dy), None, _p(dx), dy.numel(), p, seed, _s()), "eilev_dropout_add")
+        return dx, (dy if has_r else None), None, None
+
+
+def dropout_add(x, residual, p, seed):
+    """dropout(x) + residual (residual may be None); p == 0 is a plain add."""
+    if p <= 0.0:
+        return x if residual is None else x + residual
+    return _DropoutAdd.apply(x, residual, p, seed)
 
 
 class _RMSNorm(torch.autograd.Function):

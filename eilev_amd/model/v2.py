@@ -296,7 +296,11 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if cached is None or cached[0] != key:  # frozen weights -> bf16 device copies, once (trainable ones are read live)
             _require_gpu(self.query_tokens, type(self).__name__)
             cached = self._hip_train = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device))
-        loss = TrainGraph(cached[1], params).loss(input_ids, attention_mask, pixel_values, video_input_mask, labels)
+        # train() mode = dropout on, as under the reference's Trainer; a fresh mask seed every call (torch's seed + a call counter)
+        self._hip_train_calls = getattr(self, "_hip_train_calls", 0) + 1
+        seed = (torch.initial_seed() * 1000003 + self._hip_train_calls) & 0xFFFFFFFF
+        graph = TrainGraph(cached[1], params, dropout=getattr(self, "hip_train_dropout", True), seed=seed)
+        loss = graph.loss(input_ids, attention_mask, pixel_values, video_input_mask, labels)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         if not return_dict:
             return (loss,)

@@ -9,8 +9,9 @@ language projection) trains; ref:eilev/model/v2.py:132-252 is the forward whose 
 
 Everything after the ViT is composed from the autograd-wrapped HIP kernels of eilev_amd/autograd.py, so
 `loss.backward()` runs the gradient kernels of eilev_amd/csrc/backward.hip and leaves `.grad` on the trainable
-parameters exactly as the reference's `accelerator.backward(loss)` does.  Dropout (0.1 in the Q-Former / OPT configs
-while `model.train()`) is NOT applied: the graph is the deterministic eval-mode function, documented in DESIGN.md §5h.
+parameters exactly as the reference's `accelerator.backward(loss)` does.  Dropout (0.1 in the Q-Former / OPT / T5 configs
+while `model.train()`) is applied at the reference's sites when `TrainGraph(dropout=True)` (the model class does so in train()
+mode), with counter-based masks recomputed in the backward; dropout=False is the deterministic function.
 """
 from __future__ import annotations
 
@@ -42,7 +43,13 @@ class TrainGraph:
     """Loss of one batch on the HIP kernels.  ``params``: trainable tensors by state-dict key (fp32 masters or bf16);
     every other weight is read from the engine's frozen bf16 copies."""
 
-    def __init__(self, engine, params: dict):
+    def __init__(self, engine, params: dict, dropout: bool = False, seed: int = 0):
+        """dropout=True applies the configuration's dropout probabilities at every site the reference applies them in `train()` mode
+        (Q-Former hidden / attention-probability dropout, OPT residual-branch dropout, T5 dropout_rate sites) with masks derived from
+        ``seed`` (pass a different seed every step); dropout=False is the deterministic function the goldens pin."""
+        self.dropout = bool(dropout)
+        self.seed = int(seed)
+        self._site = 0
         self.eng = engine
         self.params = dict(params)
         ok = ("qformer.", "query_tokens", "language_projection.")
@@ -54,6 +61,23 @@ class TrainGraph:
         p = self.params.get(key)
         return p if p is not None else self.eng._keep[key]
 
+    # ---- dropout sites: every call draws the next mask seed of the step (same order forward after forward) ----
+    def _seed(self):
+        self._site += 1
+        return (self.seed * 2654435761 + self._site * 40503) & 0xFFFFFFFF
+
+    def _lin_res(self, x, w, b, resid, p):
+        """dense -> dropout -> + residual (hf *SelfOutput / *Output / OPTDecoderLayer / T5Layer*); fused into the GEMM without dropout"""
+        if self.dropout and p > 0.0:
+            return ag.dropout_add(ag.linear(x, w, b), resid, p, self._seed())
+        return ag.linear(x, w, b, residual=resid)
+
+    def _drop(self, x, p):
+        return ag.dropout_add(x, None, p, self._seed()) if self.dropout and p > 0.0 else x
+
+    def _adrop(self, p):
+        return (p, self._seed()) if self.dropout and p > 0.0 else None
+
     # ---- Q-Former (hf modeling_blip_2.py Blip2QFormerModel: post-LN BERT layers, cross-attention every q_cross_freq) ----
     def qformer(self, image_embeds: torch.Tensor) -> torch.Tensor:
         d = self.eng.dims
@@ -63,7 +87,9 @@ class TrainGraph:
         img = image_embeds.reshape(N * kv, Dv)
         qt = self.W("query_tokens").reshape(nq, D)
         q0 = ag.layer_norm(qt.to(torch.bfloat16), self.W("qformer.layernorm.weight"), self.W("qformer.layernorm.bias"), d.q_eps)
-        h = q0.unsqueeze(0).expand(N, nq, D).reshape(N * nq, D)
+        qc = self.eng.config.qformer_config
+        ph, pa = float(qc.hidden_dropout_prob), float(qc.attention_probs_dropout_prob)
+        h = self._drop(q0.unsqueeze(0).expand(N, nq, D).reshape(N * nq, D), ph)  # hf :913 dropout(layernorm(query_embeds))
         for l in range(d.q_layers):
             cross = l % d.q_cross_freq == 0
             k = abi.qf_layer_keys(l, cross)
@@ -71,16 +97,16 @@ class TrainGraph:
             q = ag.linear(h, w("sq_w"), w("sq_b")).view(N, nq, D)
             kk = ag.linear(h, w("sk_w"), w("sk_b")).view(N, nq, D)
             v = ag.linear(h, w("sv_w"), w("sv_b")).view(N, nq, D)
-            ctx = ag.attention(q, kk, v, H, scale).view(N * nq, D)
-            h = ag.layer_norm(ag.linear(ctx, w("so_w"), w("so_b"), residual=h), w("sln_w"), w("sln_b"), d.q_eps)
+            ctx = ag.attention(q, kk, v, H, scale, drop=self._adrop(pa)).view(N * nq, D)
+            h = ag.layer_norm(self._lin_res(ctx, w("so_w"), w("so_b"), h, ph), w("sln_w"), w("sln_b"), d.q_eps)
             if cross:
                 q = ag.linear(h, w("cq_w"), w("cq_b")).view(N, nq, D)
                 kk = ag.linear(img, w("ck_w"), w("ck_b")).view(N, kv, D)
                 v = ag.linear(img, w("cv_w"), w("cv_b")).view(N, kv, D)
-                ctx = ag.attention(q, kk, v, H, scale).view(N * nq, D)
-                h = ag.layer_norm(ag.linear(ctx, w("co_w"), w("co_b"), residual=h), w("cln_w"), w("cln_b"), d.q_eps)
+                ctx = ag.attention(q, kk, v, H, scale, drop=self._adrop(pa)).view(N * nq, D)
+                h = ag.layer_norm(self._lin_res(ctx, w("co_w"), w("co_b"), h, ph), w("cln_w"), w("cln_b"), d.q_eps)
             f = ag.gelu(ag.linear(h, w("fi_w"), w("fi_b")))
-            h = ag.layer_norm(ag.linear(f, w("fo_w"), w("fo_b"), residual=h), w("fln_w"), w("fln_b"), d.q_eps)
+            h = ag.layer_norm(self._lin_res(f, w("fo_w"), w("fo_b"), h, ph), w("fln_w"), w("fln_b"), d.q_eps)
         return h  # (N * nq, D)
 
     def _opt_qkv(self, l, k):
@@ -106,6 +132,10 @@ class TrainGraph:
         pe = self.W("language_model.model.decoder.embed_positions.weight")
         h = (inputs_embeds + pe[pos]).reshape(B * L, D)
         km = am.to(torch.int32)
+        tc = self.eng.config.text_config
+        po = float(getattr(tc, "dropout", 0.0))
+        if self.dropout and float(getattr(tc, "attention_dropout", 0.0)) > 0.0:
+            raise NotImplementedError("OPT attention_dropout > 0 (the released configurations use 0.0)")
         for l in range(d.t_layers):
             k = abi.opt_layer_keys(l)
             w = lambda f: self.W(k[f])
@@ -113,10 +143,10 @@ class TrainGraph:
             wqkv, bqkv = self._opt_qkv(l, k)
             qkv = ag.linear(x, wqkv, bqkv).view(B, L, 3 * D)  # one GEMM of N = 3 D instead of three of N = D (160 tiles each at L = 960)
             ctx = ag.attention_packed(qkv, H, scale, causal=True, key_mask=km).view(B * L, D)
-            h = ag.linear(ctx, w("o_w"), w("o_b"), residual=h)
+            h = self._lin_res(ctx, w("o_w"), w("o_b"), h, po)
             x = ag.layer_norm(h, w("ln2_w"), w("ln2_b"), d.t_eps)
             f = ag.linear_relu(x, w("fc1_w"), w("fc1_b"))  # frozen layer: ReLU in the GEMM epilogue, the output is the saved activation
-            h = ag.linear(f, w("fc2_w"), w("fc2_b"), residual=h)
+            h = self._lin_res(f, w("fc2_w"), w("fc2_b"), h, po)
         return ag.layer_norm(h, self.W("language_model.model.decoder.final_layer_norm.weight"),
                              self.W("language_model.model.decoder.final_layer_norm.bias"), d.t_eps).view(B, L, D)
 
@@ -164,24 +194,26 @@ class TrainGraph:
     def _t5_ff(self, h, k, tag):
         d = self.eng.t5dims
         x = ag.rms_norm(h, self.W(k["ln_ff"]), d.eps)
+        pt = float(self.eng.config.text_config.dropout_rate)
         ab = ag.linear(x, self._t5_cat(tag + ("wi",), [k["wi0_w"], k["wi1_w"]]))
-        return ag.linear(ag.gated_gelu(ab), self.W(k["wo_w"]), residual=h)
+        return self._lin_res(self._drop(ag.gated_gelu(ab), pt), self.W(k["wo_w"]), None, h, pt)  # hf :118 dropout before wo, :140 after
 
     def t5_loss(self, emb: torch.Tensor, enc_mask: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         d = self.eng.t5dims
         B, Le, D = emb.shape
         H, I = d.heads, d.heads * d.d_kv
         km = enc_mask.to(emb.device, torch.int32).contiguous()
-        h = emb.reshape(B * Le, D)
+        pt = float(self.eng.config.text_config.dropout_rate)
+        h = self._drop(emb.reshape(B * Le, D), pt)  # T5Stack :1012 dropout(inputs_embeds)
         rel = self._t5_rel("encoder", Le)
         for l in range(d.enc_layers):
             k = abi.t5_layer_keys("encoder", l)
             x = ag.rms_norm(h, self.W(k["ln_sa"]), d.eps)
             qkv = ag.linear(x, self._t5_cat(("enc", l, "qkv"), [k["q_w"], k["k_w"], k["v_w"]])).view(B, Le, 3 * I)
-            ctx = ag.attention_packed(qkv, H, 1.0, causal=False, key_mask=km, rel=rel).view(B * Le, I)
-            h = ag.linear(ctx, self.W(k["o_w"]), residual=h)
+            ctx = ag.attention_packed(qkv, H, 1.0, causal=False, key_mask=km, rel=rel, drop=self._adrop(pt)).view(B * Le, I)
+            h = self._lin_res(ctx, self.W(k["o_w"]), None, h, pt)
             h = self._t5_ff(h, k, ("enc", l))
-        enc = ag.rms_norm(h, self.W("language_model.encoder.final_layer_norm.weight"), d.eps)  # (B * Le, D)
+        enc = self._drop(ag.rms_norm(h, self.W("language_model.encoder.final_layer_norm.weight"), d.eps), pt)  # (B * Le, D)
 
         t = self.eng.config.text_config
         lab = labels.to(emb.device)
@@ -189,21 +221,21 @@ class TrainGraph:
         start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
         dec_ids = torch.cat((torch.full_like(lab[:, :1], start), lab[:, :-1]), dim=1)  # T5._shift_right
         dec_ids = dec_ids.masked_fill(dec_ids == -100, t.pad_token_id)
-        g = self.W("language_model.shared.weight")[dec_ids].reshape(B * Lt, D)  # frozen embedding rows
+        g = self._drop(self.W("language_model.shared.weight")[dec_ids].reshape(B * Lt, D), pt)  # frozen embedding rows
         rel = self._t5_rel("decoder", Lt)
         for l in range(d.dec_layers):
             k = abi.t5_layer_keys("decoder", l)
             x = ag.rms_norm(g, self.W(k["ln_sa"]), d.eps)
             qkv = ag.linear(x, self._t5_cat(("dec", l, "qkv"), [k["q_w"], k["k_w"], k["v_w"]])).view(B, Lt, 3 * I)
-            ctx = ag.attention_packed(qkv, H, 1.0, causal=True, rel=rel).view(B * Lt, I)
-            g = ag.linear(ctx, self.W(k["o_w"]), residual=g)
+            ctx = ag.attention_packed(qkv, H, 1.0, causal=True, rel=rel, drop=self._adrop(pt)).view(B * Lt, I)
+            g = self._lin_res(ctx, self.W(k["o_w"]), None, g, pt)
             x = ag.rms_norm(g, self.W(k["ln_ca"]), d.eps)
             q = ag.linear(x, self.W(k["cq_w"])).view(B, Lt, I)
             kv = ag.linear(enc, self._t5_cat(("dec", l, "ckv"), [k["ck_w"], k["cv_w"]])).view(B, Le, 2, I)
-            ctx = ag.attention(q, kv[:, :, 0], kv[:, :, 1], H, 1.0, causal=False, key_mask=km).view(B * Lt, I)
-            g = ag.linear(ctx, self.W(k["co_w"]), residual=g)
+            ctx = ag.attention(q, kv[:, :, 0], kv[:, :, 1], H, 1.0, causal=False, key_mask=km, drop=self._adrop(pt)).view(B * Lt, I)
+            g = self._lin_res(ctx, self.W(k["co_w"]), None, g, pt)
             g = self._t5_ff(g, k, ("dec", l))
-        out = ag.rms_norm(g, self.W("language_model.decoder.final_layer_norm.weight"), d.eps)
+        out = self._drop(ag.rms_norm(g, self.W("language_model.decoder.final_layer_norm.weight"), d.eps), pt)
         if d.scale_decoder_outputs:  # tied embeddings: hf :1037-1041
             out = out * (D ** -0.5)
         sel = lab.reshape(-1) >= 0
@@ -215,6 +247,7 @@ class TrainGraph:
     def loss(self, input_ids, attention_mask, pixel_values, video_input_mask, labels) -> torch.Tensor:
         """Token cross-entropy (ignore_index -100; shifted for the decoder-only LM), differentiable w.r.t. ``params``."""
         eng = self.eng
+        self._site = 0
         ag.new_step(eng.__dict__.setdefault("_train_frozen_t", {}))  # transposed frozen weights live and die with the engine
         dev = eng.device
         input_ids = input_ids.to(dev)

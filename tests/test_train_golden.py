@@ -112,6 +112,7 @@ def test_model_forward_returns_trainable_loss():
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}
     model.load_state_dict(sd, strict=False)
     model = model.cuda().train()
+    model.hip_train_dropout = False  # the goldens pin the deterministic function (reference in eval mode)
     for p in model.vision_model.parameters():
         p.requires_grad = False
     for p in model.language_model.parameters():
@@ -210,6 +211,7 @@ def test_t5_model_forward_returns_trainable_loss():
     model = VideoBlipForConditionalGeneration(cfg)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
     model = model.cuda().train()
+    model.hip_train_dropout = False  # the goldens pin the deterministic function (reference in eval mode)
     for p in model.vision_model.parameters():
         p.requires_grad = False
     for p in model.language_model.parameters():
@@ -229,3 +231,67 @@ def test_t5_model_forward_returns_trainable_loss():
         opt.step()
         opt.zero_grad()
     assert float(out.loss.detach()) < l0
+
+
+@pytest.mark.parametrize("case", ["mid_b2", "mid_t5_b2"])
+def test_dropout_in_the_training_graph(case):
+    """train() mode of the reference = dropout at the Q-Former / OPT / T5 sites.  Masks are a function of (seed, site, element):
+    same seed -> same loss and gradients, another seed -> another mask; the op-level masks and gradients are pinned in
+    tests/test_backward_ops.py."""
+    from eilev_amd.train import TrainGraph
+    from hip_utils import models
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, f"train_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, _, eng = models(meta["config"])
+    sd = synth_state_dict(cfg)
+    pixels, input_ids, attn, vmask, labels = _batch(meta)
+    if meta.get("t5"):
+        input_ids, labels = np.where(attn == 1, input_ids, 0), g["labels"]
+    t = lambda a: torch.from_numpy(a).cuda()
+
+    def step(dropout, seed):
+        params = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in sd.items() if k.startswith(TRAINABLE)}
+        loss = TrainGraph(eng, params, dropout=dropout, seed=seed).loss(t(input_ids), t(attn), t(pixels), t(vmask), t(labels))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.float() for k, p in params.items()}
+
+    l0, _ = step(False, 0)
+    l1, g1 = step(True, 1)
+    l1b, g1b = step(True, 1)
+    l2, _ = step(True, 2)
+    assert abs(l0 - float(g["loss"])) <= 2e-2 * abs(l0)
+    assert l1 != l0 and l2 != l1 and abs(l1 - l0) <= 0.3 * abs(l0) and abs(l2 - l0) <= 0.3 * abs(l0), (l0, l1, l2)
+    assert abs(l1 - l1b) <= 1e-5 * abs(l1)
+    for k in g1:
+        assert torch.allclose(g1[k], g1b[k], rtol=1e-3, atol=1e-5 * float(g1[k].abs().max()) + 1e-9), k
+        assert torch.isfinite(g1[k]).all()
+    print(f"{case}: loss without dropout {l0:.4f}, with (seed 1) {l1:.4f}, (seed 2) {l2:.4f}")
+
+
+def test_model_train_mode_applies_dropout():
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, "train_tiny_b2.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    model = VideoBlipForConditionalGeneration(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
+    model = model.cuda().train()
+    for p in list(model.vision_model.parameters()) + list(model.language_model.parameters()):
+        p.requires_grad = False
+    pixels, input_ids, attn, vmask, labels = _batch(meta)
+    t = lambda a: torch.from_numpy(a).cuda()
+    batch = dict(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels), video_input_mask=t(vmask), labels=t(labels))
+    a = float(model(**batch).loss.detach())
+    b = float(model(**batch).loss.detach())  # next call, next masks
+    model.hip_train_dropout = False
+    c = float(model(**batch).loss.detach())
+    assert a != b and a != c and abs(c - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    out = model(**batch)
+    out.loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
