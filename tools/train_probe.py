@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--config", default="opt27")
+    ap.add_argument("--dropout", action="store_true", help="apply the configuration's dropout (train() mode of the reference)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = blip2_config(args.config)
@@ -44,7 +45,6 @@ def main():
         labels = torch.randint(4, cfg.text_config.vocab_size, (args.samples, 14), device=dev, generator=g)
     else:
         labels = torch.where(vm == 0, ids, torch.full_like(ids, -100))
-    graph = TrainGraph(eng, params)
     opt = torch.optim.AdamW(list(params.values()), lr=1e-5)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for step in range(args.steps + 1):
@@ -54,7 +54,7 @@ def main():
         with torch.no_grad():
             eng.vit(px)  # timed alone; loss() below runs it again
         e[1].record()
-        loss = graph.loss(ids, am, px, vm, labels)
+        loss = TrainGraph(eng, params, dropout=args.dropout, seed=step).loss(ids, am, px, vm, labels)
         e[2].record()
         loss.backward()
         e[3].record()
