@@ -1,0 +1,82 @@
+"""-m gpu: the second named caller of the path — `transformers.Trainer` as ref:scripts/general/train_v2.py:207-217 drives it.
+
+The model class is handed to the stock HF Trainer exactly as the reference script does (freeze ViT + LM, enable_input_require_grads,
+bf16 autocast, gradient accumulation, weight decay, grad clipping); every forward / backward runs on the HIP training graph.
+Datasets / tokenizer are out of scope: samples are synthetic dicts of the collator's output format.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class _Samples(torch.utils.data.Dataset):
+    def __init__(self, meta, n):
+        from test_train_golden import _batch
+
+        pixels, input_ids, attn, vmask, labels = _batch(meta)
+        # one sample = row 0 of the golden batch (its clips come first in pixel order), repeated with different pixels
+        nclips0 = sum(meta["rows"][0][0])
+        self.items = []
+        rng = np.random.default_rng(0)
+        for i in range(n):
+            px = pixels[:nclips0] + 0.05 * rng.standard_normal(pixels[:nclips0].shape).astype(np.float32)
+            self.items.append(dict(pixel_values=torch.from_numpy(px), input_ids=torch.from_numpy(input_ids[0]),
+                                   attention_mask=torch.from_numpy(attn[0]), video_input_mask=torch.from_numpy(vmask[0]),
+                                   labels=torch.from_numpy(labels[0])))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _collate(samples):
+    """What DataCollatorForInterleavedVideoSeq2Seq yields (ref:eilev/data/utils.py:35-66): clips concatenated, id tensors stacked."""
+    out = {k: torch.stack([s[k] for s in samples]) for k in ("input_ids", "attention_mask", "video_input_mask", "labels")}
+    out["pixel_values"] = torch.cat([s["pixel_values"] for s in samples])
+    return out
+
+
+def test_hf_trainer_trains_the_qformer_on_the_hip_graph(tmp_path):
+    import transformers
+
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, "train_tiny_b2.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    model = VideoBlipForConditionalGeneration(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
+    # ref:scripts/general/train_v2.py:124-130
+    for p in model.vision_model.parameters():
+        p.requires_grad = False
+    for p in model.language_model.parameters():
+        p.requires_grad = False
+    model.enable_input_require_grads()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    args = transformers.TrainingArguments(
+        output_dir=str(tmp_path), per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=4, learning_rate=1e-3,
+        weight_decay=0.05, warmup_steps=0, bf16=True, remove_unused_columns=False, report_to=[], save_strategy="no", logging_steps=1,
+        dataloader_num_workers=0, optim="adamw_torch", seed=0)
+    trainer = transformers.Trainer(model=model, args=args, train_dataset=_Samples(meta, 8), data_collator=_collate)
+    result = trainer.train()
+    losses = [h["loss"] for h in trainer.state.log_history if "loss" in h]
+    assert result.global_step == 4 and len(losses) == 4 and all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses  # eight near-identical samples, lr 1e-3: the loss must come down
+    after = model.state_dict()
+    changed = [k for k in before if not torch.equal(before[k].to(after[k].device), after[k])]
+    assert changed and all(k.startswith(("qformer.", "query_tokens", "language_projection.")) for k in changed), changed[:5]
+    assert len(changed) >= 40  # every trainable tensor moved (47 at this configuration, a few biases may round to no change)
+    # evaluation loop of the Trainer: eval() mode -> the inference route, loss without a graph
+    metrics = trainer.evaluate(eval_dataset=_Samples(meta, 2))
+    assert np.isfinite(metrics["eval_loss"])
