@@ -80,3 +80,43 @@ def test_hf_trainer_trains_the_qformer_on_the_hip_graph(tmp_path):
     # evaluation loop of the Trainer: eval() mode -> the inference route, loss without a graph
     metrics = trainer.evaluate(eval_dataset=_Samples(meta, 2))
     assert np.isfinite(metrics["eval_loss"])
+
+
+def test_ddp_wrapper_reduces_the_hip_graph_gradients():
+    """Under torchrun the Trainer wraps the model in DistributedDataParallel (RCCL).  One-rank process group here: the reducer's hooks
+    must fire for every trainable parameter of the HIP graph (`ddp_find_unused_parameters False`, ref:README.md:155)."""
+    import socket
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, "train_tiny_b2.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    model = VideoBlipForConditionalGeneration(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
+    model = model.cuda().train()
+    model.hip_train_dropout = False
+    for p in list(model.vision_model.parameters()) + list(model.language_model.parameters()):
+        p.requires_grad = False
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=False)
+        batch = _collate([_Samples(meta, 1)[0]])
+        batch = {k: v.cuda() for k, v in batch.items()}
+        out = ddp(**batch)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+        ref = model(**batch)
+        assert abs(float(ref.loss.detach()) - float(out.loss.detach())) <= 1e-5 * abs(float(ref.loss.detach()))
+    finally:
+        dist.destroy_process_group()
