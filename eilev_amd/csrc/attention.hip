@@ -20,7 +20,7 @@ extern "C" int eilev_debug_attn_v1(int on) { g_attn_force_v1 = on & 1; g_attn_db
 
 namespace {
 
-template <int DP>
+template <int DP, bool DROP = false>  // DROP: dropout on the probabilities (training graph), compiled out of the inference kernel
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
     constexpr int KD = DP / 32;        // MFMA k-steps over the head dim
     constexpr int DT = DP / 16;        // 16-row tiles of O^T
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
                 const float p = okv[ct][r] ? exp2f(st[ct][r] - m_new) : 0.0f;
                 st[ct][r] = p;
                 rs += p;
-                if (a.drop_thr) {  // training: the row sum keeps every probability, the product with V only the kept ones (scaled)
+                if (DROP) {  // training: the row sum keeps every probability, the product with V only the kept ones (scaled)
                     const uint64_t idx = (((uint64_t)b * a.heads + h) * a.sq + qrow) * (uint64_t)a.skv + (kv0 + ct * 16 + lg * 4 + r);
                     st[ct][r] = eilev_hash32(a.drop_seed, idx) >= a.drop_thr ? p * a.drop_scale : 0.0f;
                 }
@@ -783,7 +783,11 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         return launch_attn_v2<2>(a, s);
     }
     const dim3 grid((a.sq + 63) / 64, a.heads, a.batch), block(256);
-    if (a.hd <= 64) hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, block, 0, s, a);
+    if (a.drop_thr) {
+        if (a.hd <= 64) hipLaunchKernelGGL((attn_prefill_kernel<64, true>), grid, block, 0, s, a);
+        else if (a.hd <= 96) hipLaunchKernelGGL((attn_prefill_kernel<96, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, s, a);
+    } else if (a.hd <= 64) hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, block, 0, s, a);
     else if (a.hd <= 96) hipLaunchKernelGGL(attn_prefill_kernel<96>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, block, 0, s, a);
     EILEV_LAUNCH_CHECK();
