@@ -143,18 +143,18 @@ class _LinearReLU(torch.autograd.Function):
         M = x2.shape[0]
         y = torch.empty((M, N), dtype=_BF, device=x2.device)
         abi.check(_lib().eilev_linear(_p(x2), _p(w16), _p(None if bias is None else _bf(bias)), None, _p(y), M, N, K, 2, 0, _s()), "eilev_linear")
-        ctx.save_for_backward(y)
-        ctx.inner = (x2, weight, w16 if weight.requires_grad else None, bias, x.shape, _cur["frozen"])
+        ctx.save_for_backward(y, weight)
+        ctx.xshape = x.shape
+        ctx.frozen = _cur["frozen"]
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        x2, weight, w16, bias, xshape, frozen = ctx.inner
+        y, weight = ctx.saved_tensors
+        xshape, frozen = ctx.xshape, ctx.frozen
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise NotImplementedError("linear_relu is used for frozen layers (the OPT feed-forward); trainable layers use linear + relu")
-        if w16 is None:
-            w16 = _bf(weight)
+        w16 = _bf(weight)
         N, K = w16.shape
         dy2 = _need(dy, "linear_relu grad").reshape(-1, N)
         dpre = torch.empty_like(dy2)
