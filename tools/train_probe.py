@@ -64,9 +64,16 @@ def main():
         torch.cuda.synchronize()
         vit, fwd, bwd, ost = (e[i].elapsed_time(e[i + 1]) for i in range(4))
         tag = "warm-up" if step == 0 else f"step {step}"
+        last = dict(step_ms=round(fwd + bwd + ost, 2), vit_ms=round(vit, 2), graph_forward_ms=round(fwd - vit, 2), backward_ms=round(bwd, 2),
+                    optimizer_ms=round(ost, 2), peak_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2))
         print(f"{tag}: loss {float(loss.detach()):.4f}  vit {vit:.1f} ms  forward(vit+graph) {fwd:.1f} ms  backward {bwd:.1f} ms  adamw {ost:.1f} ms  "
               f"step {fwd + bwd + ost:.1f} ms  peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB  ({n_par / 1e6:.1f} M trainable, "
               f"{args.samples * 17} clips, {ids.shape[1]} tokens/sample)", flush=True)
+    import json
+
+    print(json.dumps({"metric": "train_v2 step (ViT + LM frozen, Q-Former trained), one MI355X", "config": args.config, "samples_per_step": args.samples,
+                      "clips_per_step": args.samples * 17, "dropout": bool(args.dropout), "trainable_params": n_par,
+                      "clips_per_s": round(args.samples * 17 / (last["step_ms"] / 1e3), 1), **last}))
 
 
 if __name__ == "__main__":
