@@ -107,7 +107,10 @@ def test_ddp_wrapper_reduces_the_hip_graph_gradients():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    except Exception as e:  # environment without a usable RCCL transport: nothing to say about the graph
+        pytest.skip(f"RCCL process group unavailable here: {e}")
     try:
         ddp = DDP(model, device_ids=[0], find_unused_parameters=False)
         batch = _collate([_Samples(meta, 1)[0]])
