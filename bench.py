@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 from eilev_amd import abi  # noqa: E402
 from eilev_amd.configs import CONFIGS, blip2_config  # noqa: E402
-from eilev_amd.sharding import deal_clips, gather_clip_tokens  # noqa: E402
+from eilev_amd.sharding import ExchangePlan  # noqa: E402
 from eilev_amd.synth import synth_interleaved_ids  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -126,6 +126,40 @@ def cpu_baseline(cfg, seconds_budget=30.0):
                        f"({t_dec1:.3f}s); scaled to 17 clips x (39 ViT + 12 Q-Former blocks) + 32 blocks prefill + 31 x 32 decode")}
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` copies of this script, one per GPU of this node, wired for torch.distributed (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT): what `python -m torch.distributed.run --nproc-per-node n` does, without needing
+    the launcher on the command line.  Rank 0 inherits stdout (it prints the JSON line); returns the worst exit code."""
+    import socket
+    import subprocess
+
+    if torch.cuda.is_available() and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPUs are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [None] * n
+    while any(c is None for c in codes):  # a rank that dies would leave the others in a barrier forever: stop them
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.2)
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1 transport of the clip tokens: rccl = eilev_exchange_clip_tokens (direct RCCL send/recv on a side "
+                         "stream), torch = torch.distributed.all_to_all_single (also RCCL, through the process group)")
     ap.add_argument("--lm", choices=["opt27", "t5xl", "opt67"], default="opt27",
                     help="opt27 = the headline configs[1]/[2]; informational: t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), "
                          "opt67 = the OPT-6.7B backbone of configs[4] in bf16 (use --shots 32 for its 32-shot sequence)")
@@ -141,11 +178,18 @@ def main():
                     help="fp8: e4m3 weights for the OPT linears (informational line for configs[4]; the headline metric is bf16)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL)
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -163,11 +207,26 @@ def main():
     S = args.samples
     nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
     total_clips = world * S * (N_CTX + 1)
-    # every rank materialises only ITS clips of the global deal (synthetic, so just generate that many)
-    mine = deal_clips(total_clips, world, rank)
+    # clips of the global step are dealt round-robin (clip c -> rank c % world); every rank materialises only ITS clips
+    # (synthetic, so it just generates that many) and receives the projected tokens of the clips of ITS samples
+    from eilev_amd.comm import ClipExchange
+
+    plan = ExchangePlan(world * S, N_CTX + 1, world, rank, chunk_clips=max(1, 1088 // FRAMES))
     px, ids, vm, am = build_inputs(cfg, S, dev, seed=1234 + rank)
-    assert px.shape[0] == len(mine)
-    my_first_clip = rank * S * (N_CTX + 1)
+    assert px.shape[0] == plan.n_local and plan.n_consumed == S * (N_CTX + 1)
+    transport = args.exchange
+    if world > 1 and transport == "rccl":
+        try:
+            exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport="rccl")
+        except (RuntimeError, OSError) as e:  # no direct communicator: say so in the result and use torch.distributed's RCCL
+            print(f"[rank {rank}] direct RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            transport = "torch"
+        ok = torch.tensor([1 if transport == "rccl" else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks must agree on the transport
+        if int(ok.item()) == 0:
+            transport = "torch"
+    if world == 1 or transport != "rccl":
+        exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport=transport)
 
     def stamp(name):
         if eng.timing is not None:
@@ -177,9 +236,7 @@ def main():
 
     def step():
         stamp("step_begin")
-        feats = eng.encode_clips(px)                                         # (n_local*32, Dt) for my dealt clips
-        allf = gather_clip_tokens(feats, total_clips, nq)                    # RCCL all-gather (identity at N=1)
-        mine_f = allf[my_first_clip * nq:(my_first_clip + S * (N_CTX + 1)) * nq]  # clips of MY samples, global order
+        mine_f = eng.encode_and_exchange(px, exch)  # chunks of 136 clips; each chunk's RCCL exchange runs under the next ViT
         emb = eng.embed_scatter(ids, vm, mine_f)
         stamp("encode_done")
         if is_t5:  # encoder-decoder LM: encoder + cross K/V take the place of the prefill
@@ -255,7 +312,7 @@ def main():
                                    (f"{'configs[1]: eilev-blip2-opt-2.7b' if args.lm == 'opt27' else ('configs[4] backbone blip2-opt-6.7b in bf16' if args.lm_weights == 'bf16' else 'configs[4] blip2-opt-6.7b, fp8 OPT weights')} (random-init), "
                                     f"{S} samples/GPU/step x {N_CTX + 1} clips x 8 frames "
                                     f"224x224, L={seq_len} prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
-                                    f"{'RCCL all-gather' if world > 1 else 'no collective at N=1'}"),
+                                    f"{('RCCL all-to-all of the clip tokens (' + exch.transport + ')') if world > 1 else 'no collective at N=1'}"),
                        "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": seq_len, "new_tokens": NEW_TOKENS},
             "whole_path_tflops": (round((74.75 if is_t5 else TFLOP_PER_SAMPLE) * world * S * args.steps / dt, 1)
                                   if N_CTX == 16 and args.lm != "opt67" else None),

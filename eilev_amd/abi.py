@@ -248,7 +248,8 @@ EXPORTS = [
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
     "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
-    "eilev_attention_dropout_bwd",
+    "eilev_attention_dropout_bwd", "eilev_comm_bind", "eilev_comm_unique_id", "eilev_comm_init", "eilev_comm_destroy",
+    "eilev_gather_clip_tokens", "eilev_exchange_clip_tokens",
 ]
 
 
@@ -355,6 +356,18 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_t5_decode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_t5_decode_step.restype = i32
     lib.eilev_t5_decode_step.argtypes = [TP, C.POINTER(T5Weights), vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.eilev_comm_bind.restype = i32
+    lib.eilev_comm_bind.argtypes = [C.c_char_p]
+    lib.eilev_comm_unique_id.restype = i32
+    lib.eilev_comm_unique_id.argtypes = [vp]
+    lib.eilev_comm_init.restype = i32
+    lib.eilev_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp]
+    lib.eilev_comm_destroy.restype = i32
+    lib.eilev_comm_destroy.argtypes = [vp]
+    lib.eilev_gather_clip_tokens.restype = i32
+    lib.eilev_gather_clip_tokens.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp]
+    lib.eilev_exchange_clip_tokens.restype = i32
+    lib.eilev_exchange_clip_tokens.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]
     lib.eilev_prof_enable.restype = i32
     lib.eilev_prof_enable.argtypes = [i32]
     lib.eilev_prof_collect.restype = i32
@@ -364,7 +377,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 5:
+    if lib.eilev_abi_version() != 6:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 
@@ -389,4 +402,5 @@ def load_hip() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         names = {-1: "EILEV_E_BADARG", -2: "EILEV_E_UNSUPPORTED", -3: "EILEV_E_WORKSPACE"}
-        raise RuntimeError(f"{what} failed: {names.get(rc, f'hipError {rc}')}")
+        what_rc = names.get(rc, f"ncclResult {rc - 10000}" if rc >= 10000 else f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {what_rc}")

@@ -7,7 +7,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "eilev.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
@@ -53,7 +53,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                 print(warn, file=sys.stderr)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

@@ -180,17 +180,36 @@ class HipEngine:
                                                  ws.numel(), self._stream()), "eilev_qformer_forward")
         return out
 
-    def project(self, query_out: torch.Tensor):
+    def project(self, query_out: torch.Tensor, out: torch.Tensor = None):
         d = self.dims
         q = query_out.reshape(-1, d.q_hidden).contiguous()
-        out = torch.empty((q.shape[0], d.t_hidden), dtype=torch.bfloat16, device=self.device)
+        if out is None:
+            out = torch.empty((q.shape[0], d.t_hidden), dtype=torch.bfloat16, device=self.device)
+        elif out.shape != (q.shape[0], d.t_hidden) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+            raise ValueError("project(out=...): need a contiguous bf16 (rows, t_hidden) buffer")
         abi.check(self.lib.eilev_project_rows(C.byref(d), self.pack.proj_w, self.pack.proj_b, _ptr(q), q.shape[0], _ptr(out),
                                               self._stream()), "eilev_project_rows")
         return out
 
-    def encode_clips(self, pixel_values):
+    def encode_clips(self, pixel_values, out: torch.Tensor = None):
         """pixels -> projected query tokens (N*num_query, Dt): ViT + Q-Former + language_projection."""
-        return self.project(self.qformer(self.vit(pixel_values)))
+        return self.project(self.qformer(self.vit(pixel_values)), out=out)
+
+    def encode_and_exchange(self, pixel_values, exchange):
+        """Sharded encode: this rank's dealt clips go through ViT + Q-Former + projection in chunks of the exchange plan; every
+        chunk is handed to `exchange` (eilev_amd.comm.ClipExchange) as soon as it is projected, so its transfer (RCCL on a side
+        stream) runs under the next chunk's ViT.  Returns the projected rows of the clips whose samples THIS rank's language
+        model runs, in global clip order.  At world == 1 the chunks are written straight into the result (no copy)."""
+        plan = exchange.plan
+        if pixel_values.shape[0] != plan.n_local:
+            raise ValueError(f"rank {plan.rank} was dealt {plan.n_local} clips, got {pixel_values.shape[0]}")
+        for j in range(plan.rounds):
+            a, b = plan.chunk_range(j)
+            buf = exchange.chunk_buffer(j)
+            if b > a:
+                self.encode_clips(pixel_values[a:b], out=buf)
+            exchange.send_round(j, buf)
+        return exchange.finish()
 
     def embed_scatter(self, input_ids, video_mask, video_feats):
         d = self.dims

@@ -32,12 +32,14 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 5
+#define EILEV_ABI_VERSION 6
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
 #define EILEV_E_UNSUPPORTED (-2)
 #define EILEV_E_WORKSPACE (-3)
+/* RCCL failures of the exchange entries: EILEV_E_RCCL_BASE + ncclResult_t (hipError_t passthrough stays below 1000) */
+#define EILEV_E_RCCL_BASE 10000
 
 /* element types of `pixels` */
 #define EILEV_F32 0
@@ -161,6 +163,33 @@ int eilev_project_rows(const EilevDims *d, const void *proj_w, const void *proj_
 int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens, const int64_t *input_ids,
                         const uint8_t *video_mask, const void *video_feats, int64_t n_rows,
                         int64_t batch, int64_t seq_len, void *inputs_embeds, void *stream);
+
+/* ---- stage 3b: clip-token exchange between the ranks of a node (RCCL over xGMI; HIP library) -----------------------
+ * New capability named by BASELINE.json north_star ("RCCL gather over xGMI of the per-clip query tokens before the LM");
+ * closest reference ancestor: accelerate's pad + all-gather, ref:scripts/general/generate_narration_texts.py:124-127.
+ * One process per GPU; clips are dealt to ranks (eilev_amd/sharding.py), each rank runs stages 1-3 on its clips, then the
+ * projected rows (num_query x Dt bf16 per clip = 164 KB at OPT-2.7B) travel to the rank whose language-model pass needs them.
+ *   `comm` is an ncclComm_t (opaque pointer; the header does not need rccl.h).  RCCL is resolved at run time from the copy
+ *   already mapped into the process: eilev_comm_bind(path) (NULL = "librccl.so.1"); eilev_comm_unique_id fills
+ *   EILEV_COMM_ID_BYTES bytes on one rank, the caller ships them to the others (any channel), every rank calls
+ *   eilev_comm_init on ITS device.  Rows are opaque byte rows of `row_bytes`.  All calls are asynchronous launches on `stream`
+ *   (a side stream: the exchange of one encode chunk overlaps the ViT of the next) and need no comm when world == 1.
+ * eilev_gather_clip_tokens: every rank receives every rank's rows, rank-major in `all` (rows[r] rows from rank r;
+ *   ncclAllGather when the counts are equal, grouped send/recv otherwise).
+ * eilev_exchange_clip_tokens: all-to-all-v — send_rows[r] rows from row send_off[r] of `send` go to rank r; recv_rows[q] rows
+ *   from rank q land at row recv_off[q] of `recv` (each rank receives only the clips of its own samples).
+ * Errors: EILEV_E_RCCL_BASE + ncclResult_t.  The oracle library implements world == 1 (a copy) and returns
+ * EILEV_E_UNSUPPORTED otherwise. */
+#define EILEV_COMM_ID_BYTES 128
+int eilev_comm_bind(const char *librccl_path);
+int eilev_comm_unique_id(void *id);
+int eilev_comm_init(void **comm, int world, int rank, const void *id);
+int eilev_comm_destroy(void *comm);
+int eilev_gather_clip_tokens(void *comm, const void *local, void *all, const int64_t *rows, int world, int rank,
+                             int64_t row_bytes, void *stream);
+int eilev_exchange_clip_tokens(void *comm, const void *send, const int64_t *send_rows, const int64_t *send_off, void *recv,
+                               const int64_t *recv_rows, const int64_t *recv_off, int world, int rank, int64_t row_bytes,
+                               void *stream);
 
 /* ---- fp8-weight linear (BASELINE configs[4]: "fp8 MFMA weights") ------------------------------------
  * nn.Linear with the weight matrix stored as OCP e4m3 bytes (torch.float8_e4m3fn) and one fp32 scale per output channel:

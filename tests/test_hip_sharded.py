@@ -1,0 +1,124 @@
+"""-m gpu: the N > 1 path on ONE GPU.
+
+(1) A simulated 2-way (and 3-way) deal: the clips of a global step are dealt to "ranks" exactly as eilev_amd/sharding.py deals
+    them, every "rank" runs its encode passes on the same GPU, the blocks of its ExchangePlan are moved by hand, and each
+    rank's language-model pass must produce the SAME token ids as the plain single-process path.
+(2) The direct-RCCL entries of the C ABI on a real device with a one-rank communicator: bind, unique id, comm init,
+    ncclAllGather through `eilev_gather_clip_tokens`, the self block of `eilev_exchange_clip_tokens`.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from hip_utils import models
+from eilev_amd import abi
+from eilev_amd.comm import ClipExchange
+from eilev_amd.sharding import ExchangePlan, deal_clips, my_samples
+from eilev_amd.synth import synth_interleaved_ids, synth_pixels
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(cfg, num_samples, cps, frames):
+    nq, vocab = cfg.num_query_tokens, cfg.text_config.vocab_size
+    px = torch.from_numpy(synth_pixels(num_samples * cps, frames, cfg.vision_config.image_size)).cuda()
+    ids, vm = zip(*[synth_interleaved_ids([1] * cps, [5] * (cps - 1) + [4], nq, vocab, seed=3 + s) for s in range(num_samples)])
+    ids, vm = torch.from_numpy(np.stack(ids)).cuda(), torch.from_numpy(np.stack(vm)).cuda()
+    return px, ids, vm, torch.ones_like(ids, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("world,num_samples,cps,chunk", [(2, 4, 3, 2), (3, 5, 2, 100), (2, 3, 5, 1)])
+def test_simulated_deal_equals_plain_path(world, num_samples, cps, chunk):
+    cfg, _, eng = models("mid")
+    nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
+    px, ids, vm, am = _inputs(cfg, num_samples, cps, frames=2)
+    # plain path: one process encodes everything and runs the LM on all samples
+    plain_feats = eng.encode_clips(px)
+    plain_ids = eng.greedy_decode(eng.embed_scatter(ids, vm, plain_feats), am, 6, eos_id=-1, use_graph=False)
+
+    plans = [ExchangePlan(num_samples, cps, world, r, chunk) for r in range(world)]
+    staging = [torch.empty((p.n_consumed * nq, Dt), dtype=torch.bfloat16, device="cuda") for p in plans]
+    for q, p in enumerate(plans):  # "rank" q: its dealt clips, chunk by chunk
+        mine = deal_clips(num_samples * cps, world, q)
+        local_px = px[torch.tensor(mine, device="cuda")] if mine else px[:0]
+        for j in range(p.rounds):
+            a, b = p.chunk_range(j)
+            if b == a:
+                continue
+            rows = eng.encode_clips(local_px[a:b])
+            for r in range(world):  # what eilev_exchange_clip_tokens moves: block (q -> r) of round j
+                n, o = p.send_rows[j][r] * nq, p.send_off[j][r] * nq
+                assert plans[r].recv_rows[j][q] * nq == n
+                d = plans[r].recv_off[j][q] * nq
+                staging[r][d:d + n] = rows[o:o + n]
+    got = torch.empty_like(plain_ids)
+    for r, p in enumerate(plans):
+        sm = my_samples(num_samples, world, r)
+        if not sm:
+            continue
+        feats = staging[r].view(p.n_consumed, nq, Dt)[torch.tensor(p.order, device="cuda")].reshape(-1, Dt)
+        sel = torch.tensor(sm, device="cuda")
+        first = sm[0] * cps * nq
+        assert torch.equal(feats, plain_feats[first:first + feats.shape[0]])  # clip-batch invariance: bit-identical rows
+        emb = eng.embed_scatter(ids[sel], vm[sel], feats)
+        got[sel] = eng.greedy_decode(emb, am[sel], 6, eos_id=-1, use_graph=False)
+    assert torch.equal(got, plain_ids)
+
+
+def test_single_rank_exchange_object_is_copy_free_and_exact():
+    cfg, _, eng = models("mid")
+    nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
+    px, ids, vm, am = _inputs(cfg, 3, 3, frames=2)
+    ex = ClipExchange(ExchangePlan(3, 3, 1, 0, chunk_clips=4), nq, Dt, torch.bfloat16, "cuda")
+    assert ex.transport == "local"
+    a = eng.encode_and_exchange(px, ex)
+    b = eng.encode_and_exchange(px, ex)  # a second step must not overwrite the rows of the first
+    plain = eng.encode_clips(px)
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a, b)
+    # chunking the encode changes the GEMM row counts, not the per-row arithmetic
+    assert torch.equal(a, plain)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_entries_on_a_one_rank_communicator():
+    import torch.distributed as dist
+
+    from eilev_amd.comm import RcclComm
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    except Exception as e:  # no RCCL process group on this box
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        comm = RcclComm(torch.device("cuda", 0))
+        lib = abi.load_hip()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        i64 = lambda *v: (C.c_int64 * len(v))(*v)
+        src = torch.randn(96, 2560, device="cuda").to(torch.bfloat16)
+        dst = torch.zeros_like(src)
+        abi.check(lib.eilev_gather_clip_tokens(comm.handle, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), i64(96), 1, 0,
+                                               2560 * 2, st), "eilev_gather_clip_tokens")  # ncclAllGather on one rank
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst)
+        dst.zero_()
+        abi.check(lib.eilev_exchange_clip_tokens(comm.handle, C.c_void_p(src.data_ptr()), i64(64), i64(32), C.c_void_p(dst.data_ptr()),
+                                                 i64(64), i64(0), 1, 0, 2560 * 2, st), "eilev_exchange_clip_tokens")
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:64], src[32:]) and not bool(dst[64:].any())
+        # bad arguments are refused, not launched
+        assert lib.eilev_exchange_clip_tokens(comm.handle, None, i64(1), i64(0), None, i64(2), i64(0), 1, 0, 4, st) == -1
+        comm.close()
+    finally:
+        dist.destroy_process_group()
