@@ -239,7 +239,7 @@ class WeightPack:
 
 
 EXPORTS = [
-    "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward",
+    "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward", "eilev_vit_forward_debug",
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
@@ -275,6 +275,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_vit_workspace_bytes.argtypes = [DP, i64, i64]
     lib.eilev_vit_forward.restype = i32
     lib.eilev_vit_forward.argtypes = [DP, C.POINTER(VitWeights), vp, i32, i64, i64, vp, vp, vp, sz, vp]
+    lib.eilev_vit_forward_debug.restype = i32
+    lib.eilev_vit_forward_debug.argtypes = [DP, C.POINTER(VitWeights), vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.eilev_qformer_workspace_bytes.restype = sz
     lib.eilev_qformer_workspace_bytes.argtypes = [DP, i64, i64]
     lib.eilev_qformer_forward.restype = i32
@@ -377,7 +379,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 6:
+    if lib.eilev_abi_version() != 7:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

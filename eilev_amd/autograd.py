@@ -431,7 +431,12 @@ class _LMHeadCE(torch.autograd.Function):
         tg = targets.to(rows.device, torch.int64).contiguous()
         n_valid = int((tg >= 0).sum().item())
         if n_valid == 0:
-            raise ValueError("labels contain no supervised position")
+            # no supervised position in the batch: F.cross_entropy's mean over zero rows is NaN (what the reference's loss is);
+            # the gradient is defined as zero here so that one empty batch does not poison the parameters
+            ctx.empty = True
+            ctx.shape = (R, D)
+            return torch.full((), float("nan"), dtype=torch.float32, device=rows.device)
+        ctx.empty = False
         logits = _gemm(rows, e16, None, None, R, V, D, out_f32=True)
         row_loss = torch.empty(R, dtype=torch.float32, device=rows.device)
         # dlogits is the A operand of dRows = dlogits . E: its row length is padded to a multiple of 256 (zero columns, matched by
@@ -450,6 +455,8 @@ class _LMHeadCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.empty:
+            return torch.zeros(ctx.shape, dtype=_BF, device=g.device), None, None
         dlogits, embed, e16 = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("the token embedding / lm_head is frozen on the train_v2 path")

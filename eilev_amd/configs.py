@@ -40,6 +40,21 @@ CONFIGS = {
                          word_embed_proj_dim=2560),
         num_query_tokens=32,
     ),
+    # the REAL widths of eilev-blip2-opt-2.7b (ViT-g/14 at 224x224, Q-Former, OPT-2.7B incl. the 50272-token vocabulary) with
+    # one ViT block, one Q-Former block pair (cross-attention on block 0) and one OPT block: the configuration of the
+    # real-shape golden fixtures (SURVEY 8c golden plan (2)) — every kernel variant that depends on a WIDTH or a head size
+    # (strip im2col at 224/14, frame attention 257 x 88, cross-attention over 2056 keys, hd 80 causal attention, K = 1408 /
+    # 6144 / 2560 / 10240 GEMMs, the 50272-wide lm_head + argmax) is exercised against the reference at its true size
+    "real_1l": dict(
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=1,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+                            intermediate_size=3072, encoder_hidden_size=1408),
+        text_config=dict(model_type="opt", hidden_size=2560, num_hidden_layers=1, ffn_dim=10240,
+                         num_attention_heads=32, vocab_size=50272, max_position_embeddings=2048,
+                         word_embed_proj_dim=2560),
+        num_query_tokens=32,
+    ),
     "opt67": dict(  # blip2-opt-6.7b backbone (BASELINE configs[4]): hidden 4096, 32 heads x 128, ffn 16384
         vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
                            num_attention_heads=16, patch_size=14, image_size=224),

@@ -681,11 +681,11 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
     const float *lr = logits + row * vocab;
-    bf16 *dr = dlogits + row * vocab;
+    bf16 *dr = dlogits ? dlogits + row * vocab : nullptr;  // null: loss only (eval / classify)
     const int64_t t = targets[row];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (t < 0 || t >= vocab) {
-        for (int c = tid; c < vocab; c += 256) dr[c] = (bf16)0.0f;
+        for (int c = tid; dr && c < vocab; c += 256) dr[c] = (bf16)0.0f;
         if (tid == 0) row_loss[row] = 0.0f;
         return;
     }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
     __syncthreads();
     sum = red[0] + red[1] + red[2] + red[3];
     const float lse = mx + __logf(sum), inv = grad_scale / sum;
-    for (int c = tid; c < vocab; c += 256) {
+    for (int c = tid; dr && c < vocab; c += 256) {
         const float p = __expf(lr[c] - mx) * inv;
         dr[c] = (bf16)(c == t ? p - grad_scale : p);
     }
@@ -811,7 +811,7 @@ extern "C" int eilev_act_bwd(const void *pre, const void *dy, void *dx, int64_t 
 
 extern "C" int eilev_ce_loss(const float *logits, const int64_t *targets, float grad_scale, float *row_loss, void *dlogits, int64_t rows,
                              int64_t vocab, void *stream) {
-    if (!logits || !targets || !row_loss || !dlogits || rows <= 0 || vocab <= 0) return EILEV_E_BADARG;
+    if (!logits || !targets || !row_loss || rows <= 0 || vocab <= 0) return EILEV_E_BADARG;
     hipLaunchKernelGGL(ce_loss_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, targets, grad_scale, row_loss, (bf16 *)dlogits,
                        (int)vocab);
     EILEV_LAUNCH_CHECK();

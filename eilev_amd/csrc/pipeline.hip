@@ -153,10 +153,77 @@ extern "C" size_t eilev_vit_workspace_bytes(const EilevDims *d, int64_t n_clips,
     return b + 256;
 }
 
+namespace {
+// Debug output of the slow path: softmax(scale * q k^T) of one (frame, head) as a (tok, tok) bf16 matrix.  One wave per query
+// row, a lane owns keys lane, lane + 64, ...; fp32 scores, max, sum — no tiling, no LDS: this is off the throughput path.
+__global__ void __launch_bounds__(256) attn_probs_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ probs, int tok, int heads,
+                                                         int hd, int D, float scale) {
+    const int fh = blockIdx.x, f = fh / heads, h = fh % heads;
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= tok) return;
+    const bf16 *base = qkv + (int64_t)f * tok * 3 * D;
+    const bf16 *q = base + (int64_t)i * 3 * D + h * hd;
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int j = lane + 64 * t;
+        float acc = -INFINITY;
+        if (j < tok) {
+            const bf16 *k = base + (int64_t)j * 3 * D + D + h * hd;
+            acc = 0.0f;
+            for (int e = 0; e < hd; e += 8) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(q + e), ka = *reinterpret_cast<const bf16x8 *>(k + e);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf((float)qa[u], (float)ka[u], acc);
+            }
+            acc *= scale;
+        }
+        sc[t] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        sc[t] = (lane + 64 * t < tok) ? __expf(sc[t] - mx) : 0.0f;
+        sum += sc[t];
+    }
+    sum = wave_sum(sum);
+    bf16 *out = probs + ((int64_t)fh * tok + i) * tok;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (lane + 64 * t < tok) out[lane + 64 * t] = (bf16)(sc[t] / sum);
+}
+
+int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype, int64_t n_clips, int64_t frames,
+                     void *image_embeds, void *pooler, void *hidden_states, void *attentions, void *workspace, size_t workspace_bytes,
+                     void *stream);
+}  // namespace
+
 extern "C" int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
                                  int64_t n_clips, int64_t frames, void *image_embeds, void *pooler, void *workspace,
                                  size_t workspace_bytes, void *stream) {
+    return vit_forward_impl(d, w, pixels, pixels_dtype, n_clips, frames, image_embeds, pooler, nullptr, nullptr, workspace,
+                            workspace_bytes, stream);
+}
+
+// The reference's debug outputs (ref:eilev/model/v2.py:76-103, asserted by ref:tests/model/test_model_v2.py:57-83): the residual
+// stream after the embeddings and after every block, and every block's attention probabilities.  Same kernels as
+// eilev_vit_forward plus copies / the unfused probability kernel: a slow path, off the benchmark.
+extern "C" int eilev_vit_forward_debug(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
+                                       int64_t n_clips, int64_t frames, void *image_embeds, void *pooler, void *hidden_states,
+                                       void *attentions, void *workspace, size_t workspace_bytes, void *stream) {
+    return vit_forward_impl(d, w, pixels, pixels_dtype, n_clips, frames, image_embeds, pooler, hidden_states, attentions, workspace,
+                            workspace_bytes, stream);
+}
+
+namespace {
+int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype, int64_t n_clips, int64_t frames,
+                     void *image_embeds, void *pooler, void *hidden_states, void *attentions, void *workspace, size_t workspace_bytes,
+                     void *stream) {
     if (!d || !w || !pixels || !image_embeds || !workspace || n_clips <= 0 || frames <= 0) return EILEV_E_BADARG;
+    if (attentions && vit_tok(d) > 1024) return EILEV_E_UNSUPPORTED;
     if (!dims_ok_vit(d)) return EILEV_E_UNSUPPORTED;
     if (workspace_bytes < eilev_vit_workspace_bytes(d, n_clips, frames)) return EILEV_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -180,12 +247,19 @@ extern "C" int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, c
         RC(launch_gemm(g, 5, s));
     }
     RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
+    const size_t hs_bytes = (size_t)M * D * sizeof(bf16);
+    if (hidden_states) RC((int)hipMemcpyAsync(hidden_states, x, hs_bytes, hipMemcpyDeviceToDevice, s));
 
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < d->v_layers; ++l) {
         const EilevVitLayer *L = &w->layers[l];
         RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
         RC(launch_gemm(mk_gemm(ln, D, L->qkv_w, D, L->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0), 3, s));
+        if (attentions) {
+            bf16 *pr = (bf16 *)attentions + (size_t)l * F * H * tok * tok;
+            attn_probs_kernel<<<dim3((unsigned)(F * H), (unsigned)((tok + 3) / 4)), 256, 0, s>>>(qkv, pr, (int)tok, H, hd, D, scale);
+            EILEV_LAUNCH_CHECK();
+        }
         AttnArgs a;
         a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.o = att;
         a.q_bs = a.k_bs = a.v_bs = tok * 3 * (int64_t)D; a.o_bs = tok * (int64_t)D;
@@ -198,6 +272,8 @@ extern "C" int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, c
         RC(launch_layernorm(x, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, ln, D, M, D, d->v_eps, s));
         RC(launch_gemm(mk_gemm(ln, D, L->fc1_w, D, L->fc1_b, nullptr, 0, mlp, Fi, M, Fi, D, 1), 1, s));
         RC(launch_gemm(mk_gemm(mlp, Fi, L->fc2_w, Fi, L->fc2_b, x, D, x, D, M, D, Fi, 0), 2, s));
+        if (hidden_states)
+            RC((int)hipMemcpyAsync((char *)hidden_states + (size_t)(l + 1) * hs_bytes, x, hs_bytes, hipMemcpyDeviceToDevice, s));
     }
     RC(launch_layernorm(x, D, (const bf16 *)w->post_ln_w, (const bf16 *)w->post_ln_b, (bf16 *)image_embeds, D, M, D, d->v_eps, s));
     if (pooler)
@@ -205,6 +281,7 @@ extern "C" int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, c
                             (bf16 *)pooler, D, F, D, d->v_eps, s));
     return EILEV_OK;
 }
+}  // namespace
 
 // =====================================================================================================
 // Stage 2: Q-Former

@@ -30,6 +30,18 @@ def clean_narration_text(narration_text: str) -> str:
     return out
 
 
+def generate_chunks(list_to_chunk, chunk_size: int):
+    """Consecutive slices of at most ``chunk_size`` items (ref:eilev/data/utils.py:229-231; used by icl_eval's class batching)."""
+    for start in range(0, len(list_to_chunk), chunk_size):
+        yield list_to_chunk[start:start + chunk_size]
+
+
+def parse_timestamp(timestamp: str) -> float:
+    """``hh:mm:ss.cc`` -> seconds (ref:eilev/data/utils.py:234-241; vectors ref:tests/data/test_utils.py:865-874)."""
+    hours, minutes, seconds = timestamp.split(":")
+    return float(hours) * 60 * 60 + float(minutes) * 60 + float(seconds)
+
+
 def _ids(tokenizer, text, **kw):
     return list(tokenizer(text, **kw).input_ids)
 

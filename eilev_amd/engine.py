@@ -168,6 +168,29 @@ class HipEngine:
                                                  _ptr(ws), ws.numel(), self._stream()), "eilev_vit_forward")
         return (out, pool) if want_pooler else out
 
+    def vit_debug(self, pixel_values: torch.Tensor, want_hidden: bool = True, want_attn: bool = True):
+        """Slow path of the vision wrapper's debug outputs [ref:eilev/model/v2.py:76-103]: returns (last_hidden_state (N, T*tok, Dv),
+        pooler (N, T, Dv), hidden_states (layers + 1, N, T*tok, Dv) or None, attentions (layers, N, T, heads, tok, tok) or None)."""
+        d = self.dims
+        px = pixel_values.to(self.device)
+        if px.dtype not in (torch.float32, torch.bfloat16):
+            px = px.float()
+        px = px.contiguous()
+        N, ch, T, Hh, Ww = px.shape
+        if ch != 3 or Hh != d.image_size or Ww != d.image_size:
+            raise ValueError(f"pixel_values must be (N, 3, T, {d.image_size}, {d.image_size}), got {tuple(px.shape)}")
+        tok = self.tokens_per_frame
+        bf = dict(dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((N, T * tok, d.v_hidden), **bf)
+        pool = torch.empty((N, T, d.v_hidden), **bf)
+        hid = torch.empty((d.v_layers + 1, N, T * tok, d.v_hidden), **bf) if want_hidden else None
+        att = torch.empty((d.v_layers, N, T, d.v_heads, tok, tok), **bf) if want_attn else None
+        nb = self.lib.eilev_vit_workspace_bytes(C.byref(d), N, T)
+        ws = self._workspace("vit", nb)
+        abi.check(self.lib.eilev_vit_forward_debug(C.byref(d), C.byref(self.pack.vit), _ptr(px), abi_dtype(px), N, T, _ptr(out), _ptr(pool),
+                                                   _ptr(hid), _ptr(att), _ptr(ws), ws.numel(), self._stream()), "eilev_vit_forward_debug")
+        return out, pool, hid, att
+
     def qformer(self, image_embeds: torch.Tensor):
         d = self.dims
         img = image_embeds.contiguous()
@@ -232,6 +255,25 @@ class HipEngine:
                                                self._stream()), "eilev_embed_scatter")
         return out
 
+    def ce_rows(self, logits32: torch.Tensor, targets: torch.Tensor):
+        """Per-row cross entropy of fp32 logits (rows, vocab) against int64 targets; rows with target < 0 (ignore_index -100) give 0
+        [hf loss_utils.ForCausalLMLoss / F.cross_entropy(reduction='none')] — `eilev_ce_loss` without the gradient output."""
+        lg = logits32.contiguous()
+        if lg.dtype != torch.float32:
+            raise ValueError("ce_rows needs fp32 logits")
+        tg = targets.to(self.device, torch.int64).contiguous()
+        rows, vocab = lg.shape
+        out = torch.empty(rows, dtype=torch.float32, device=self.device)
+        if rows:
+            abi.check(self.lib.eilev_ce_loss(_ptr(lg), _ptr(tg), 1.0, _ptr(out), None, rows, vocab, self._stream()), "eilev_ce_loss")
+        return out
+
+    def ce_mean(self, logits32: torch.Tensor, targets: torch.Tensor):
+        """Mean over the rows with a valid target (NaN when there is none, as F.cross_entropy gives)."""
+        tg = targets.to(self.device, torch.int64).reshape(-1)
+        rows = self.ce_rows(logits32.reshape(-1, logits32.shape[-1]), tg)
+        return rows.sum() / (tg >= 0).sum().to(torch.float32)
+
     def new_kv_cache(self, batch, capacity):
         nb = self.lib.eilev_opt_kv_cache_bytes(C.byref(self.dims), batch, capacity)
         # not zeroed (10 GB at batch 32): every slot is written (kv_write) before any kernel reads it
@@ -293,7 +335,7 @@ class HipEngine:
             logits = self.extend(emb, full, L, kv_rows, cap)
             shift = torch.cat((last.repeat_interleave(nc, dim=0)[:, None], logits[:, :-1]), dim=1)
             labels = torch.where(rows_msk != 0, rows_ids, torch.full_like(rows_ids, -100))
-            nll = torch.nn.functional.cross_entropy(shift.reshape(-1, d.vocab), labels.reshape(-1), reduction="none")
+            nll = self.ce_rows(shift.reshape(-1, d.vocab), labels.reshape(-1))
             cols.append(-nll.view(B, nc, Lc).sum(-1) / msk.sum(-1).unsqueeze(0).to(torch.float32))
             del kv_rows
         return torch.cat(cols, dim=1)
@@ -308,7 +350,14 @@ class HipEngine:
         if max_new_tokens <= 0:
             return torch.empty((B, 0), dtype=torch.int64, device=self.device)
         if B > 32:
-            raise NotImplementedError("decode batch > 32 per call is not supported yet; split the batch")
+            # the decode kernels stream the weights once for up to 32 rows: larger batches run as consecutive 32-row decodes (the
+            # reference accepts any batch size); rows that stop early are padded like HF pads them
+            if return_step_logits:
+                raise NotImplementedError("return_step_logits with more than 32 rows")
+            parts = [self.greedy_decode(inputs_embeds[i:i + 32], attention_mask[i:i + 32], max_new_tokens, eos_id, pad_id, use_graph, poll_every)
+                     for i in range(0, B, 32)]
+            n = max(p.shape[1] for p in parts)
+            return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
         cap = L + max_new_tokens
         n_dec = max_new_tokens - 1
         graphable = use_graph and n_dec > 1 and not return_step_logits
@@ -406,8 +455,16 @@ class HipEngine:
         d = self.dims
         B, L, _ = inputs_embeds.shape
         R = B * num_beams
+        if num_beams > 32:
+            raise NotImplementedError("num_beams > 32")
         if R > 32:
-            raise NotImplementedError("batch * num_beams > 32 rows per decode call is not supported yet")
+            # at most 32 decode rows per call: beam search of a large batch runs sample group by sample group (groups are
+            # independent in beam search); shorter results are padded with pad_id like HF pads finished hypotheses
+            per = max(1, 32 // num_beams)
+            parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
+                                      pad_id, early_stopping, num_return_sequences) for i in range(0, B, per)]
+            n = max(p.shape[1] for p in parts)
+            return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
         cap = L + max_new_tokens
         am = attention_mask.to(self.device, torch.int32).contiguous()
         last, _, kv_small = self.prefill(inputs_embeds, am, kv_capacity=cap)

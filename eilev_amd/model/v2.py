@@ -8,8 +8,8 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
-Not built yet (raise ``NotImplementedError``): sampling / contrastive decoding, the Flan-T5 language model, ``classify``,
-``output_attentions`` / ``output_hidden_states``, and autograd through the HIP path (training).
+Not built (raise ``NotImplementedError``): sampling / contrastive decoding; ``output_attentions`` / ``output_hidden_states`` of the
+Q-Former and the language model inside the full model's ``forward`` (the vision wrapper serves them from a slow path).
 """
 from __future__ import annotations
 
@@ -172,15 +172,23 @@ class VideoBlipVisionModel(nn.Module):
     def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None):
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / per-layer hidden states are not exported by the fused HIP path")
         _require_gpu(next(self.parameters()), "VideoBlipVisionModel.forward")
         dtype = next(self.parameters()).dtype
-        last, pooled = self._engine().vit(pixel_values, want_pooler=True)
+        hidden = attn = None
+        if output_attentions or output_hidden_states:
+            # debug outputs: the slow path of the library (eilev_vit_forward_debug), shapes as ref:eilev/model/v2.py:76-103:
+            # hidden_states = layers + 1 tensors (N, T*tokens, D), attentions = layers tensors (N, T, heads, tokens, tokens)
+            last, pooled, hid, att = self._engine().vit_debug(pixel_values, bool(output_hidden_states), bool(output_attentions))
+            if hid is not None:
+                hidden = tuple(h.to(dtype) for h in hid)
+            if att is not None:
+                attn = tuple(a.to(dtype) for a in att)
+        else:
+            last, pooled = self._engine().vit(pixel_values, want_pooler=True)
         last, pooled = last.to(dtype), pooled.to(dtype)
         if return_dict is False:
-            return (last, pooled, None, None)
-        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled, hidden_states=None, attentions=None)
+            return tuple(v for v in (last, pooled, hidden, attn) if v is not None)
+        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled, hidden_states=hidden, attentions=attn)
 
 
 def _params_key(module: nn.Module):
@@ -259,13 +267,17 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device, lm_weights=lm_weights))
         return self._hip[1]
 
-    def _encode(self, pixel_values, input_ids, video_input_mask):
+    def _encode(self, pixel_values, input_ids, video_input_mask, vision_debug=(False, False)):
         eng = self.engine()
         feats = None
         vision = qf = None
         if pixel_values is not None:
             assert video_input_mask is not None
-            img, pooled = eng.vit(pixel_values, want_pooler=True)
+            if any(vision_debug):  # slow path: per-block hidden states / attention maps of the ViT
+                img, pooled, hid, att = eng.vit_debug(pixel_values, want_hidden=vision_debug[0], want_attn=vision_debug[1])
+                self._vision_debug = (None if hid is None else tuple(hid), None if att is None else tuple(att))
+            else:
+                img, pooled = eng.vit(pixel_values, want_pooler=True)
             q = eng.qformer(img)
             feats = eng.project(q)
             vision, qf = (img, pooled), q
@@ -277,13 +289,29 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                 decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         """pixel_values: (num_videos, C, T, H, W); video_input_mask: (batch, seq_len)  [ref:eilev/model/v2.py:132-252].
 
-        In ``train()`` mode with ``labels``, autograd enabled and at least one trainable parameter (what `Trainer` does for train_v2:
+        With ``labels``, autograd enabled and at least one trainable parameter (what `Trainer` does for train_v2:
         ref:scripts/general/train_v2.py:124-130, 207-217) the call returns a loss with a gradient, computed by the training
-        graph of eilev_amd/train.py (logits are not materialised on that route).  Otherwise it runs without autograd."""
-        if self.training and labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        graph of eilev_amd/train.py (logits are not materialised on that route); dropout is applied in ``train()`` mode only.
+        Otherwise (no labels, ``torch.no_grad()``, or nothing trainable) it runs the inference kernels without autograd."""
+        # the differentiable route is chosen by what the CALL needs (labels, autograd on, a train_v2-style trainable set), see
+        # _wants_graph: `model.eval()` + `loss.backward()` (fine-tuning with dropout off) gets a loss with a graph too; the module
+        # mode decides whether dropout is applied, as in the reference
+        if labels is not None and torch.is_grad_enabled() and self._wants_graph():
             return self._forward_train(input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict)
         return self._forward_eval(input_ids, attention_mask, pixel_values, video_input_mask, decoder_input_ids, decoder_attention_mask,
                                   output_attentions, output_hidden_states, labels, return_dict)
+
+    def _wants_graph(self) -> bool:
+        """train() mode with anything trainable -> the training graph (which refuses, loudly, a trainable ViT / language model).
+        eval() mode -> the graph only when the model is frozen the way train_v2 freezes it (ViT + language model frozen, something
+        else trainable): `model.eval(); loss.backward()` then works, while a freshly built model (every parameter trainable) that
+        is merely evaluated without `torch.no_grad()` keeps getting logits from the inference route."""
+        trainable = [n for n, p in self.named_parameters() if p.requires_grad]
+        if not trainable:
+            return False
+        if self.training:
+            return True
+        return not any(n.startswith(("vision_model.", "language_model.")) for n in trainable)
 
     def _forward_train(self, input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict):
         from ..engine import HipEngine
@@ -299,7 +327,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         # train() mode = dropout on, as under the reference's Trainer; a fresh mask seed every call (torch's seed + a call counter)
         self._hip_train_calls = getattr(self, "_hip_train_calls", 0) + 1
         seed = (torch.initial_seed() * 1000003 + self._hip_train_calls) & 0xFFFFFFFF
-        graph = TrainGraph(cached[1], params, dropout=getattr(self, "hip_train_dropout", True), seed=seed)
+        graph = TrainGraph(cached[1], params, dropout=self.training and getattr(self, "hip_train_dropout", True), seed=seed)
         loss = graph.loss(input_ids, attention_mask, pixel_values, video_input_mask, labels)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         if not return_dict:
@@ -318,11 +346,14 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                       decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         if pixel_values is not None:
             assert video_input_mask is not None
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / per-layer hidden states are not exported by the fused HIP path")
+        # output_hidden_states / output_attentions: the VISION outputs carry them (slow path of the library, what
+        # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper); the fused Q-Former / language-model kernels do not
+        # export per-block tensors, their output objects keep these fields None
+        self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
-        emb, vision, qf = self._encode(pixel_values, input_ids, video_input_mask)
+        emb, vision, qf = self._encode(pixel_values, input_ids, video_input_mask,
+                                       vision_debug=(bool(output_hidden_states), bool(output_attentions)))
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if self._is_t5:
@@ -333,11 +364,14 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             # HF causal-LM loss: shifted CE, ignore_index -100 (hf loss_utils.ForCausalLMLoss)
             shift = logits32[:, :-1].reshape(-1, logits32.size(-1))
             tgt = labels.to(logits32.device)[:, 1:].reshape(-1)
-            loss = nn.functional.cross_entropy(shift, tgt, ignore_index=-100).to(dtype)
+            loss = self.engine().ce_mean(shift, tgt).to(dtype)
         logits = logits32.to(dtype)
         vis_out = qf_out = None
         if vision is not None:
-            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype))
+            vh, va = getattr(self, "_vision_debug", (None, None))
+            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype),
+                                                 hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
+                                                 attentions=None if va is None else tuple(a.to(dtype) for a in va))
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
         lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
         if not return_dict:
@@ -364,12 +398,14 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         logits32, enc = self.engine().t5_forward(emb, attention_mask, decoder_input_ids)
         loss = None
         if labels is not None:
-            loss = nn.functional.cross_entropy(logits32.reshape(-1, logits32.size(-1)), labels.to(logits32.device).reshape(-1),
-                                               ignore_index=-100).to(dtype)
+            loss = self.engine().ce_mean(logits32.reshape(-1, logits32.size(-1)), labels.to(logits32.device).reshape(-1)).to(dtype)
         logits = logits32.to(dtype)
         vis_out = qf_out = None
         if vision is not None:
-            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype))
+            vh, va = getattr(self, "_vision_debug", (None, None))
+            vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype),
+                                                 hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
+                                                 attentions=None if va is None else tuple(a.to(dtype) for a in va))
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
         lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype))
         if not return_dict:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 6
+#define EILEV_ABI_VERSION 7
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -140,6 +140,16 @@ size_t eilev_vit_workspace_bytes(const EilevDims *d, int64_t n_clips, int64_t fr
 int eilev_vit_forward(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
                       int64_t n_clips, int64_t frames, void *image_embeds, void *pooler,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug outputs of the vision wrapper (ref:eilev/model/v2.py:76-103; shapes asserted by ref:tests/model/test_model_v2.py:57-83):
+ * eilev_vit_forward plus, when non-NULL,
+ *   hidden_states: (v_layers + 1, N, T*tokens, Dv) — embeddings output, then the residual stream after every block (what
+ *                  hf Blip2Encoder :466-478 collects with output_hidden_states=True);
+ *   attentions:    (v_layers, N, T, heads, tokens, tokens) — softmax(scale q k^T) of every block (hf eager attention weights).
+ * A slow path (copies + an unfused probability kernel); tokens <= 1024 for `attentions`. */
+int eilev_vit_forward_debug(const EilevDims *d, const EilevVitWeights *w, const void *pixels, int pixels_dtype,
+                            int64_t n_clips, int64_t frames, void *image_embeds, void *pooler, void *hidden_states,
+                            void *attentions, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- stage 2: Q-Former --------------------------------------------------------------------
  * Replaces Blip2QFormerModel.forward as called from ref:eilev/model/v2.py:291-300 with
@@ -352,7 +362,8 @@ int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_
  * eilev_colsum: out[c] += sum_r dy[r, c] (bias gradient; f32, accumulated).
  * eilev_act_fwd / eilev_act_bwd: y = act(pre) / dx = dy * act'(pre); kind 1 erf-GELU, 2 ReLU.
  * eilev_ce_loss: hf loss_utils.ForCausalLMLoss per row: row_loss[r] = logsumexp(logits[r]) - logits[r, target[r]],
- *   dlogits[r] = (softmax(logits[r]) - onehot(target[r])) * grad_scale; rows with target < 0 (ignore_index -100) get 0. */
+ *   dlogits[r] = (softmax(logits[r]) - onehot(target[r])) * grad_scale; rows with target < 0 (ignore_index -100) get 0.
+ *   dlogits may be NULL (loss only: the eval-mode loss of forward(labels=...) and classify's log-likelihoods). */
 int eilev_attention_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, void *dq,
                         void *dk, void *dv, float *lse_delta, int64_t batch, int64_t heads, int64_t sq,
                         int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddq,

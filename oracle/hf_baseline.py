@@ -1,0 +1,106 @@
+"""CPU baseline from STOCK transformers modules (TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT).
+
+The reference (yukw777/EILEV) computes this path with `transformers` classes it subclasses / instantiates
+(ref:eilev/model/v2.py:3-17, 111-127: Blip2VisionModel, Blip2QFormerModel, nn.Linear, OPTForCausalLM) — the reference's own
+files never travel to the GPU box, so the same stock classes are composed HERE by this harness:
+    pixels (N, 3, T, H, W) -> permute/flatten -> Blip2VisionModel -> (N, T*257, 1408)   [what v2.py:57-70 does]
+    -> Blip2QFormerModel(query_tokens, encoder_hidden_states) -> language_projection -> embed + boolean scatter
+    -> OPTForCausalLM.generate(inputs_embeds=..., greedy)                               [what v2.py:285-322 does]
+and timed on the host CPUs.  Only `bench.py::cpu_baseline` and tests import this module.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def build_hf_modules(cfg, host_weights: dict, dtype=torch.float32):
+    """Stock HF modules holding `host_weights` (name -> fp32 numpy / tensor, reference key names).  Built on the meta device and
+    assigned, so no random init of 3.7 B parameters."""
+    from transformers import OPTForCausalLM
+    from transformers.models.blip_2.modeling_blip_2 import Blip2QFormerModel, Blip2VisionModel
+
+    def sub(prefix):
+        out = {}
+        for k, v in host_weights.items():
+            if k.startswith(prefix):
+                t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+                out[k[len(prefix):]] = t.to(dtype)
+        return out
+
+    def make(cls, conf, prefix):
+        with torch.device("meta"):
+            m = cls(conf)
+        sd = sub(prefix)
+        if prefix == "language_model." and "lm_head.weight" not in sd:
+            sd["lm_head.weight"] = sd["model.decoder.embed_tokens.weight"]
+        missing, unexpected = m.load_state_dict(sd, assign=True, strict=False)
+        left = [n for n, p in list(m.named_parameters()) + list(m.named_buffers()) if p.device.type == "meta"]
+        if left or unexpected:
+            raise RuntimeError(f"{cls.__name__}: unfilled {left[:4]} unexpected {list(unexpected)[:4]}")
+        return m.eval()
+
+    vit = make(Blip2VisionModel, cfg.vision_config, "vision_model.")
+    qf = make(Blip2QFormerModel, cfg.qformer_config, "qformer.")
+    lm = make(OPTForCausalLM, cfg.text_config, "language_model.")
+    to_t = lambda v: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).to(dtype)
+    proj_w, proj_b = to_t(host_weights["language_projection.weight"]), to_t(host_weights["language_projection.bias"])
+    query_tokens = to_t(host_weights["query_tokens"])
+    return vit, qf, lm, (proj_w, proj_b), query_tokens
+
+
+@torch.no_grad()
+def hf_encode(vit, qf, proj, query_tokens, pixels: torch.Tensor):
+    """(N, 3, T, H, W) -> (N * num_query, Dt): what ref:eilev/model/v2.py:57-70, 285-310 compose out of the same modules."""
+    N, _, T, H, W = pixels.shape
+    flat = pixels.permute(0, 2, 1, 3, 4).flatten(0, 1)
+    hid = vit(pixel_values=flat).last_hidden_state                     # (N*T, 257, Dv)
+    img = hid.reshape(N, T * hid.shape[1], hid.shape[2])
+    mask = torch.ones(img.shape[:-1], dtype=torch.long)
+    q = qf(query_embeds=query_tokens.expand(N, -1, -1), encoder_hidden_states=img, encoder_attention_mask=mask).last_hidden_state
+    return torch.nn.functional.linear(q, proj[0], proj[1]).reshape(-1, proj[0].shape[0])
+
+
+@torch.no_grad()
+def hf_generate(lm, feats, input_ids, video_mask, new_tokens: int):
+    emb = lm.get_input_embeddings()(input_ids)
+    emb[video_mask.bool()] = feats.to(emb.dtype)
+    am = torch.ones_like(input_ids)
+    return lm.generate(inputs_embeds=emb, attention_mask=am, max_new_tokens=new_tokens, min_new_tokens=new_tokens, do_sample=False,
+                       num_beams=1, pad_token_id=1)
+
+
+def time_hf_cpu(cfg, host_weights, n_ctx: int, frames: int, new_tokens: int, synth_ids, threads: int | None = None):
+    """C1 (1 clip, 0-shot, L = 48, greedy) end to end, and a bounded sample of C2 (16-shot): one clip through ViT + Q-Former,
+    one L = 960 prefill and the decode steps of one sample; C2 = (n_ctx + 1) x clip + LM.  fp32 (the reference's default
+    dtype on CPU, ref:samples/eilev_generate_action_narration.py:98-100)."""
+    cores = os.cpu_count() or 1
+    threads = threads or cores
+    torch.set_num_threads(threads)
+    vit, qf, lm, proj, qt = build_hf_modules(cfg, host_weights)
+    nq, vocab = cfg.num_query_tokens, cfg.text_config.vocab_size
+    g = torch.Generator().manual_seed(1234)
+    px = torch.randn((1, 3, frames, cfg.vision_config.image_size, cfg.vision_config.image_size), generator=g).clamp_(-2.5, 2.5)
+    # C1: 1 clip, 0 in-context: [bos] + 32 pads + nl + 14 prompt tokens = 48 tokens
+    ids1, vm1 = synth_ids([1], [14], nq, vocab, seed=1)
+    ids1, vm1 = torch.from_numpy(ids1)[None], torch.from_numpy(vm1)[None]
+    t0 = time.perf_counter()
+    feats = hf_encode(vit, qf, proj, qt, px)
+    t_clip = time.perf_counter() - t0
+    out1 = hf_generate(lm, feats, ids1, vm1, new_tokens)
+    t_c1 = time.perf_counter() - t0
+    assert out1.shape == (1, new_tokens)
+    # C2 sample: the language-model part of ONE 16-shot sample (L = 960) on projected tokens of the clip above repeated
+    ids2, vm2 = synth_ids([1] * (n_ctx + 1), [24] * n_ctx + [14], nq, vocab, seed=1)
+    ids2, vm2 = torch.from_numpy(ids2)[None], torch.from_numpy(vm2)[None]
+    t0 = time.perf_counter()
+    out2 = hf_generate(lm, feats.repeat(n_ctx + 1, 1), ids2, vm2, new_tokens)
+    t_lm = time.perf_counter() - t0
+    assert out2.shape == (1, new_tokens)
+    per_sample = (n_ctx + 1) * t_clip + t_lm
+    return {"c1_seconds": round(t_c1, 2), "c1_clips_per_s": round(1.0 / t_c1, 4), "clip_encode_seconds": round(t_clip, 2),
+            "lm_16shot_seconds": round(t_lm, 2), "c2_clips_per_s": round((n_ctx + 1) / per_sample, 4), "threads": threads, "cores": cores,
+            "torch": torch.__version__, "dtype": "fp32"}

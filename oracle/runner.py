@@ -74,6 +74,22 @@ class OracleModel:
                                              _p(pool), _p(ws), nbytes, None), "oracle vit")
         return (out, pool) if want_pooler else out
 
+    def vit_debug(self, pixels: np.ndarray):
+        """(last, pooler, hidden_states (L+1, N, T*tok, D), attentions (L, N, T, H, tok, tok)) — ref:eilev/model/v2.py:76-103."""
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        N, _, T = px.shape[:3]
+        d = self.dims
+        tok = self.tokens_per_frame
+        out = np.empty((N, T * tok, d.v_hidden), np.float32)
+        pool = np.empty((N, T, d.v_hidden), np.float32)
+        hid = np.empty((d.v_layers + 1, N, T * tok, d.v_hidden), np.float32)
+        att = np.empty((d.v_layers, N, T, d.v_heads, tok, tok), np.float32)
+        nbytes = self.lib.eilev_vit_workspace_bytes(C.byref(d), N, T)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_vit_forward_debug(C.byref(d), C.byref(self.pack.vit), _p(px), abi_f32(), N, T, _p(out), _p(pool), _p(hid),
+                                                   _p(att), _p(ws), nbytes, None), "oracle vit debug")
+        return out, pool, hid, att
+
     def qformer(self, image_embeds: np.ndarray):
         img = np.ascontiguousarray(image_embeds, dtype=np.float32)
         N, kv = img.shape[:2]

@@ -59,3 +59,20 @@ def stream_ptr():
 
 def P(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def record_parity(section: str, **numbers):
+    """Append measured parity distances to gpurun_out/parity_r02.json (merged back from the GPU box; the copy under
+    profiles/ is the tracked one).  Numbers only: what HIP-vs-reference distances actually are, next to the tolerance."""
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_r02.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as fh:
+            data = json.load(fh)
+    except (OSError, ValueError):
+        data = {}
+    data.setdefault(section, {}).update({k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v)
+                                         for k, v in numbers.items()})
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1, sort_keys=True)

@@ -120,3 +120,44 @@ def test_classify_like_the_reference(golden_dir, name, dtype):
     assert np.abs(host(ll2) - host(ll)).max() <= 2e-2  # chunking only changes GEMM shapes
     if dtype == torch.float32:
         assert np.array_equal(host(ll).argmax(-1), truth.argmax(-1)) or np.sort(truth, -1)[:, -1].min() - np.sort(truth, -1)[:, -2].max() < 5e-2
+
+
+def test_vision_model_debug_outputs_like_the_reference(golden_dir):
+    """VideoBlipVisionModel(output_hidden_states=True, output_attentions=True): shapes of ref:tests/model/test_model_v2.py:57-83,
+    values against the reference's own run (tests/golden/mid_vitdebug.npz, eager attention)."""
+    import json
+    import os
+
+    import numpy as np
+
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipVisionModel
+    from eilev_amd.synth import synth_pixels
+    from hip_utils import rel_rms
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(golden_dir, "mid_vitdebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    vc = cfg.vision_config
+    vm = VideoBlipVisionModel(vc)
+    sd = synth_state_dict(cfg)
+    vm.load_state_dict({k[len("vision_model."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("vision_model.")})
+    vm = vm.cuda().eval()
+    px = torch.from_numpy(synth_pixels(meta["clips"], meta["frames"], vc.image_size)).cuda()
+    N, T, L = meta["clips"], meta["frames"], vc.num_hidden_layers
+    tok = (vc.image_size // vc.patch_size) ** 2 + 1
+    o = vm(px, output_attentions=True, output_hidden_states=True, return_dict=True)
+    assert o.last_hidden_state.shape == (N, T * tok, vc.hidden_size) and o.pooler_output.shape == (N, T, vc.hidden_size)
+    assert len(o.hidden_states) == L + 1 and all(h.shape == (N, T * tok, vc.hidden_size) for h in o.hidden_states)
+    assert len(o.attentions) == L and all(a.shape == (N, T, vc.num_attention_heads, tok, tok) for a in o.attentions)
+    hid = np.stack([h.float().cpu().numpy() for h in o.hidden_states])
+    att = np.stack([a.float().cpu().numpy() for a in o.attentions])
+    ref_dev = np.abs(g["bf16_hidden_states"] - g["fp32_hidden_states"]).max()
+    assert np.abs(hid - g["fp32_hidden_states"]).max() <= 1.5 * ref_dev + 1e-3 and rel_rms(hid, g["fp32_hidden_states"]) <= 1e-2
+    assert np.abs(att - g["fp32_attentions"]).max() <= 1.5 * np.abs(g["bf16_attentions"] - g["fp32_attentions"]).max() + 4e-3
+    # the debug path and the fused path agree on what both return
+    fused = vm(px, return_dict=True)
+    assert torch.equal(fused.last_hidden_state, o.last_hidden_state) and torch.equal(fused.pooler_output, o.pooler_output)
+    tup = vm(px, output_hidden_states=True, return_dict=False)
+    assert len(tup) == 3 and len(tup[2]) == L + 1

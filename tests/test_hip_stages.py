@@ -193,3 +193,23 @@ def test_extend_vs_oracle(golden_dir, name):
     assert rel_rms(host(emb), emb_o) <= 1e-2
     ll = eng.classify_loglik(emb, t(g["attention_mask"]), t(g["class_input_ids"]), t(g["class_attention_mask"]))
     assert np.abs(host(ll) - ll_o).max() <= 1.5 * np.abs(g["bf16_classify"] - g["fp32_classify"]).max() + 2e-2
+
+
+def test_decode_batches_above_32_rows_are_chunked(golden_dir):
+    """the reference accepts any batch size; the decode kernels take 32 rows per call, so larger batches (and
+    batch x beams > 32) run in consecutive groups — same ids as running the groups by hand."""
+    g, meta, px = load_case(golden_dir, "mid_b2")
+    cfg, oracle, eng = models(meta["config"])
+    feats = eng.encode_clips(torch.from_numpy(px).cuda())
+    emb = eng.embed_scatter(torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["video_input_mask"]).cuda(), feats)
+    am = torch.from_numpy(g["attention_mask"]).cuda()
+    n = meta["new_tokens"]
+    two = eng.greedy_decode(emb, am, n, eos_id=int(g["fp32_eos_id"]))
+    big_e, big_m = emb.repeat(21, 1, 1), am.repeat(21, 1)                       # 42 rows
+    ids = eng.greedy_decode(big_e, big_m, n, eos_id=int(g["fp32_eos_id"]))
+    assert ids.shape[0] == 42 and torch.equal(ids[:2], two) and torch.equal(ids[40:], two)
+    beams = eng.beam_decode(emb, am, n, 5, -1.0, eos_id=int(g["fp32_eos_id"]))
+    many = eng.beam_decode(emb.repeat(5, 1, 1), am.repeat(5, 1), n, 5, -1.0, eos_id=int(g["fp32_eos_id"]))  # 10 samples x 5 beams = 50 rows
+    assert many.shape[0] == 10
+    for i in range(5):
+        assert torch.equal(many[2 * i: 2 * i + 2, : beams.shape[1]], beams)

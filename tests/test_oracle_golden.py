@@ -199,3 +199,22 @@ def test_t5_beam_search_matches_reference(golden_dir, models, name, nm, nb, lp):
     assert ids.shape == ref.shape and np.array_equal(ids, ref), (ids, ref)
     free = m.t5_generate_beam(*args, eos_id=-1)
     assert np.array_equal(free, g[f"fp32_{nm}_free"])
+
+
+def test_vision_debug_outputs_match_reference(golden_dir):
+    """output_hidden_states / output_attentions of the vision wrapper (ref:eilev/model/v2.py:76-103; shapes asserted by
+    ref:tests/model/test_model_v2.py:57-83) — the oracle's eilev_vit_forward_debug against the reference's eager-attention run."""
+    g = np.load(os.path.join(golden_dir, "mid_vitdebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(meta["clips"], meta["frames"], cfg.vision_config.image_size)
+    m = OracleModel(cfg, synth_state_dict(cfg))
+    last, pool, hid, att = m.vit_debug(px)
+    L, N, T = cfg.vision_config.num_hidden_layers, meta["clips"], meta["frames"]
+    tok = (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2 + 1
+    assert hid.shape == (L + 1, N, T * tok, cfg.vision_config.hidden_size) == g["fp32_hidden_states"].shape
+    assert att.shape == (L, N, T, cfg.vision_config.num_attention_heads, tok, tok) == g["fp32_attentions"].shape
+    assert np.abs(last - g["fp32_last"]).max() < 2e-4 and np.abs(pool - g["fp32_pooler"]).max() < 2e-4
+    assert np.abs(hid - g["fp32_hidden_states"]).max() < 2e-4
+    assert np.abs(att - g["fp32_attentions"]).max() < 1e-5
+    assert np.allclose(att.sum(-1), 1.0, atol=1e-5)

@@ -1,0 +1,43 @@
+"""Pins the CPU oracle at the REAL widths of eilev-blip2-opt-2.7b (tests/golden/real_b1.npz: one ViT block at 1408 / 6144 /
+16 heads on 224 x 224 frames, a Q-Former block pair with cross-attention over the real 2056 keys, one OPT-2.7B block with
+the 50272-token vocabulary; produced by tools/make_goldens.py from the reference).  Outputs are subsampled in the fixture;
+tolerances as in test_oracle_golden.py (fp32, summation order only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from eilev_amd.configs import blip2_config
+from eilev_amd.synth import synth_pixels
+from oracle.runner import OracleModel, synth_state_dict
+
+
+@pytest.fixture(scope="module")
+def case(golden_dir):
+    g = np.load(os.path.join(golden_dir, "real_b1.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)
+    return g, meta, cfg, px, OracleModel(cfg, synth_state_dict(cfg))
+
+
+def test_real_width_stages_match_reference(case):
+    g, meta, cfg, px, m = case
+    img, pool = m.vit(px, want_pooler=True)
+    rows = img.reshape(-1, img.shape[-1])[g["vit_rows"]]
+    assert np.abs(rows - g["fp32_vit_rows"]).max() < 2e-4
+    assert abs(img.astype(np.float64).sum() - g["fp32_vit_checksum"][0]) < 1e-6 * g["fp32_vit_checksum"][1]
+    assert np.abs(pool - g["fp32_pooler"]).max() < 2e-4
+    q = m.qformer(img)
+    assert np.abs(q - g["fp32_qformer"]).max() < 2e-4
+    logits = m.forward_logits(px, g["input_ids"], g["attention_mask"], g["video_input_mask"])
+    assert np.abs(logits[:, :, g["logit_cols"]] - g["fp32_logits_cols"]).max() < 5e-4
+    assert np.abs(logits[:, -1] - g["fp32_logits_last"]).max() < 5e-4
+    assert abs(logits.astype(np.float64).sum() - g["fp32_logits_checksum"][0]) < 1e-6 * g["fp32_logits_checksum"][1]
+
+
+def test_real_width_greedy_ids_match_reference(case):
+    g, meta, cfg, px, m = case
+    ids = m.generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
+    assert np.array_equal(ids, g["fp32_greedy_free"])

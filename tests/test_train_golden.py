@@ -325,3 +325,43 @@ def test_bf16_parameters_train_too():
             assert p.grad is not None and p.grad.dtype == torch.bfloat16, k
             got = float(p.grad.float().norm())
             assert abs(got - norms[k]) <= 8e-2 * norms[k] + floor, (k, got, norms[k])
+
+
+def test_eval_mode_backward_and_unsupervised_batch():
+    """(a) `model.eval()` fine-tuning (dropout off) still gets a loss with a graph — and the SAME loss as train() mode with
+    dropout disabled; (b) a batch without any supervised position gives the reference's NaN loss (F.cross_entropy over zero rows)
+    with a zero gradient instead of an exception."""
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from oracle.runner import synth_state_dict
+
+    g = np.load(os.path.join(GOLD, "train_tiny_b2.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    model = VideoBlipForConditionalGeneration(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
+    model = model.cuda()
+    for p in list(model.vision_model.parameters()) + list(model.language_model.parameters()):
+        p.requires_grad = False
+    pixels, input_ids, attn, vmask, labels = _batch(meta)
+    t = lambda a: torch.from_numpy(a).cuda()
+    batch = dict(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels), video_input_mask=t(vmask), labels=t(labels))
+    model.eval()
+    out = model(**batch)
+    assert out.loss.requires_grad and abs(float(out.loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    out.loss.backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad}
+    assert grads and all(torch.isfinite(v).all() for v in grads.values())
+    model.zero_grad()
+    model.train()
+    model.hip_train_dropout = False
+    again = model(**batch)
+    assert float(again.loss) == float(out.loss)
+    with torch.no_grad():  # no autograd -> the inference route, logits present
+        assert model(**batch).logits is not None
+    model.zero_grad()
+    empty = dict(batch, labels=torch.full_like(batch["labels"], -100))
+    o = model(**empty)
+    assert torch.isnan(o.loss)
+    o.loss.backward()
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in model.parameters() if p.requires_grad)

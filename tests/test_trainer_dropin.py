@@ -38,11 +38,18 @@ class _Samples(torch.utils.data.Dataset):
         return self.items[i]
 
 
+def _collator():
+    """The SHIPPED collator, constructed as train_v2 does (ref:scripts/general/train_v2.py:207-216: tokenizer,
+    pad_to_multiple_of=8 under bf16).  The fixture rows were LEFT padded when they were made, so the padding the collator adds
+    (right side, training convention) comes on top: ids get pad 1, labels -100, the masks 0."""
+    from eilev_amd.data.utils import DataCollatorForInterleavedVideoSeq2Seq
+    from tok_utils import tiny_opt_like_tokenizer
+
+    return DataCollatorForInterleavedVideoSeq2Seq(tiny_opt_like_tokenizer("right"), pad_to_multiple_of=8)
+
+
 def _collate(samples):
-    """What DataCollatorForInterleavedVideoSeq2Seq yields (ref:eilev/data/utils.py:35-66): clips concatenated, id tensors stacked."""
-    out = {k: torch.stack([s[k] for s in samples]) for k in ("input_ids", "attention_mask", "video_input_mask", "labels")}
-    out["pixel_values"] = torch.cat([s["pixel_values"] for s in samples])
-    return out
+    return _collator()([dict(s) for s in samples])
 
 
 def test_hf_trainer_trains_the_qformer_on_the_hip_graph(tmp_path):
@@ -68,7 +75,7 @@ def test_hf_trainer_trains_the_qformer_on_the_hip_graph(tmp_path):
         output_dir=str(tmp_path), per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=4, learning_rate=1e-3,
         weight_decay=0.05, warmup_steps=0, bf16=True, remove_unused_columns=False, report_to=[], save_strategy="no", logging_steps=1,
         dataloader_num_workers=0, optim="adamw_torch", seed=0)
-    trainer = transformers.Trainer(model=model, args=args, train_dataset=_Samples(meta, 8), data_collator=_collate)
+    trainer = transformers.Trainer(model=model, args=args, train_dataset=_Samples(meta, 8), data_collator=_collator())
     result = trainer.train()
     losses = [h["loss"] for h in trainer.state.log_history if "loss" in h]
     assert result.global_step == 4 and len(losses) == 4 and all(np.isfinite(losses))

@@ -273,6 +273,93 @@ def run_case(name):
           os.path.getsize(path))
 
 
+REAL_CASES = {
+    # name: (config, frames T, rows, new_tokens) — real widths, one block per stack (SURVEY 8c golden plan (2)).  The clip has
+    # the real 8 frames so the Q-Former's cross-attention sees the real 2056 keys; L = 1 + 2 * 33 + 18 = 85 tokens.
+    "real_b1": ("real_1l", 8, [([1, 1], [10, 8])], 5),
+}
+REAL_VIT_ROWS, REAL_LOGIT_COLS = 64, 512
+
+
+def real_subsample(cfg, n_clips, frames, L):
+    """Which rows / columns of the big tensors a real-shape fixture keeps (deterministic; tests rebuild the same index sets)."""
+    from eilev_amd.synth import det_uniform_int
+
+    tokens = frames * ((cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2 + 1)
+    rows = np.unique(np.concatenate([[0, 1, 256, 257, tokens - 1, n_clips * tokens - 1],   # CLS rows, frame seams, the last row
+                                     det_uniform_int("real_vit_rows", (REAL_VIT_ROWS,), 0, n_clips * tokens)]))
+    cols = np.unique(det_uniform_int("real_logit_cols", (REAL_LOGIT_COLS,), 0, cfg.text_config.vocab_size))
+    return rows, cols
+
+
+@torch.no_grad()
+def run_real_case(name):
+    """Real-width single-block fixture: outputs are SUBSAMPLED (the weights come from the seed, not from the file)."""
+    cfg_name, frames, rows, new_tokens = REAL_CASES[name]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, labels = build_inputs(cfg_name, frames, rows)
+    B, L = input_ids.shape
+    vit_rows, logit_cols = real_subsample(cfg, pixels.shape[0], frames, L)
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        px = t(pixels).to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=px, video_input_mask=t(vmask), labels=t(labels), return_dict=True)
+        vit = o.vision_outputs.last_hidden_state.float().numpy()
+        out[f"{tag}_vit_rows"] = vit.reshape(-1, vit.shape[-1])[vit_rows]
+        out[f"{tag}_vit_checksum"] = np.asarray([vit.astype(np.float64).sum(), np.abs(vit.astype(np.float64)).sum()])
+        out[f"{tag}_pooler"] = o.vision_outputs.pooler_output.float().numpy()
+        out[f"{tag}_qformer"] = o.qformer_outputs.last_hidden_state.float().numpy()
+        lg = o.logits.float().numpy()
+        out[f"{tag}_logits_cols"] = lg[:, :, logit_cols]          # every position, sampled vocabulary columns
+        out[f"{tag}_logits_last"] = lg[:, -1]                     # the row generate() consumes, full vocabulary
+        out[f"{tag}_logits_checksum"] = np.asarray([lg.astype(np.float64).sum(), np.abs(lg.astype(np.float64)).sum()])
+        out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
+        g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                       max_new_tokens=new_tokens, min_new_tokens=new_tokens, num_beams=1, do_sample=False)
+        assert g.shape == (B, new_tokens), g.shape
+        out[f"{tag}_greedy_free"] = g.numpy().astype(np.int64)
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="fanin",
+                torch=torch.__version__, transformers=transformers.__version__, generator="tools/make_goldens.py",
+                reference="/root/reference/eilev/model/v2.py", subsample="eilev_amd.synth.det_uniform_int: see real_subsample()")
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, labels=labels, vit_rows=vit_rows, logit_cols=logit_cols,
+               meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
+@torch.no_grad()
+def run_vit_debug_case(name="mid_vitdebug"):
+    """output_hidden_states / output_attentions of the reference's VideoBlipVisionModel (ref:eilev/model/v2.py:76-103), eager
+    attention (sdpa returns no attention maps): 2 clips x 3 frames at the `mid` widths."""
+    cfg = blip2_config("mid")
+    cfg.vision_config._attn_implementation = "eager"
+    vm = _ref.VideoBlipVisionModel(cfg.vision_config).eval()
+    sd = {k: torch.from_numpy(synth_param("vision_model." + k, tuple(v.shape))) for k, v in vm.state_dict().items()}
+    vm.load_state_dict(sd)
+    frames, clips = 3, 2
+    pixels = synth_pixels(clips, frames, cfg.vision_config.image_size)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        o = vm.to(dtype)(torch.from_numpy(pixels).to(dtype), output_attentions=True, output_hidden_states=True, return_dict=True)
+        out[f"{tag}_last"] = o.last_hidden_state.float().numpy()
+        out[f"{tag}_pooler"] = o.pooler_output.float().numpy()
+        out[f"{tag}_hidden_states"] = np.stack([h.float().numpy() for h in o.hidden_states])
+        out[f"{tag}_attentions"] = np.stack([a.float().numpy() for a in o.attentions])
+    meta = dict(case=name, config="mid", frames=frames, clips=clips, weight_mode="fanin", torch=torch.__version__,
+                transformers=transformers.__version__, attn_implementation="eager", generator="tools/make_goldens.py",
+                reference="/root/reference/eilev/model/v2.py::VideoBlipVisionModel")
+    out["meta"] = np.asarray(json.dumps(meta))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: v.shape for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES)):
-        (run_t5_case if n in T5_CASES else run_case)(n)
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + ["mid_vitdebug"]):
+        (run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_vit_debug_case if n == "mid_vitdebug" else run_case)(n)
