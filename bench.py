@@ -162,13 +162,15 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     (b) one sample through the language model: the oracle prefills the SAME inputs_embeds (L = 960) and then decodes
         teacher-forced on the ids the HIP path generated (batch-32 prefill + hipGraph decode, as timed): last-row prefill
         logits, and per step the oracle's logit of the HIP token against the oracle's maximum.
-    bf16 storage vs an fp32 oracle: relative RMS <= 1e-2 (tests/test_hip_stages.py), and a generated id may differ from the
-    oracle's argmax only at a near-tie (margin <= 5 % of the logits' standard deviation)."""
+    The oracle runs with `emulate_bf16` (activations rounded to bf16 wherever the HIP path stores bf16, fp32 accumulation): through
+    39 + 12 + 32 blocks of random-init weights a pure-fp32 run is ~1.1e-2 relative RMS away from ANY bf16 implementation (measured:
+    profiles/parity_r02.json), so the fp32 distance says nothing about kernel correctness at this depth.  Bar: relative RMS <= 1e-2,
+    and a generated id may differ from the oracle's argmax only at a near-tie (margin <= 5 % of the logits' standard deviation)."""
     from oracle.runner import OracleModel
 
     t0 = time.perf_counter()
     host = lambda t: t.detach().float().cpu().numpy()
-    ora = OracleModel(cfg, weights)
+    ora = OracleModel(cfg, weights, emulate_bf16=True)  # rounds activations to bf16 where the HIP path stores bf16 (fp32 accumulation)
     chunk = px[: max(1, 1088 // FRAMES)]
     feats = eng.encode_clips(chunk)                                   # bench-shaped launch (M = 1088 x 257 rows in the ViT)
     nq = cfg.num_query_tokens
@@ -208,7 +210,7 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     ok = bool(q_rel <= 1e-2 and p_rel <= 1e-2 and max(margins) <= 0.05)
     return ok, {"query_tokens_rel_rms": round(q_rel, 5), "prefill_logits_rel_rms": round(p_rel, 5), "ids_equal_oracle_argmax": f"{exact}/{new_tokens}",
                 "max_margin_over_logit_std": round(max(margins), 5), "seconds": round(time.perf_counter() - t0, 1),
-                "what": "oracle/libeilev_ref.so fp32 on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
+                "what": "oracle/libeilev_ref.so (bf16-storage emulation, fp32 accumulate) on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
                         "sample 0 inputs_embeds -> prefill last-row logits + teacher-forced decode on the HIP ids (batch-32 prefill, hipGraph decode)"}
 
 
@@ -431,6 +433,11 @@ def main():
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
         if do_verify or do_cpu:  # fp32 host copy of the weights, shared by the oracle check and the stock-HF CPU baseline
+            from oracle.hf_baseline import effective_cpus
+
+            # the OpenMP pool (shared by torch's CPU ops and the oracle) sized to what the container may really use: a box that
+            # reports 256 logical CPUs under a smaller quota runs 10-40x slower with 256 spinning threads
+            torch.set_num_threads(max(1, min(effective_cpus(), 64)))
             host_w = {k: v.detach().float().cpu().numpy() for k, v in weights.items()}
         if do_verify:
             res["verified"], res["verification"] = verify_against_oracle(cfg, eng, host_w, px, ids, vm, am, NEW_TOKENS)

@@ -140,6 +140,10 @@ struct GemmArgs {
     const uint8_t *W8 = nullptr;    // [N, K] e4m3 bytes (ldw = K) when the weights are still quantised (skinny kernel)
     bf16 *w8_scratch = nullptr;     // [N, K] bf16: where a large-M call expands W8 to (exact: every e4m3 value is a bf16 value)
     int k_slice = 0;                // > 0: split-K launch (gridDim.y slices of k_slice K-steps, f32 output accumulated atomically)
+    // probe-only (tools/gemm_trace.py): per-tile phase timestamps of the persistent ping-pong kernel, 8 u64 per (workgroup, wave
+    // group, tile): s_memrealtime at loop top / K-loop start / K-loop end / epilogue start / epilogue end, s_memtime at top / end
+    unsigned long long *trace = nullptr;
+    int trace_tiles = 0;
 };
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);

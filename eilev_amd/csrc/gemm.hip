@@ -19,6 +19,9 @@
 
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
+unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
+int g_gemm_trace_tiles = 0;
+extern "C" int eilev_debug_gemm_trace(void *buf, int tiles) { g_gemm_trace = (unsigned long long *)buf; g_gemm_trace_tiles = tiles; return 0; }
 
 namespace {
 
@@ -769,7 +772,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     stage_step(0, w_piece_mine(n0));
     bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
+    int trace_i = 0;
+    const bool tracer = g.trace != nullptr && (wid == 0 || wid == NW / 2) && lane == 0;
+    auto stamp = [&](int k, bool core = false) {
+        if (tracer && trace_i < g.trace_tiles)
+            g.trace[(((size_t)blockIdx.x * 2 + (late ? 1 : 0)) * g.trace_tiles + trace_i) * 8 + k] =
+                core ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
+    };
     for (; t < ntiles; t += gridDim.x) {
+        stamp(0);
+        stamp(5, true);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -781,6 +793,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_BARRIER();
         if (late) PP_BARRIER();
+        stamp(1);
         const int nsd = (g.dbg & 2) ? 1 : ns;
         const bool half_tile = n0 + 128 >= g.N && !(g.dbg & 524288);
         if (half_tile) {
@@ -813,6 +826,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 PP_BARRIER();
             }
         }
+        stamp(2);
         if (!late) PP_BARRIER();
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
@@ -826,6 +840,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             pre1 = lean && ns > 1;
             if (pre1) stage_step(1, w_piece_mine(n0));
         }
+        stamp(3);
         if (lean) {
             lean_epilogue(cm0, cn0);
         } else if (half_tile) {
@@ -834,6 +849,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
             gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
         }
+        stamp(4);
+        stamp(6, true);
+        ++trace_i;
     }
 #undef PP_BARRIER
 }
@@ -1614,6 +1632,8 @@ int launch_tiled(const GemmArgs &g, hipStream_t s) {
 int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     GemmArgs g = g_in;
     g.dbg = g_gemm_debug;
+    g.trace = g_gemm_trace;
+    g.trace_tiles = g_gemm_trace_tiles;
     if (g.dbg & 4096) g.lda = 0;   // probe: every A row aliases row 0 (cache-resident operand)
     if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
     if (g.dbg & 131072) g.ldc = 0;  // probe: every output row aliases row 0 (stores stay in L2)
