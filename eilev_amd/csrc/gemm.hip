@@ -659,14 +659,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // ---- lean epilogue (interior tiles, bf16 output, no column tail / patch remap / column scaling) -------------------------
     // 4 KiB of LDS staging per wave OUTSIDE the two step buffers, so the next tile's first TWO K-steps are already in flight
     // while it runs (the general epilogue below stages 69.6 KB through step buffer 1 and leaves a DMA-latency bubble at the top
-    // of the next tile).  Units of 32 rows x 64 columns (one i block of the wave): bias / activation / residual / bf16 into the
-    // staging rows (16-byte chunk c of row r at chunk c ^ (r & 7)), read back as 128-byte row segments, buffer stores whose
-    // descriptor drops rows past M.
+    // of the next tile).  Units of 32 rows x 64 columns (one i block of the wave): activation / residual / bf16 into the staging
+    // rows (16-byte chunk c of row r at chunk c ^ (r & 7)), read back as 128-byte row segments, buffer stores whose descriptor
+    // drops rows past M.  Round 2 (tools/gemm_trace.py: 6.7 us of a 42 us bias-only tile, 8.5 us with GELU, all of it with the
+    // MFMA pipe idle and most of it instruction issue): the residual variant is a compile-time copy (no per-cell branches, the
+    // unit's 8 residual cells fetched from the staging rows in one batch, the next unit's rows in flight), and the GELU is the
+    // degree-8 form of common.h.  (Folding the bias into the first MFMAs' C operand — no accumulator initialisation, no bias
+    // arithmetic here — was built and makes hipcc spill 200-600 VGPRs in this 256-register kernel: not adopted.)
     char *const stg = smem + 2 * STEP + wid * 4096;
     const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
     const int srow = lane >> 3, schunk = lane & 7;
-    auto lean_epilogue = [&](int cm0, int cn0) {
-        constexpr int CPC = EPI == 1 ? 16 : 4, NCH = 4 * CPC + 8;
+    auto is_lean = [&](int n0_) {
+        return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
+               !(g.dbg & (1024 | 2048 | 1)) && !(g.dbg & 16777216);
+    };
+    auto lean_epilogue = [&](int cm0, int cn0, auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         const int r0 = cm0 + wm * WM;
         const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
@@ -677,10 +685,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             return __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
         };
         const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + wn * WN, rows * (int)(g.ldc * 2));
-        const bool has_res = g.resid != nullptr;
-        const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(has_res ? g.resid + (int64_t)r0 * g.ldr + cn0 + wn * WN : g.A, has_res ? rows * (int)(g.ldr * 2) : 0);
+        const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + cn0 + wn * WN : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
         const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
-        bf16x4 biasr[TN][4];
+        u32x4_t rv[4];
+        auto res_load = [&](int u) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (u * 32 + it * 8) * (int)(g.ldr * 2), 0);
+        };
+        if constexpr (RES) res_load(0);
+        bf16x4 biasr[TN][4];  // columns j*32 + q*8 + hi*4 + (0..3) of the wave's 64: the accumulator layout
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -688,74 +701,64 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 if (g.bias) biasr[j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + cn0 + wn * WN + j * 32 + q * 8 + hi * 4);
                 else biasr[j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             }
-        f32x2 ex[4], eu[4], et[4], ep[4];
-        bf16x8 erb[2];
-        auto chunk = [&](auto unit_c, auto ch_c) {
-            constexpr int U = decltype(unit_c)::value, CH = decltype(ch_c)::value;
-            constexpr float gc[13] = EILEV_GELU_COEFFS;
-            if constexpr (CH < 4 * CPC) {
-                constexpr int CP = CH / CPC, SUB = CH % CPC, J = CP >> 1, QP = CP & 1;
-                if constexpr (SUB < 2) {  // prepare half h = SUB: x = acc + bias (ReLU / GELU argument reduction)
-                    constexpr int h = SUB;
-                    const bf16x4 b4 = biasr[J][2 * QP + h];
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        f32x2 v = {acc[U][J][(2 * QP + h) * 4 + 2 * e2] + (float)b4[2 * e2], acc[U][J][(2 * QP + h) * 4 + 2 * e2 + 1] + (float)b4[2 * e2 + 1]};
-                        if (EPI == 2) v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
-                        if (EPI == 1) {
-                            eu[h * 2 + e2] = (f32x2){fminf(fabsf(v.x), 5.0f), fminf(fabsf(v.y), 5.0f)};
-                            et[h * 2 + e2] = eu[h * 2 + e2] * 0.4f + (-1.0f);
-                            ep[h * 2 + e2] = (f32x2){gc[12], gc[12]};
-                            v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
-                        }
-                        ex[h * 2 + e2] = v;
-                    }
-                }
-                if constexpr (EPI == 1 && SUB >= 2 && SUB < 14) {
-                    constexpr int kk = 13 - SUB;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) ep[n] = ep[n] * et[n] + gc[kk];
-                }
-                if constexpr (SUB >= CPC - 2) {  // finish half h: (GELU: relu(x) - u p(t),) + residual, bf16, one 8-byte cell
-                    constexpr int h = SUB - (CPC - 2);
-                    f32x2 y0 = ex[h * 2], y1 = ex[h * 2 + 1];
-                    if (EPI == 1) {
-                        y0 = y0 - eu[h * 2] * ep[h * 2];
-                        y1 = y1 - eu[h * 2 + 1] * ep[h * 2 + 1];
-                    }
-                    constexpr int c = J * 4 + 2 * QP + h;
-                    unsigned ca;
-                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(c << 4), "v"(stg_sw));
-                    if (has_res) {
-                        const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(smem + ca);
-                        y0 = y0 + (f32x2){(float)r4[0], (float)r4[1]};
-                        y1 = y1 + (f32x2){(float)r4[2], (float)r4[3]};
-                    }
-                    *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)y0.x, (bf16)y0.y, (bf16)y1.x, (bf16)y1.y};
-                }
-            } else {  // read-backs and stores in the order R0 R1 S0 S1 R2 R3 S2 S3 (two buffers)
-                constexpr int X = CH - 4 * CPC, IT = (X >> 2) * 2 + (X & 1);
-                if constexpr ((X & 2) == 0) {
-                    const int row = IT * 8 + srow;
-                    erb[IT & 1] = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4));
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[IT & 1]), rc, st_voff, (U * 32 + IT * 8) * (int)(g.ldc * 2), 0);
-                }
-            }
-        };
         static_for<TM>([&](auto u_c) {
             constexpr int U = decltype(u_c)::value;
-            if (has_res) {  // the unit's residual rows -> staging (coalesced), each lane then adds its cell in place
-                u32x4_t rv[4];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (U * 32 + it * 8) * (int)(g.ldr * 2), 0);
+            bf16x4 rcell[TN][4];
+            if constexpr (RES) {  // the unit's residual rows -> staging (coalesced); every lane then fetches its 8 cells in one batch
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + srow;
                     *reinterpret_cast<u32x4_t *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[it];
                 }
+                if constexpr (U + 1 < TM) res_load(U + 1);  // the next unit's rows arrive under this unit's arithmetic
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned ca;
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
+                        rcell[j][q] = *reinterpret_cast<const bf16x4 *>(smem + ca);
+                    }
             }
-            static_for<NCH>([&](auto c_c) { chunk(u_c, c_c); });
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[U][j][q * 4 + e] + (float)biasr[j][q][e];
+                    if constexpr (EPI == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                    if constexpr (EPI == 1) gelu_erf_n<4>(v);
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rcell[j][q][e];
+                    }
+                    unsigned ca;
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
+                    *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                }
+            __builtin_amdgcn_sched_barrier(0);  // cells of a unit first, then its read-backs and stores; nothing of the next unit in between
+            bf16x8 erb[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {  // read-backs and stores in the order R0 R1 S0 S1 R2 R3 S2 S3
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int row = (h2 * 2 + b) * 8 + srow;
+                    erb[b] = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff, (U * 32 + (h2 * 2 + b) * 8) * (int)(g.ldc * 2), 0);
+            }
+            // Measured on gfx950 (round 2): with the next unit's arithmetic scheduled between these stores, a VALU write to the data
+            // registers of a 128-bit buffer store issued the cycle before corrupted the first dword of the stored chunk (the "SGPR
+            // soffset needs no wait state" exception of the GFX9 hazard table does not hold here).  Keep the scheduler out, and two
+            // idle states between the last store and whatever reuses its registers.
+            asm volatile("s_nop 1" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
 #define PP_BARRIER()                       \
@@ -772,6 +775,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     stage_step(0, w_piece_mine(n0));
     bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
+    bool lean_cur = is_lean(n0);  // this tile runs the lean epilogue: its accumulators start from the bias
     int trace_i = 0;
     const bool tracer = g.trace != nullptr && (wid == 0 || wid == NW / 2) && lane == 0;
     auto stamp = [&](int k, bool core = false) {
@@ -796,53 +800,62 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         stamp(1);
         const int nsd = (g.dbg & 2) ? 1 : ns;
         const bool half_tile = n0 + 128 >= g.N && !(g.dbg & 524288);
-        if (half_tile) {
+        // one K-step = two half-steps; FIRST (compile-time) marks the tile's first K-step, whose first 16 MFMAs take C = bias / 0
+        auto kstep = [&](int st, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            read_half(st, 0);
+            if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half();
+            PP_BARRIER();
+            read_half(st, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half();
+            PP_BARRIER();
+        };
+        auto kstep_ht = [&](int st, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
             const bool w_mine = wid < NW / 2;
-            for (int st = 0; st < nsd; ++st) {
-                read_half_ht(st, 0);
-                if (st + 1 < ns && !(st == 0 && pre1)) stage_step(st + 1, w_mine);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                mma_half_ht();
-                PP_BARRIER();
-                read_half_ht(st, 1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                mma_half_ht();
-                PP_BARRIER();
-            }
+            read_half_ht(st, 0);
+            if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half_ht();
+            PP_BARRIER();
+            read_half_ht(st, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            mma_half_ht();
+            PP_BARRIER();
+        };
+        if (half_tile) {
+            kstep_ht(0, std::true_type{});
+            for (int st = 1; st < nsd; ++st) kstep_ht(st, std::false_type{});
         } else {
-            for (int st = 0; st < nsd; ++st) {
-                read_half(st, 0);
-                if (st + 1 < ns && !(st == 0 && pre1)) stage_step(st + 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                mma_half();
-                PP_BARRIER();
-                read_half(st, 1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                mma_half();
-                PP_BARRIER();
-            }
+            kstep(0, std::true_type{});
+            for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{});
         }
         stamp(2);
         if (!late) PP_BARRIER();
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
         const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
-        const bool lean = !half_tile && cn0 + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !(g.dbg & (1024 | 2048 | 1)) &&
-                          !(g.dbg & 16777216);
+        const bool lean = lean_cur;
         pre1 = false;
+        lean_cur = false;
         if (tn < ntiles) {
             set_tile(tn, m0, n0);
             stage_step(0, w_piece_mine(n0));
             pre1 = lean && ns > 1;
             if (pre1) stage_step(1, w_piece_mine(n0));
+            lean_cur = is_lean(n0);
         }
         stamp(3);
         if (lean) {
-            lean_epilogue(cm0, cn0);
+            if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{});
+            else lean_epilogue(cm0, cn0, std::false_type{});
         } else if (half_tile) {
             gemm_epilogue<64, 64, EPI>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
         } else {
@@ -901,7 +914,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 128, WM = 128, WN = 64, TM = 4, TN = 2, NF = TM + TN;
     constexpr int STEP = (BM + BN) * 128, NST = 3;
-    constexpr int CPC = EPI == 1 ? 16 : 4;  // epilogue chunks per cell pair: prepare x 2, (GELU: 12 Horner steps,) finish x 2
+    constexpr int CPC = EPI == 1 ? 4 + EILEV_GELU_DEG : 4;  // epilogue chunks per cell pair: prepare x 2, (GELU: one chunk per Horner step,) finish x 2
     constexpr int NCH = 4 * CPC + 8;        // chunks per 32-row unit: 4 cell pairs, 4 read-backs, 4 stores
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1020,7 +1033,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
     };
     auto epi_chunk = [&](auto unit_c, auto ch_c) {
         constexpr int U = decltype(unit_c)::value, CH = decltype(ch_c)::value;
-        constexpr float gc[13] = EILEV_GELU_COEFFS;
+        constexpr float gc[EILEV_GELU_DEG + 1] = EILEV_GELU_COEFFS;
         if constexpr (CH < 4 * CPC) {
             constexpr int CP = CH / CPC, SUB = CH % CPC, J = CP >> 1, QP = CP & 1;
             if constexpr (SUB < 2) {  // prepare half h = SUB (ReLU / GELU argument reduction)
@@ -1030,16 +1043,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
                     f32x2 v = {accp[U][J][(2 * QP + h) * 4 + 2 * e2], accp[U][J][(2 * QP + h) * 4 + 2 * e2 + 1]};
                     if (EPI == 2) v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
                     if (EPI == 1) {
-                        eu[h * 2 + e2] = (f32x2){fminf(fabsf(v.x), 5.0f), fminf(fabsf(v.y), 5.0f)};
-                        et[h * 2 + e2] = eu[h * 2 + e2] * 0.4f + (-1.0f);
-                        ep[h * 2 + e2] = (f32x2){gc[12], gc[12]};
+                        eu[h * 2 + e2] = (f32x2){fminf(fabsf(v.x), EILEV_GELU_UMAX), fminf(fabsf(v.y), EILEV_GELU_UMAX)};
+                        et[h * 2 + e2] = eu[h * 2 + e2] * (2.0f / EILEV_GELU_UMAX) + (-1.0f);
+                        ep[h * 2 + e2] = (f32x2){gc[EILEV_GELU_DEG], gc[EILEV_GELU_DEG]};
                         v = (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
                     }
                     ex[h * 2 + e2] = v;
                 }
             }
-            if constexpr (EPI == 1 && SUB >= 2 && SUB < 14) {
-                constexpr int kk = 13 - SUB;
+            if constexpr (EPI == 1 && SUB >= 2 && SUB < 2 + EILEV_GELU_DEG) {
+                constexpr int kk = EILEV_GELU_DEG + 1 - SUB;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) ep[n] = ep[n] * et[n] + gc[kk];
             }
@@ -1047,8 +1060,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w6_kernel(const GemmArgs g) {
                 constexpr int h = SUB - (CPC - 2);
                 f32x2 y0 = ex[h * 2], y1 = ex[h * 2 + 1];
                 if (EPI == 1) {
-                    y0 = y0 - eu[h * 2] * ep[h * 2];
-                    y1 = y1 - eu[h * 2 + 1] * ep[h * 2 + 1];
+                    y0 = y0 - ep[h * 2];
+                    y1 = y1 - ep[h * 2 + 1];
                 }
                 constexpr int c = J * 4 + 2 * QP + h;
                 unsigned ca;

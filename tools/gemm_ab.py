@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""GPU probe: A/B two builds of the library on the ViT GEMM shapes, interleaved in ONE process on ONE box (boxes differ by up
+to 8 % on identical kernels, so cross-call comparisons are useless).
+
+    python tools/gemm_ab.py <libA.so> <libB.so> [rows] [rounds]
+"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from eilev_amd import abi
+
+libs = [abi.bind(C.CDLL(os.path.abspath(p))) for p in sys.argv[1:3]]
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 139808
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 7
+P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+SHAPES = {"fc1": (6144, 1408, 1, False), "fc1_noact": (6144, 1408, 0, False), "fc2": (1408, 6144, 0, True), "qkv": (4224, 1408, 0, False),
+          "proj": (1408, 1408, 0, True)}
+for name, (n, k, epi, resid) in SHAPES.items():
+    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda").to(torch.bfloat16)
+    r = torch.randn(m, n, device="cuda").to(torch.bfloat16) if resid else None
+    outs = [torch.empty(m, n, device="cuda", dtype=torch.bfloat16) for _ in libs]
+    for lib, o in zip(libs, outs):
+        lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+    torch.cuda.synchronize()
+    d = (outs[0].float() - outs[1].float()).abs().max().item()
+    times = [[] for _ in libs]
+    for rd in range(rounds + 1):
+        for i, (lib, o) in enumerate(zip(libs, outs)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+            e1.record()
+            torch.cuda.synchronize()
+            if rd:
+                times[i].append(e0.elapsed_time(e1) / 5)
+    med = [statistics.median(t) for t in times]
+    tf = [2 * m * n * k / x / 1e9 for x in med]
+    print(f"{name:10s} M={m} A {med[0]*1e3:7.1f} us {tf[0]:7.1f} TF/s | B {med[1]*1e3:7.1f} us {tf[1]:7.1f} TF/s | B/A speed {tf[1]/tf[0]:.3f} | max |A-B| {d:.4g}", flush=True)
