@@ -162,22 +162,26 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     (b) one sample through the language model: the oracle prefills the SAME inputs_embeds (L = 960) and then decodes
         teacher-forced on the ids the HIP path generated (batch-32 prefill + hipGraph decode, as timed): last-row prefill
         logits, and per step the oracle's logit of the HIP token against the oracle's maximum.
-    The oracle runs with `emulate_bf16` (activations rounded to bf16 wherever the HIP path stores bf16, fp32 accumulation): through
-    39 + 12 + 32 blocks of random-init weights a pure-fp32 run is ~1.1e-2 relative RMS away from ANY bf16 implementation (measured:
-    profiles/parity_r02.json), so the fp32 distance says nothing about kernel correctness at this depth.  Bar: relative RMS <= 1e-2,
-    and a generated id may differ from the oracle's argmax only at a near-tie (margin <= 5 % of the logits' standard deviation)."""
+    Bar (the one of tests/test_hip_stages.py): the HIP result must be as close to the fp32 oracle as a bf16-storage run of the SAME
+    arithmetic is — distance <= 1.5 x (oracle with `emulate_bf16` vs oracle fp32) + 1e-3 in relative RMS.  Through 39 + 12 + 32
+    blocks of random-init weights that noise floor is ~1e-2 (it is printed next to the HIP distance), so a fixed 1e-2 would be
+    a coin flip.  A generated id may differ from the oracle's argmax only at a near-tie (margin <= 5 % of the logits' standard
+    deviation)."""
     from oracle.runner import OracleModel
 
     t0 = time.perf_counter()
     host = lambda t: t.detach().float().cpu().numpy()
-    ora = OracleModel(cfg, weights, emulate_bf16=True)  # rounds activations to bf16 where the HIP path stores bf16 (fp32 accumulation)
+    ora = OracleModel(cfg, weights)                       # fp32 truth
+    ora16 = OracleModel(cfg, weights, emulate_bf16=True)  # the same arithmetic with activations rounded to bf16 where HIP stores bf16
     chunk = px[: max(1, 1088 // FRAMES)]
     feats = eng.encode_clips(chunk)                                   # bench-shaped launch (M = 1088 x 257 rows in the ViT)
     nq = cfg.num_query_tokens
-    ref_q = ora.project(ora.qformer(ora.vit(host(px[:1]))))           # clip 0 on the CPU: 8 frames x 39 blocks + Q-Former
+    px0 = host(px[:1])
+    ref_q = ora.project(ora.qformer(ora.vit(px0)))                    # clip 0 on the CPU: 8 frames x 39 blocks + Q-Former
+    ref_q16 = ora16.project(ora16.qformer(ora16.vit(px0)))
     got_q = host(feats[:nq])
     rr = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30))
-    q_rel = rr(got_q, ref_q)
+    q_rel, q_noise = rr(got_q, ref_q), rr(ref_q16, ref_q)
     n_clips = ids.shape[0] * (N_CTX + 1)
     all_feats = torch.cat([eng.encode_clips(px[i:i + chunk.shape[0]]) for i in range(0, n_clips, chunk.shape[0])])
     emb = eng.embed_scatter(ids, vm, all_feats)
@@ -188,7 +192,8 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     hip_ids = out_ids[0].cpu().numpy()
     emb0, am0 = host(emb[:1]), np.ones((1, L), np.int32)
     ref_last, _, kv = ora.prefill(emb0, am0, kv_capacity=L + new_tokens, all_logits=False)
-    p_rel = rr(host(last[:1]), ref_last)
+    ref_last16, _, _ = ora16.prefill(emb0, am0, kv_capacity=L, all_logits=False)
+    p_rel, p_noise = rr(host(last[:1]), ref_last), rr(ref_last16, ref_last)
     d = ora.dims
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     state = np.array([1, 1], np.int32); fin = np.zeros(1, np.uint8); tok = np.zeros(1, np.int64)
@@ -207,10 +212,12 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
                                            P(lg), P(fin), -1, 1, P(scratch), new_tokens, P(ws), nb, None)
         assert rc == 0, rc
         logits = lg
-    ok = bool(q_rel <= 1e-2 and p_rel <= 1e-2 and max(margins) <= 0.05)
-    return ok, {"query_tokens_rel_rms": round(q_rel, 5), "prefill_logits_rel_rms": round(p_rel, 5), "ids_equal_oracle_argmax": f"{exact}/{new_tokens}",
+    ok = bool(q_rel <= 1.5 * q_noise + 1e-3 and p_rel <= 1.5 * p_noise + 1e-3 and max(margins) <= 0.05)
+    return ok, {"query_tokens_rel_rms_vs_fp32": round(q_rel, 5), "bf16_storage_noise_query_tokens": round(q_noise, 5),
+                "prefill_logits_rel_rms_vs_fp32": round(p_rel, 5), "bf16_storage_noise_prefill_logits": round(p_noise, 5),
+                "ids_equal_oracle_argmax": f"{exact}/{new_tokens}",
                 "max_margin_over_logit_std": round(max(margins), 5), "seconds": round(time.perf_counter() - t0, 1),
-                "what": "oracle/libeilev_ref.so (bf16-storage emulation, fp32 accumulate) on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
+                "what": "oracle/libeilev_ref.so fp32 (and its bf16-storage emulation as the noise floor) on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
                         "sample 0 inputs_embeds -> prefill last-row logits + teacher-forced decode on the HIP ids (batch-32 prefill, hipGraph decode)"}
 
 

@@ -9,6 +9,9 @@
 int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s);
 int launch_pad_rows(const bf16 *w, bf16 *out, int rows, int k, int kp, hipStream_t s);
 int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_total, int tok, int d, hipStream_t s);
+int launch_patch_embed_ln(const void *pix, int pix_dtype, const bf16 *wpad, const bf16 *bias, const bf16 *pos, const bf16 *cls,
+                          const bf16 *gamma, const bf16 *beta, bf16 *x, bf16 *ln, int64_t frames_total, int frames_per_clip, int img,
+                          int patch, int D, int KP, float eps, hipStream_t s);
 int launch_broadcast_rows(const bf16 *src, bf16 *dst, int64_t copies, int64_t n, hipStream_t s);
 int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *mask, const bf16 *feats, int64_t n_rows,
                          int64_t total, int vocab, bf16 *out, int d, hipStream_t s);
@@ -91,6 +94,9 @@ extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms,
 }
 
 extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
+// probe / test switch: 1 = take the unfused patch path (im2col -> GEMM -> CLS rows -> LayerNorm) even where the fused kernel applies
+static int g_no_fused_patch = 0;
+extern "C" int eilev_debug_no_fused_patch(int on) { g_no_fused_patch = on; return 0; }
 extern "C" const char *eilev_backend(void) { return "hip-gfx950"; }
 
 namespace {
@@ -238,22 +244,36 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     bf16 *wpad = cv.take<bf16>((size_t)D * KP);
     if (!cv.ok()) return EILEV_E_WORKSPACE;
 
-    // patch embedding (+ bias + position, CLS rows): hf modeling_blip_2.py:243-255
-    RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
+    // patch embedding (+ bias + position, CLS rows) fused with layer_norm1 of block 0: hf modeling_blip_2.py:243-255, :390.
+    // One kernel (patch.hip); shapes it does not take fall back to im2col -> GEMM -> CLS rows (+ the separate LayerNorm below).
     RC(launch_pad_rows((const bf16 *)w->patch_w, wpad, D, PK, KP, s));
+    bool ln0_done = false;
     {
-        GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
-        g.patch_group = (int)G2;
-        RC(launch_gemm(g, 5, s));
+        const EilevVitLayer *L0 = d->v_layers > 0 ? &w->layers[0] : nullptr;
+        const int rc_ = g_no_fused_patch ? EILEV_E_UNSUPPORTED
+                                         : launch_patch_embed_ln(pixels, pixels_dtype, wpad, (const bf16 *)w->patch_b, (const bf16 *)w->pos,
+                                                                 (const bf16 *)w->cls, L0 ? (const bf16 *)L0->ln1_w : nullptr,
+                                                                 L0 ? (const bf16 *)L0->ln1_b : nullptr, x, L0 ? ln : nullptr, F, (int)frames,
+                                                                 d->image_size, d->patch_size, D, KP, d->v_eps, s);
+        if (rc_ == EILEV_OK) {
+            ln0_done = L0 != nullptr;
+        } else if (rc_ == EILEV_E_UNSUPPORTED) {
+            RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
+            GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
+            g.patch_group = (int)G2;
+            RC(launch_gemm(g, 5, s));
+            RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
+        } else {
+            return rc_;
+        }
     }
-    RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
     const size_t hs_bytes = (size_t)M * D * sizeof(bf16);
     if (hidden_states) RC((int)hipMemcpyAsync(hidden_states, x, hs_bytes, hipMemcpyDeviceToDevice, s));
 
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < d->v_layers; ++l) {
         const EilevVitLayer *L = &w->layers[l];
-        RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
+        if (!(l == 0 && ln0_done)) RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
         RC(launch_gemm(mk_gemm(ln, D, L->qkv_w, D, L->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0), 3, s));
         if (attentions) {
             bf16 *pr = (bf16 *)attentions + (size_t)l * F * H * tok * tok;
