@@ -270,8 +270,9 @@ def main():
                     help="opt27 = the headline configs[1]/[2]; informational: t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), "
                          "opt67 = the OPT-6.7B backbone of configs[4] in bf16 (use --shots 32 for its 32-shot sequence)")
     ap.add_argument("--shots", type=int, default=16, help="in-context examples per sample (16 = the headline workload)")
-    ap.add_argument("--lm-weights", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8: e4m3 weights for the OPT linears (informational line for configs[4]; the headline metric is bf16)")
+    ap.add_argument("--lm-weights", choices=["bf16", "fp8", "fp8_mfma"], default="bf16",
+                    help="fp8: e4m3 weights for the OPT linears, bf16 activations; fp8_mfma: e4m3 weights AND per-token e4m3 activations "
+                         "on the fp8 MFMA in prefill (informational lines for configs[4]; the headline metric is bf16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -407,10 +408,11 @@ def main():
                       {"t5xl": "eilev-blip2-flan-t5-xl", "opt27": "eilev-blip2-opt-2.7b", "opt67": "blip2-opt-6.7b backbone (bf16)"}[args.lm],
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.lm_weights == "bf16" else "bf16 activations, fp8 (e4m3) OPT weights", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp8": "bf16 activations, fp8 (e4m3) OPT weights",
+                                          "fp8_mfma": "ViT / Q-Former bf16; OPT prefill linears fp8 e4m3 x e4m3 on the fp8 MFMA (fp32 accumulate), OPT decode bf16 x fp8 weights"}[args.lm_weights], "data": "synthetic",
             "config": {"workload": (f"configs[3]: eilev-blip2-flan-t5-xl (random-init), {S} samples/GPU/step x 17 clips x 8 frames "
                                     f"224x224, encoder L=960, 32 greedy decoder tokens (EOS off)") if is_t5 else
-                                   (f"{'configs[1]: eilev-blip2-opt-2.7b' if args.lm == 'opt27' else ('configs[4] backbone blip2-opt-6.7b in bf16' if args.lm_weights == 'bf16' else 'configs[4] blip2-opt-6.7b, fp8 OPT weights')} (random-init), "
+                                   (f"{'configs[1]: eilev-blip2-opt-2.7b' if args.lm == 'opt27' else ('configs[4] backbone blip2-opt-6.7b in bf16' if args.lm_weights == 'bf16' else ('configs[4] blip2-opt-6.7b, fp8 OPT weights' if args.lm_weights == 'fp8' else 'configs[4] blip2-opt-6.7b, fp8 MFMA (e4m3 weights + activations in prefill)'))} (random-init), "
                                     f"{S} samples/GPU/step x {N_CTX + 1} clips x 8 frames "
                                     f"224x224, L={seq_len} prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
                                     f"{('RCCL all-to-all of the clip tokens (' + exch.transport + ')') if world > 1 else 'no collective at N=1'}"),

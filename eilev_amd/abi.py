@@ -62,7 +62,8 @@ class OptLayerW8(C.Structure):
 
 class OptWeights(C.Structure):
     _fields_ = [("embed_tokens", vp), ("embed_positions", vp), ("final_ln_w", vp), ("final_ln_b", vp),
-                ("layers", C.POINTER(OptLayer)), ("layers_w8", C.POINTER(OptLayerW8)), ("w8_expand", vp), ("w8_expand_bytes", C.c_size_t)]
+                ("layers", C.POINTER(OptLayer)), ("layers_w8", C.POINTER(OptLayerW8)), ("w8_expand", vp), ("w8_expand_bytes", C.c_size_t),
+                ("w8_act_fp8", C.c_int32)]
 
 
 class T5Dims(C.Structure):
@@ -245,7 +246,7 @@ EXPORTS = [
     "eilev_opt_decode_step", "eilev_linear", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
-    "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
+    "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_quant_rows_e4m3", "eilev_linear_a8w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
     "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
     "eilev_attention_dropout_bwd", "eilev_comm_bind", "eilev_comm_unique_id", "eilev_comm_init", "eilev_comm_destroy",
@@ -253,7 +254,7 @@ EXPORTS = [
 ]
 
 
-def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int):
+def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int, act_fp8: bool = False):
     """Point ``pack.opt`` at fp8 (e4m3) linears: per_layer = [{"qkv": (bytes_ptr, scale_ptr), "o": ..., "fc1": ..., "fc2": ...}, ...]."""
     arr = (OptLayerW8 * len(per_layer))()
     for i, d in enumerate(per_layer):
@@ -264,6 +265,7 @@ def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int):
     pack.opt.layers_w8 = C.cast(arr, C.POINTER(OptLayerW8))
     pack.opt.w8_expand = expand_ptr
     pack.opt.w8_expand_bytes = expand_bytes
+    pack.opt.w8_act_fp8 = 1 if act_fp8 else 0
 
 
 def bind(lib: C.CDLL) -> C.CDLL:
@@ -287,6 +289,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_linear_w8_scratch_bytes.argtypes = [i64, i64, i64]
     lib.eilev_linear_w8.restype = i32
     lib.eilev_linear_w8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
+    lib.eilev_quant_rows_e4m3.restype = i32
+    lib.eilev_quant_rows_e4m3.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.eilev_linear_a8w8.restype = i32
+    lib.eilev_linear_a8w8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.eilev_process_workspace_bytes.restype = sz
     lib.eilev_process_workspace_bytes.argtypes = [i64, i64, i64, i64]
     lib.eilev_process_frames.restype = i32
@@ -379,7 +385,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 7:
+    if lib.eilev_abi_version() != 8:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

@@ -55,6 +55,18 @@ CONFIGS = {
                          word_embed_proj_dim=2560),
         num_query_tokens=32,
     ),
+    # `mid` with a text model whose K dimensions are multiples of 128 (hidden 256 = 2 heads x 128, ffn 512): the smallest
+    # configuration that takes the fp8-MFMA prefill path (eilev_linear_a8w8 needs k % 128 == 0)
+    "mid_k128": dict(
+        vision_config=dict(hidden_size=176, intermediate_size=352, num_hidden_layers=2,
+                           num_attention_heads=2, patch_size=14, image_size=56),
+        qformer_config=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=256, encoder_hidden_size=176),
+        text_config=dict(model_type="opt", hidden_size=256, num_hidden_layers=2, ffn_dim=512,
+                         num_attention_heads=2, vocab_size=512, max_position_embeddings=128,
+                         word_embed_proj_dim=256),
+        num_query_tokens=8,
+    ),
     "opt67": dict(  # blip2-opt-6.7b backbone (BASELINE configs[4]): hidden 4096, 32 heads x 128, ffn 16384
         vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
                            num_attention_heads=16, patch_size=14, image_size=224),

@@ -147,6 +147,10 @@ struct GemmArgs {
     const float *wscale = nullptr;  // [N] or null
     const uint8_t *W8 = nullptr;    // [N, K] e4m3 bytes (ldw = K) when the weights are still quantised (skinny kernel)
     bf16 *w8_scratch = nullptr;     // [N, K] bf16: where a large-M call expands W8 to (exact: every e4m3 value is a bf16 value)
+    // fp8 (e4m3) ACTIVATIONS with one fp32 scale per row (eilev_linear_a8w8): together with W8 the product runs on the fp8 MFMA
+    // (v_mfma_f32_32x32x64_f8f6f4, twice the bf16 rate): C = (Aq . Wq^T) * ascale[m] * wscale[n] + bias.  lda / ldw count BYTES = k.
+    const uint8_t *A8 = nullptr;    // [M, K] e4m3 bytes
+    const float *ascale = nullptr;  // [M]
     int k_slice = 0;                // > 0: split-K launch (gridDim.y slices of k_slice K-steps, f32 output accumulated atomically)
     // probe-only (tools/gemm_trace.py): per-tile phase timestamps of the persistent ping-pong kernel, 8 u64 per (workgroup, wave
     // group, tile): s_memrealtime at loop top / K-loop start / K-loop end / epilogue start / epilogue end, s_memtime at top / end

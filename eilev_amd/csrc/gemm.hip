@@ -94,6 +94,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float v = acc[i][j][q * 4 + e];
+                            if (g.ascale) v *= g.ascale[row];
                             if (g.wscale && col + e < g.N) v *= g.wscale[col + e];
                             if (g.bias) v += (float)g.bias[col + e];
                             if (col + e < g.scale_cols) v *= g.scale;
@@ -181,6 +182,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
                     const float ws = col + e < g.N ? g.wscale[col + e] : 1.0f;
 #pragma unroll
                     for (int i = 0; i < NI; ++i) acc[IBEG + i][j][q * 4 + e] *= ws;
+                }
+            }
+            if (g.ascale) {  // fp8 activations: per-row (token) scale
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = wrow0 + (IBEG + i) * 32 + l31;
+                    const float as = row < g.M ? g.ascale[row] : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[IBEG + i][j][q * 4 + e] *= as;
                 }
             }
 #pragma unroll
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
 // half K-steps as 16 rows x 64 B lands only 56-64 B/ns per CU, as long as the 16 MFMAs it should hide under; 128-byte rows
 // land 97-146 B/ns: tools/probes/lds_dma_rate.hip.)  Two 64-KiB step buffers; step s + 1 is issued in the read phase of
 // half 2s and waited for in the read phase of half 2s + 1.
-template <int EPI>
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
@@ -612,15 +622,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             }
         }
     };
+    // F8: the operands are e4m3 BYTES (the kernel is launched with K = bytes / 2 so every address below is unchanged): the 64 bytes a
+    // lane group holds for a half K-step (its two 16-byte chunks of every row) are ONE 32x32x64 fp8 MFMA — twice the flops of the two
+    // bf16 MFMAs they would be.  Which k a byte position stands for is irrelevant as long as A and W use the same assignment (they
+    // do: same chunk indices), the products are summed over all 64.
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+    struct Pair16 { bf16x8 lo, hi; };
+    auto cat32 = [](const bf16x8 &lo, const bf16x8 &hi2) { return __builtin_bit_cast(i32x8_t, Pair16{lo, hi2}); };
     auto mma_half = [&]() {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat32(bfr[0][j], bfr[1][j]), cat32(af[0][i], af[1][i]), acc[i][j],
+                                                                               0, 0, 0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // Half-empty last column tile (N % 256 <= 128, e.g. N = 1408 = 5.5 x 256): only columns [0, 128) of the tile exist.
@@ -647,13 +673,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     };
     auto mma_half_ht = [&]() {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat32(bfr[0][j], bfr[1][j]), cat32(af[0][i], af[1][i]), acc[i][j],
+                                                                               0, 0, 0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // ---- lean epilogue (interior tiles, bf16 output, no column tail / patch remap / column scaling) -------------------------
@@ -670,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
     const int srow = lane >> 3, schunk = lane & 7;
     auto is_lean = [&](int n0_) {
-        return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale &&
+        return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale &&
                !(g.dbg & (1024 | 2048 | 1)) && !(g.dbg & 16777216);
     };
     auto lean_epilogue = [&](int cm0, int cn0, auto res_c) {
@@ -885,6 +920,23 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    if (g.A8) {  // fp8 x fp8 on the fp8 MFMA: byte operands, K halved so that the kernel's 2-byte strides are byte strides
+        static bool attr8 = false;
+        if (!attr8) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr8 = true;
+        }
+        if (g.epi == 1) return EILEV_E_UNSUPPORTED;
+        GemmArgs h = g;
+        h.A = reinterpret_cast<const bf16 *>(g.A8);
+        h.W = reinterpret_cast<const bf16 *>(g.W8);
+        h.K = g.K / 2; h.lda = g.lda / 2; h.ldw = g.ldw / 2;
+        if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, true>), dim3(grid), dim3(512), smem, s, h);
+        else hipLaunchKernelGGL((gemm_pp4_kernel<0, true>), dim3(grid), dim3(512), smem, s, h);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);
     else hipLaunchKernelGGL(gemm_pp4_kernel<0>, dim3(grid), dim3(512), smem, s, g);
@@ -1651,6 +1703,19 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
     if (g.dbg & 131072) g.ldc = 0;  // probe: every output row aliases row 0 (stores stay in L2)
     if (g.M <= 0) return EILEV_OK;
+    if (g.A8) {
+        // fp8 activations x fp8 weights (eilev_linear_a8w8): the persistent ping-pong kernel on the fp8 MFMA, general epilogue
+        // with the row and column scales
+        if (!g.W8 || !g.C || !g.wscale || !g.ascale || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
+        if ((g.K % 128) || g.lda != g.K || g.ldw != g.K || ((uintptr_t)g.A8 & 15) || ((uintptr_t)g.W8 & 15) || g.patch_group != 0 ||
+            (int64_t)g.M * g.K >= 0x7fff0000ll || (int64_t)g.N * g.K >= 0x7fff0000ll)
+            return EILEV_E_UNSUPPORTED;
+        if (!g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))))) return EILEV_E_UNSUPPORTED;
+        if (prof_kind >= 0) prof_begin(prof_kind, 2.0 * g.M * (double)g.N * g.K, s);
+        const int rc8 = launch_pp4(g, s);
+        if (prof_kind >= 0) prof_end(s);
+        return rc8;
+    }
     if (g.W8) {
         // fp8 weights.  M <= 32 (decode): streamed as bytes by the fp8 skinny kernel.  Larger M (prefill): expanded to bf16 in the
         // caller's scratch (exact), then the bf16 kernels with the per-channel scale in their epilogue.

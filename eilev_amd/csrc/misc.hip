@@ -783,3 +783,49 @@ extern "C" int eilev_process_frames(const uint8_t *video, int64_t batch, int64_t
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+
+
+// ---- per-row (per-token) dynamic quantisation of activations to OCP e4m3 (eilev_quant_rows_e4m3, include/eilev.h) -----------------
+// scale[r] = absmax / 448 (1 for an all-zero row), q = e4m3_rne(clamp(x * (448 / absmax), +-448)).  One wave per row, two passes
+// (the second read of the row hits L2); 16-byte loads, 8-byte stores.  HBM-bound: 2 bytes in, 1 byte out per element.
+namespace {
+__global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16 *__restrict__ x, int64_t ldx, uint8_t *__restrict__ q, float *__restrict__ scale,
+                                                              int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16 *xr = x + row * ldx;
+    const int nch = cols >> 3;
+    float amax = 0.0f;
+    for (int c = lane; c < nch; c += 64) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8 *>(xr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)t[e]));
+    }
+    amax = wave_max(amax);
+    const float inv = amax > 0.0f ? 448.0f / amax : 0.0f;
+    if (lane == 0) scale[row] = amax > 0.0f ? amax / 448.0f : 1.0f;
+    uint8_t *qr = q + row * (int64_t)cols;
+    for (int c = lane; c < nch; c += 64) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8 *>(xr + c * 8);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fminf(fmaxf((float)t[e] * inv, -448.0f), 448.0f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
+        *reinterpret_cast<int2 *>(qr + c * 8) = make_int2(lo, hi);
+    }
+}
+}  // namespace
+
+int launch_quant_rows_e4m3(const bf16 *x, int64_t ldx, uint8_t *q, float *scale, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return EILEV_OK;
+    if (!x || !q || !scale) return EILEV_E_BADARG;
+    if ((cols & 7) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return EILEV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, q, scale, rows, cols);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

@@ -9,6 +9,7 @@
 int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frames, int img, int patch, int kp, hipStream_t s);
 int launch_pad_rows(const bf16 *w, bf16 *out, int rows, int k, int kp, hipStream_t s);
 int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_total, int tok, int d, hipStream_t s);
+int launch_quant_rows_e4m3(const bf16 *x, int64_t ldx, uint8_t *q, float *scale, int64_t rows, int cols, hipStream_t s);
 int launch_patch_embed_ln(const void *pix, int pix_dtype, const bf16 *wpad, const bf16 *bias, const bf16 *pos, const bf16 *cls,
                           const bf16 *gamma, const bf16 *beta, bf16 *x, bf16 *ln, int64_t frames_total, int frames_per_clip, int img,
                           int patch, int D, int KP, float eps, hipStream_t s);
@@ -421,6 +422,7 @@ extern "C" size_t eilev_opt_workspace_bytes(const EilevDims *d, int64_t batch, i
     b += align_up((size_t)M * d->t_ffn * 2, 256);               // ffn
     b += align_up((size_t)M * 4, 256);                          // position ids
     b += kSkinnyScratch;
+    b += align_up((size_t)M * (d->t_ffn > d->t_hidden ? d->t_ffn : d->t_hidden), 256) + align_up((size_t)M * 4, 256);  // fp8 activations + row scales
     return b + 256;
 }
 
@@ -434,6 +436,8 @@ struct OptBufs {
     bf16 *h, *x, *att, *qkv, *ffn;
     int32_t *pid;
     float *scratch;
+    uint8_t *a8;      // fp8 (e4m3) copy of the current linear's input rows (EilevOptWeights.w8_act_fp8)
+    float *a8_scale;  // one scale per row
 };
 
 bool carve_opt(const EilevDims *d, int64_t M, void *ws, size_t bytes, OptBufs &b) {
@@ -445,12 +449,25 @@ bool carve_opt(const EilevDims *d, int64_t M, void *ws, size_t bytes, OptBufs &b
     b.ffn = cv.take<bf16>((size_t)M * d->t_ffn);
     b.pid = cv.take<int32_t>((size_t)M);
     b.scratch = cv.take<float>(kSkinnyScratch / sizeof(float));
+    b.a8 = cv.take<uint8_t>((size_t)M * (d->t_ffn > d->t_hidden ? d->t_ffn : d->t_hidden));
+    b.a8_scale = cv.take<float>((size_t)M);
     return cv.ok();
 }
 
 // fp8 form of a linear (EilevOptLayerW8): bytes + per-channel scales; large-M calls expand into w->w8_expand
-int use_w8(GemmArgs &g, const EilevOptWeights *w, const uint8_t *w8, const float *sc) {
+int use_w8(GemmArgs &g, const EilevOptWeights *w, const uint8_t *w8, const float *sc, const OptBufs &b, hipStream_t s) {
     if (!w8 || !sc) return EILEV_E_BADARG;
+    if (w->w8_act_fp8 && g.M > 32 && g.K % 128 == 0 && (int64_t)g.M * g.K < 0x7fff0000ll && (int64_t)g.N * g.K < 0x7fff0000ll) {
+        // configs[4] "fp8 MFMA": quantise this linear's input rows per token and run the product on the fp8 MFMA
+        RC(launch_quant_rows_e4m3(g.A, g.lda, b.a8, b.a8_scale, g.M, g.K, s));
+        g.A8 = b.a8;
+        g.ascale = b.a8_scale;
+        g.lda = g.K;
+        g.W8 = w8;
+        g.wscale = sc;
+        g.ldw = g.K;
+        return EILEV_OK;
+    }
     if (g.M > 32 || g.K % 256 != 0) {
         if (!w->w8_expand || w->w8_expand_bytes < (size_t)g.N * g.K * sizeof(bf16)) return EILEV_E_WORKSPACE;
         g.w8_scratch = (bf16 *)w->w8_expand;
@@ -472,7 +489,7 @@ int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &
         if (!bias_fused && (L->q_b || L->k_b || L->v_b)) return EILEV_E_UNSUPPORTED;  // fp8 q|k|v is one matrix: one bias vector
         GemmArgs g = mk_gemm(b.x, D, nullptr, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
         g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
-        RC(use_w8(g, w, w->layers_w8[l].qkv_w8, w->layers_w8[l].qkv_scale));
+        RC(use_w8(g, w, w->layers_w8[l].qkv_w8, w->layers_w8[l].qkv_scale, b, s));
         return launch_gemm(g, 5, s);
     }
     const bool fused = (const bf16 *)L->k_w == qw + (size_t)D * D && (const bf16 *)L->v_w == qw + 2 * (size_t)D * D && bias_fused;
@@ -499,16 +516,16 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     const int D = d->t_hidden, Ft = d->t_ffn;
     GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
-    if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale));
+    if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale, b, s));
     RC(launch_gemm(g, 5, s));
     RC(launch_layernorm(b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, b.x, D, M, D, d->t_eps, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
-    if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale));
+    if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale, b, s));
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
-    if (Q) RC(use_w8(g, w, Q->fc2_w8, Q->fc2_scale));
+    if (Q) RC(use_w8(g, w, Q->fc2_w8, Q->fc2_scale, b, s));
     return launch_gemm(g, 5, s);
 }
 
@@ -675,6 +692,21 @@ extern "C" int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_
         g.scratch = (float *)scratch;
         g.scratch_bytes = scratch_bytes;
     }
+    return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
+extern "C" int eilev_quant_rows_e4m3(const void *x, uint8_t *q, float *scale, int64_t rows, int64_t cols, void *stream) {
+    if (!x || !q || !scale || rows < 0 || cols <= 0 || cols > 0x7fffffff) return EILEV_E_BADARG;
+    return launch_quant_rows_e4m3((const bf16 *)x, cols, q, scale, rows, (int)cols, (hipStream_t)stream);
+}
+
+extern "C" int eilev_linear_a8w8(const uint8_t *a8, const float *a_scale, const uint8_t *w8, const float *w_scale, const void *bias,
+                                 const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
+    if (!a8 || !a_scale || !w8 || !w_scale || !c || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;
+    if (epilogue != 0 && epilogue != 2) return EILEV_E_UNSUPPORTED;
+    GemmArgs g = mk_gemm(nullptr, k, nullptr, k, bias, (const bf16 *)residual, n, c, n, m, (int)n, (int)k, epilogue);
+    g.out_f32 = out_f32;
+    g.A8 = a8; g.ascale = a_scale; g.W8 = w8; g.wscale = w_scale;
     return launch_gemm(g, 5, (hipStream_t)stream);
 }
 

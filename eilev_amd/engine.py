@@ -39,14 +39,15 @@ class HipEngine:
         self._decode_warm = False
         self._dec_cache = None  # most recent captured decode step + the buffers it is bound to
         self.parts = tuple(parts)
-        if lm_weights not in ("bf16", "fp8"):
-            raise ValueError("lm_weights must be 'bf16' or 'fp8'")
-        if lm_weights == "fp8" and (self.is_t5 or "opt" not in self.parts):
+        if lm_weights not in ("bf16", "fp8", "fp8_mfma"):
+            raise ValueError("lm_weights must be 'bf16', 'fp8' (e4m3 weights, bf16 activations) or 'fp8_mfma' (e4m3 weights AND per-token "
+                             "e4m3 activations on the fp8 MFMA for prefill)")
+        if lm_weights != "bf16" and (self.is_t5 or "opt" not in self.parts):
             raise NotImplementedError("fp8 weights are built for the OPT language model")
         self.lm_weights = lm_weights
         self._load(named_tensors)
-        if lm_weights == "fp8":
-            self._quantize_opt()
+        if lm_weights != "bf16":
+            self._quantize_opt(act_fp8=lm_weights == "fp8_mfma")
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
     # ---- weights ------------------------------------------------------------------------------------
@@ -109,7 +110,7 @@ class HipEngine:
         self.pack = abi.WeightPack(d, addr_t5 if t5d is not None else addr, t5d)
         self._keep = store
 
-    def _quantize_opt(self):
+    def _quantize_opt(self, act_fp8: bool = False):
         """fp8 (e4m3) weights for the OPT linears (BASELINE configs[4]): per output channel absmax / 448 scales
         (eilev_amd/quant.py); q|k|v as one [3 D, D] matrix.  Embeddings / lm_head, LayerNorms and biases stay bf16."""
         from .quant import quantize_e4m3_per_channel
@@ -130,7 +131,7 @@ class HipEngine:
         nb = max(d.t_ffn, 3 * d.t_hidden) * d.t_hidden * 2
         expand = torch.empty(nb, dtype=torch.uint8, device=self.device)
         self._w8_keep = (keep, expand)
-        abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb)
+        abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb, act_fp8=act_fp8)
 
     # ---- workspaces ----------------------------------------------------------------------------------
     def _workspace(self, tag, nbytes):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 7
+#define EILEV_ABI_VERSION 8
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -124,6 +124,10 @@ typedef struct EilevOptWeights {
     const EilevOptLayerW8 *layers_w8;
     void *w8_expand;
     size_t w8_expand_bytes;
+    /* ABI version 8.  Non-zero with layers_w8: prefill / extend (more than 32 rows) quantise the INPUT of each of the four linears
+     * per token to e4m3 (eilev_quant_rows_e4m3) and run the products on the fp8 MFMA (eilev_linear_a8w8) instead of expanding the
+     * weights to bf16 — BASELINE configs[4] "fp8 MFMA".  Decode steps keep bf16 activations (weight-streaming, HBM-bound). */
+    int32_t w8_act_fp8;
 } EilevOptWeights;
 
 int eilev_abi_version(void);
@@ -212,6 +216,17 @@ int eilev_exchange_clip_tokens(void *comm, const void *send, const int64_t *send
 size_t eilev_linear_w8_scratch_bytes(int64_t m, int64_t n, int64_t k);
 int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_scale, const void *bias, const void *residual, void *c, int64_t m,
                     int64_t n, int64_t k, int epilogue, int out_f32, void *scratch, size_t scratch_bytes, void *stream);
+
+/* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
+ * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.
+ * eilev_quant_rows_e4m3: dynamic per-row (per-token) quantisation of x (rows, cols) [bf16 / oracle f32]:
+ *     amax = max_c |x[r, c]|;  scale[r] = amax / 448 (1 if amax = 0);  q[r, c] = e4m3_rne(clamp(x[r, c] * (448 / amax), +-448))
+ *   (fp32 arithmetic: one division for 448 / amax, one multiplication per element, round-to-nearest-even to OCP e4m3).
+ * eilev_linear_a8w8: C[m, n] = epilogue((sum_k dq(a8[m, k]) * dq(w8[n, k])) * a_scale[m] * w_scale[n] + bias[n]) (+ residual);
+ *   every product of two e4m3 values is exact in fp32, sums accumulate in fp32.  epilogue 0 none, 2 ReLU.  k % 128 == 0. */
+int eilev_quant_rows_e4m3(const void *x, uint8_t *q, float *scale, int64_t rows, int64_t cols, void *stream);
+int eilev_linear_a8w8(const uint8_t *a8, const float *a_scale, const uint8_t *w8, const float *w_scale, const void *bias,
+                      const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream);
 
 /* ---- stage 0: frames -> pixel_values (device-side process()) -------------------------------------------
  * Replaces the image half of process() (ref:eilev/model/utils.py:5-26: frames flattened into the HF image batch,
