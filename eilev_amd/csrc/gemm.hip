@@ -19,6 +19,7 @@
 
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
+int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
 unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
 int g_gemm_trace_tiles = 0;
 extern "C" int eilev_debug_gemm_trace(void *buf, int tiles) { g_gemm_trace = (unsigned long long *)buf; g_gemm_trace_tiles = tiles; return 0; }
@@ -1495,6 +1496,119 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
 // 4 KiB (half the bytes of the bound stream).  Piece i = rows 4i .. 4i+3 x 256 B; 16-byte chunk c of row r is stored at chunk
 // c ^ (r & 15).  A lane's 8 weights of an MFMA k-step are 8 bytes: v_cvt_pk_f32_fp8 + one v_perm_b32 per pair make the bf16
 // fragment (every e4m3 value is exactly a bf16 value); the per-channel scale is applied to the fp32 sum in the epilogue.
+// ---- weight streaming with the activations held in registers across several weight blocks (round 2) ---------------------------
+// gemm_skinny_dma_kernel<MB, true> loads a wave's activation fragments (MB x 16 rows x its K slice, up to 192 VGPRs) and then streams
+// ONE 16-row weight block (at most 3 tiles of 8 KB per wave): every workgroup pays 2 x its weight bytes in activation loads from L2
+// and never reaches a steady stream (measured at batch 32: 2.1 TB/s).  Here a workgroup keeps the SAME activation fragments for NB
+// consecutive weight blocks: the loads are paid once per NB blocks and each wave streams NB x its tiles through a 3-deep LDS-DMA
+// ring (24 KB in flight per wave).  Partial sums of the 4 waves (K quarters) meet in LDS per block, in a fixed order.
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a) {
+    const GemmArgs &g = a.g;
+    extern __shared__ __attribute__((aligned(16))) char smem_nb[];
+    char(*wbuf)[3][8192] = reinterpret_cast<char(*)[3][8192]>(smem_nb);                                  // [4 waves][3 stages][8 KB]
+    float(*red)[NB][MB][64][4] = reinterpret_cast<float(*)[NB][MB][64][4]>(smem_nb + 4 * 3 * 8192);       // [4][NB][MB][64][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nblocks = (g.N + 15) / 16;
+    const int b0 = blockIdx.x * NB;
+    const int ktiles = g.K / 256;
+    const int per_wg = (ktiles + a.ks - 1) / a.ks;
+    const int wg_beg = blockIdx.y * per_wg, wg_end = min(ktiles, wg_beg + per_wg);
+    const int per_w = (max(wg_end - wg_beg, 0) + 3) / 4;
+    const int beg = wg_beg + wid * per_w, end = min(wg_end, beg + per_w);
+    const int nt = max(end - beg, 0);  // tiles of this wave per weight block (<= 3)
+
+    const int prow = lane >> 5, pslot = lane & 31;
+    // piece i of block j: rows 2i, 2i+1 of the block; lane p -> row 2i + p/32, LDS slot p%32 <- global chunk slot ^ (row & 15)
+    auto src = [&](int j, int i) {
+        const int row = 2 * i + prow;
+        int gr = (b0 + j) * 16 + row;
+        gr = gr < g.N ? gr : g.N - 1;
+        return g.W + (int64_t)gr * g.ldw + ((pslot ^ (row & 15)) << 3);
+    };
+    auto stage_in = [&](int stage, int j, int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(src(j, i) + t * 256), (lds_void *)(&wbuf[wid][stage][i * 1024]), 16, 0, 0);
+    };
+    // activation fragments of this wave's K slice, once
+    bf16x8 av[MB][24];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+        if (tt < nt) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int r = mb * 16 + l15;
+                const bf16 *ap = g.A + (int64_t)(r < g.M ? r : 0) * g.lda + lg * 8 + (beg + tt) * 256;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[mb][tt * 8 + u] = r < g.M ? *reinterpret_cast<const bf16x8 *>(ap + u * 32) : zero8();
+            }
+        }
+    const int nbl = min(NB, nblocks - b0);  // weight blocks of this workgroup
+    const int total = nbl * nt;             // tiles this wave streams: flat index f = j * nt + tt
+    // prologue: two tiles in flight
+    if (total > 0) stage_in(0, 0, beg);
+    if (total > 1) stage_in(1, 1 / nt, beg + 1 % nt);
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int f = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < nbl) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                if (tt < nt) {
+                    // issue tile f + 2, then wait until tile f has landed: at most the 16 pieces of f + 1 and f + 2 stay in flight
+                    if (f + 2 < total) {
+                        stage_in((f + 2) % 3, (f + 2) / nt, beg + (f + 2) % nt);
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    } else if (f + 1 < total) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char *wb = &wbuf[wid][f % 3][0] + l15 * 512;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][tt * 8 + u], wv, acc[mb], 0, 0, 0);
+                    }
+                    ++f;
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid][j][mb][lane][r] = acc[mb][r];
+            acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // NB x MB result tiles (16 rows x 16 columns each), dealt to the 4 waves; the 4 K-quarter partials summed in a fixed order
+    for (int unit = wid; unit < NB * MB; unit += 4) {
+        const int j = unit / MB, mb = unit % MB;
+        if (j >= nbl) continue;
+        const int col = (b0 + j) * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w][j][mb][lane][r];
+            const int row = mb * 16 + lg * 4 + r;
+            if (row < g.M && col < g.N) {
+                if (a.ks == 1) skinny_epilogue(g, row, col, v);
+                else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
+            }
+        }
+    }
+}
+
 template <int MB, bool PRE>
 __global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
@@ -1754,12 +1868,37 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         // tiles of 256 per wave: ceil(ceil(K / 256 / ks) / 4); up to 3 (every decode shape) the activations are preloaded
         const int per_w = ((g.K / 256 + ks - 1) / ks + 3) / 4;
         const bool pre = per_w <= 3 && !(g.dbg & 128);
+        // weight blocks per workgroup (activation fragments reused): probe override (dbg >> 26) & 7 = 1 / 2 / 4; default by shape below
+        int nbsel = (g.dbg >> 26) & 7;
+        // measured at M = 32 (tools/skinny_sweep.py): qkv (480 blocks) 2.25 -> 2.59 TB/s with 2 blocks per workgroup, fc1 (640) 2.15 -> 2.40
+        // and the lm_head (3142) 2.82 -> 3.07 with 4; one block is best at M <= 16 and for the small matrices
+        if (nbsel == 0) nbsel = g.M > 16 ? (nb >= 600 ? 4 : (nb >= 400 ? 2 : 1)) : g_skinny_nb_default;
+        if (nbsel != 2 && nbsel != 4) nbsel = 1;
+        if (g.W8) nbsel = 1;
         if (g.W8 && g.M > 16) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);
         } else if (g.W8) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        } else if (dma_ok && pre && nbsel > 1) {
+            // activations held across NB weight blocks per workgroup (see gemm_skinny_nb_kernel)
+            static bool attr_nb = false;
+            constexpr int smem_nb4 = 4 * 3 * 8192 + 4 * 4 * 2 * 64 * 4 * 4;
+            if (!attr_nb) {
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
+                attr_nb = true;
+            }
+            const int mbk = g.M > 16 ? 2 : 1;
+            const int grid_x = (nb + nbsel - 1) / nbsel;
+            const size_t sm = 4 * 3 * 8192 + (size_t)4 * nbsel * mbk * 64 * 4 * 4;
+            if (mbk == 2 && nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 4>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else if (mbk == 2) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else if (nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 4>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
         } else if (dma_ok && g.M > 16) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);
