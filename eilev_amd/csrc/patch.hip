@@ -15,6 +15,9 @@
 // L2 (1.8 MB; HBM sees it once).  HBM-bound stage: per frame 3*H*W*2 B in, 2 * 257 * D * 2 B out.
 #include "common.h"
 
+unsigned long long *g_patch_trace = nullptr;
+extern "C" int eilev_debug_patch_trace(void *buf) { g_patch_trace = (unsigned long long *)buf; return 0; }
+
 namespace {
 
 constexpr int TR = 64;      // patches (output rows) per workgroup
@@ -28,6 +31,7 @@ struct PatchArgs {
     bf16 *x, *ln;           // (F * tok, D) each; ln may be null (no encoder block follows)
     int frames, T, IMG, P, G, G2, tok, D, PK, KP, KS, tiles_per_frame;
     float eps;
+    unsigned long long *trace;  // probe-only: 8 s_memtime stamps per workgroup (tools/patch_trace.py)
 };
 
 template <typename PT>
@@ -41,6 +45,8 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
     float *sRed = reinterpret_cast<float *>(smem + (size_t)TR * LDA * 2);  // [TR][NWAVE]
     bf16 *sOut = reinterpret_cast<bf16 *>(smem + (size_t)TR * LDA * 2 + TR * NWAVE * 4);  // [16][D + 8]
     const int D = a.D, NB = D >> 4;
+    auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
 
     // ---- stage the im2col tile: item = (patch row r, channel c, dy) -> P contiguous pixels of one image row -------------------
     {
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
         for (int it = tid; it < TR * padk; it += 512) sA[(it / padk) * LDA + a.PK + it % padk] = (bf16)0.0f;
     }
     __syncthreads();
+    stamp(1);
 
     // ---- K loop: wave w owns column blocks w, w + 8, ... (16 columns each); A from LDS, W straight from L2 ---------------------
     f32x4 acc[4][JMAX];
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
         }
     }
 
+    stamp(2);
     // ---- epilogue: x = bf16(acc + bias + pos); LayerNorm over the bf16 values (what the unfused path normalises) ---------------
     // lane holds rows rb*16 + lg*4 + r (r = 0..3) of column (wid + j*8)*16 + l15
     float xv[4][JMAX][4];
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
                 }
         }
     }
+    stamp(3);
     float mean[4][4], rstd[4][4];
     auto row_reduce = [&](float (&part)[4][4], float (&out)[4][4]) {
         // part[rb][r]: this lane's partial over its columns -> sum over the 16 lanes of a row group -> over the 8 waves via LDS
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
             for (int r = 0; r < 4; ++r) rstd[rb][r] = rsqrtf(rstd[rb][r] / (float)D + a.eps);
     }
 
+    stamp(4);
     // ---- stores: one 16-row block at a time through LDS so that HBM sees 16-byte pieces of whole rows ---------------------------
     const int LDO = D + 8;
     const int chunks = D >> 3;  // 16-byte chunks per row
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(const PatchArgs a) 
         }
     }
 
+    stamp(5);
     // ---- the frame's CLS row (token 0): x = cls + pos[0], LayerNorm of it — by the frame's first tile, wave 0 ----------------------
     if (tile == 0 && wid == 0) {
         float s = 0.0f;
@@ -244,7 +255,7 @@ int launch_patch_embed_ln(const void *pix, int pix_dtype, const bf16 *wpad, cons
     PatchArgs a;
     a.pix = pix; a.wpad = wpad; a.bias = bias; a.pos = pos; a.cls = cls; a.gamma = gamma; a.beta = beta; a.x = x; a.ln = ln;
     a.frames = (int)frames_total; a.T = frames_per_clip; a.IMG = img; a.P = patch; a.G = G; a.G2 = G2; a.tok = G2 + 1; a.D = D;
-    a.PK = PK; a.KP = KP; a.KS = KS; a.tiles_per_frame = (G2 + TR - 1) / TR; a.eps = eps;
+    a.PK = PK; a.KP = KP; a.KS = KS; a.tiles_per_frame = (G2 + TR - 1) / TR; a.eps = eps; a.trace = g_patch_trace;
     static bool attr = false;
     if (!attr) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(patch_embed_ln_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
