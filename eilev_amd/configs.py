@@ -67,6 +67,17 @@ CONFIGS = {
                          word_embed_proj_dim=256),
         num_query_tokens=8,
     ),
+    # the REAL widths of eilev-blip2-flan-t5-xl with one block per stack (ViT 1, Q-Former pair, T5 encoder 1 + decoder 1): the
+    # real-shape fixture of the encoder-decoder path (BASELINE configs[3])
+    "real_t5_1l": dict(
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=1,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+                            intermediate_size=3072, encoder_hidden_size=1408),
+        text_config=dict(model_type="t5", d_model=2048, d_kv=64, num_heads=32, d_ff=5120, num_layers=1, num_decoder_layers=1,
+                         vocab_size=32128, feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0),
+        num_query_tokens=32,
+    ),
     "opt67": dict(  # blip2-opt-6.7b backbone (BASELINE configs[4]): hidden 4096, 32 heads x 128, ffn 16384
         vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=39,
                            num_attention_heads=16, patch_size=14, image_size=224),

@@ -156,3 +156,28 @@ def test_fused_patch_embed_layernorm_equals_unfused_path(cfg_name, frames, dtype
     record_parity("fused_patch_embed", **{f"{cfg_name}_{str(dtype)[6:]}_relrms_vs_unfused": worst, f"{cfg_name}_{str(dtype)[6:]}_x_mismatch_frac": float((e0 != r0).mean())})
     assert worst <= 4e-3, worst
     assert rel_rms(host(pool), host(ref_pool)) <= 4e-3
+
+
+def test_real_width_t5_path(golden_dir):
+    """BASELINE configs[3] at its real widths (flan-t5-xl, one block per stack): encoder output and logits vs the reference fixture,
+    judged like the OPT path; greedy ids equal to the reference's fp32 or bf16 run."""
+    g = np.load(os.path.join(golden_dir, "real_t5_b1.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, _, eng = models(meta["config"])
+    px = torch.from_numpy(synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)).cuda()
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    emb = eng.embed_scatter(t("input_ids"), t("video_input_mask"), eng.encode_clips(px))
+    logits, enc = eng.t5_forward(emb, t("attention_mask"), t("decoder_input_ids"))
+    e = host(enc)[:, g["enc_rows"]]
+    ref_dev = float(np.abs(g["bf16_enc_rows"] - g["fp32_enc_rows"]).max())
+    record_parity("real_t5_b1", enc_hip_vs_fp32_maxabs=float(np.abs(e - g["fp32_enc_rows"]).max()), enc_refbf16_vs_fp32_maxabs=ref_dev,
+                  enc_hip_vs_fp32_relrms=rel_rms(e, g["fp32_enc_rows"]), enc_refbf16_vs_fp32_relrms=rel_rms(g["bf16_enc_rows"], g["fp32_enc_rows"]))
+    assert np.abs(e - g["fp32_enc_rows"]).max() <= 1.5 * ref_dev + 1e-3
+    assert rel_rms(e, g["fp32_enc_rows"]) <= 1.2 * rel_rms(g["bf16_enc_rows"], g["fp32_enc_rows"]) + 2e-3
+    lg = host(logits)[:, :, g["logit_cols"]]
+    record_parity("real_t5_b1", logits_hip_vs_fp32_relrms=rel_rms(lg, g["fp32_logits_cols"]),
+                  logits_refbf16_vs_fp32_relrms=rel_rms(g["bf16_logits_cols"], g["fp32_logits_cols"]))
+    assert np.abs(lg - g["fp32_logits_cols"]).max() <= 2.0 * np.abs(g["bf16_logits_cols"] - g["fp32_logits_cols"]).max() + 1e-3
+    assert rel_rms(lg, g["fp32_logits_cols"]) <= 1.2 * rel_rms(g["bf16_logits_cols"], g["fp32_logits_cols"]) + 2e-3
+    ids = eng.t5_greedy(emb, t("attention_mask"), meta["new_tokens"], eos_id=-1).cpu().numpy()
+    assert any(np.array_equal(ids, g[k]) for k in ("fp32_greedy_free", "bf16_greedy_free")), (ids, g["fp32_greedy_free"], g["bf16_greedy_free"])

@@ -41,3 +41,20 @@ def test_real_width_greedy_ids_match_reference(case):
     g, meta, cfg, px, m = case
     ids = m.generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
     assert np.array_equal(ids, g["fp32_greedy_free"])
+
+
+def test_real_width_t5_matches_reference(golden_dir):
+    """flan-t5-xl widths (d_model 2048, 32 heads x 64, d_ff 5120, vocab 32128), one block per stack — tests/golden/real_t5_b1.npz."""
+    g = np.load(os.path.join(golden_dir, "real_t5_b1.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)
+    m = OracleModel(cfg, synth_state_dict(cfg))
+    logits, enc = m.t5_forward_logits(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"])
+    assert np.abs(enc[:, g["enc_rows"]] - g["fp32_enc_rows"]).max() < 5e-4
+    assert abs(enc.astype(np.float64).sum() - g["fp32_enc_checksum"][0]) < 1e-6 * g["fp32_enc_checksum"][1]
+    assert np.abs(logits[:, :, g["logit_cols"]] - g["fp32_logits_cols"]).max() < 1e-3
+    assert abs(logits.astype(np.float64).sum() - g["fp32_logits_checksum"][0]) < 1e-6 * g["fp32_logits_checksum"][1]
+    assert np.array_equal(logits.argmax(-1), g["fp32_logits_argmax"])
+    ids = m.t5_generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
+    assert np.array_equal(ids, g["fp32_greedy_free"])

@@ -333,6 +333,53 @@ def run_real_case(name):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
 
 
+REAL_T5_CASES = {"real_t5_b1": ("real_t5_1l", 8, [([1, 1], [10, 8])], 6, 5)}
+
+
+@torch.no_grad()
+def run_real_t5_case(name):
+    """Real-width single-block fixture of the encoder-decoder path (flan-t5-xl widths): subsampled outputs, weights from the seed."""
+    from eilev_amd.synth import det_uniform_int
+
+    cfg_name, frames, rows, tgt_len, new_tokens = REAL_T5_CASES[name]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, _ = build_inputs(cfg_name, frames, rows)  # one row: no padding
+    B, L = input_ids.shape
+    vocab = cfg.text_config.vocab_size
+    rng = np.random.default_rng(11)
+    labels = rng.integers(2, vocab, size=(B, tgt_len)).astype(np.int64)
+    dec_in = np.concatenate([np.zeros((B, 1), np.int64), labels[:, :-1]], axis=1)
+    enc_rows = np.unique(np.concatenate([[0, 1, 32, 33, L - 1], det_uniform_int("real_t5_enc_rows", (16,), 0, L)]))
+    cols = np.unique(det_uniform_int("real_t5_logit_cols", (REAL_LOGIT_COLS,), 0, vocab))
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        px = t(pixels).to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=px, video_input_mask=t(vmask), labels=t(labels), return_dict=True)
+        enc = o.language_model_outputs.encoder_last_hidden_state.float().numpy()
+        out[f"{tag}_enc_rows"] = enc[:, enc_rows]
+        out[f"{tag}_enc_checksum"] = np.asarray([enc.astype(np.float64).sum(), np.abs(enc.astype(np.float64)).sum()])
+        lg = o.logits.float().numpy()
+        out[f"{tag}_logits_cols"] = lg[:, :, cols]
+        out[f"{tag}_logits_checksum"] = np.asarray([lg.astype(np.float64).sum(), np.abs(lg.astype(np.float64)).sum()])
+        out[f"{tag}_logits_argmax"] = lg.argmax(-1)
+        out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
+        g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                       max_new_tokens=new_tokens, min_new_tokens=new_tokens, num_beams=1, do_sample=False)
+        out[f"{tag}_greedy_free"] = g.numpy().astype(np.int64)
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="fanin", torch=torch.__version__,
+                transformers=transformers.__version__, generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py")
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, labels=labels, decoder_input_ids=dec_in, enc_rows=enc_rows,
+               logit_cols=cols, meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
 @torch.no_grad()
 def run_vit_debug_case(name="mid_vitdebug"):
     """output_hidden_states / output_attentions of the reference's VideoBlipVisionModel (ref:eilev/model/v2.py:76-103), eager
@@ -361,5 +408,6 @@ def run_vit_debug_case(name="mid_vitdebug"):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + ["mid_vitdebug"]):
-        (run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_vit_debug_case if n == "mid_vitdebug" else run_case)(n)
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug"]):
+        (run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
+         else run_vit_debug_case if n == "mid_vitdebug" else run_case)(n)
