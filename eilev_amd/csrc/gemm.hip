@@ -1502,12 +1502,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_dma_kernel(const SkinnyArgs a
 // and never reaches a steady stream (measured at batch 32: 2.1 TB/s).  Here a workgroup keeps the SAME activation fragments for NB
 // consecutive weight blocks: the loads are paid once per NB blocks and each wave streams NB x its tiles through a 3-deep LDS-DMA
 // ring (24 KB in flight per wave).  Partial sums of the 4 waves (K quarters) meet in LDS per block, in a fixed order.
-template <int MB, int NB>
+template <int MB, int NB, int ST = 3>
 __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
     extern __shared__ __attribute__((aligned(16))) char smem_nb[];
-    char(*wbuf)[3][8192] = reinterpret_cast<char(*)[3][8192]>(smem_nb);                                  // [4 waves][3 stages][8 KB]
-    float(*red)[NB][MB][64][4] = reinterpret_cast<float(*)[NB][MB][64][4]>(smem_nb + 4 * 3 * 8192);       // [4][NB][MB][64][4]
+    char(*wbuf)[ST][8192] = reinterpret_cast<char(*)[ST][8192]>(smem_nb);                                  // [4 waves][ST stages][8 KB]
+    float(*red)[4][MB][64][4] = reinterpret_cast<float(*)[4][MB][64][4]>(smem_nb + 4 * ST * 8192);       // [2 (ping-pong)][4 waves][MB][64][4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -1548,9 +1548,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
         }
     const int nbl = min(NB, nblocks - b0);  // weight blocks of this workgroup
     const int total = nbl * nt;             // tiles this wave streams: flat index f = j * nt + tt
-    // prologue: two tiles in flight
+    // prologue: ST - 1 tiles in flight
     if (total > 0) stage_in(0, 0, beg);
-    if (total > 1) stage_in(1, 1 / nt, beg + 1 % nt);
+    if (ST > 2 && total > 1) stage_in(1, 1 / nt, beg + 1 % nt);
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1561,17 +1561,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
                 if (tt < nt) {
-                    // issue tile f + 2, then wait until tile f has landed: at most the 16 pieces of f + 1 and f + 2 stay in flight
-                    if (f + 2 < total) {
-                        stage_in((f + 2) % 3, (f + 2) / nt, beg + (f + 2) % nt);
-                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    } else if (f + 1 < total) {
+                    // issue tile f + ST - 1, then wait until tile f has landed: the 8 pieces of each younger tile stay in flight
+                    constexpr int AH = ST - 1;
+                    if (f + AH < total) {
+                        stage_in((f + AH) % ST, (f + AH) / nt, beg + (f + AH) % nt);
+                        if (AH == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else if (AH == 2 && f + 1 < total) {
                         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const char *wb = &wbuf[wid][f % 3][0] + l15 * 512;
+                    const char *wb = &wbuf[wid][f % ST][0] + l15 * 512;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wb + (((u * 4 + lg) ^ l15) << 4));
@@ -1585,25 +1587,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wid][j][mb][lane][r] = acc[mb][r];
+            for (int r = 0; r < 4; ++r) red[j & 1][wid][mb][lane][r] = acc[mb][r];
             acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    }
-    __syncthreads();
-    // NB x MB result tiles (16 rows x 16 columns each), dealt to the 4 waves; the 4 K-quarter partials summed in a fixed order
-    for (int unit = wid; unit < NB * MB; unit += 4) {
-        const int j = unit / MB, mb = unit % MB;
-        if (j >= nbl) continue;
-        const int col = (b0 + j) * 16 + l15;
+        // one barrier per weight block; the partials ping-pong between two LDS regions, so the waves that finish block j (below) are
+        // done before anybody writes region j & 1 again (after the barrier of block j + 1)
+        __syncthreads();
+        if (wid < MB && j < nbl) {  // wave mb finishes row tile mb of this block: the 4 K-quarter partials summed in a fixed order
+            const int mb = wid;
+            const int col = (b0 + j) * 16 + l15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[w][j][mb][lane][r];
-            const int row = mb * 16 + lg * 4 + r;
-            if (row < g.M && col < g.N) {
-                if (a.ks == 1) skinny_epilogue(g, row, col, v);
-                else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
+                for (int w = 0; w < 4; ++w) v += red[j & 1][w][mb][lane][r];
+                const int row = mb * 16 + lg * 4 + r;
+                if (row < g.M && col < g.N) {
+                    if (a.ks == 1) skinny_epilogue(g, row, col, v);
+                    else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
+                }
             }
         }
     }
@@ -1870,10 +1872,16 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         const bool pre = per_w <= 3 && !(g.dbg & 128);
         // weight blocks per workgroup (activation fragments reused): probe override (dbg >> 26) & 7 = 1 / 2 / 4; default by shape below
         int nbsel = (g.dbg >> 26) & 7;
-        // measured at M = 32 (tools/skinny_sweep.py): qkv (480 blocks) 2.25 -> 2.59 TB/s with 2 blocks per workgroup, fc1 (640) 2.15 -> 2.40
-        // and the lm_head (3142) 2.82 -> 3.07 with 4; one block is best at M <= 16 and for the small matrices
-        if (nbsel == 0) nbsel = g.M > 16 ? (nb >= 600 ? 4 : (nb >= 400 ? 2 : 1)) : g_skinny_nb_default;
-        if (nbsel != 2 && nbsel != 4) nbsel = 1;
+        // measured at M = 32 (tools/skinny_sweep.py, 2 LDS stages so that two workgroups share a CU): lm_head (3142 blocks) 2.82 -> 3.45 /
+        // 3.76 / 4.20 TB/s with 2 / 4 / 8 blocks per workgroup, qkv (480) 2.25 -> 2.46 with 2 (1.71 with 4: 120 workgroups leave CUs idle),
+        // fc1 (640) 2.17 -> 2.30 with 2; the 2560-row matrices and M <= 16 are best with one block: keep >= 240 workgroups
+        if (nbsel == 0) {
+            nbsel = g_skinny_nb_default;
+            if (g.M > 16) nbsel = nb >= 8 * 240 ? 8 : (nb >= 4 * 240 ? 4 : (nb >= 2 * 240 ? 2 : 1));
+        }
+        if (nbsel == 7) nbsel = 8;  // probe encoding
+        if (nbsel != 2 && nbsel != 4 && nbsel != 8) nbsel = 1;
+        if (nbsel == 8 && g.M <= 16) nbsel = 4;
         if (g.W8) nbsel = 1;
         if (g.W8 && g.M > 16) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
@@ -1882,23 +1890,26 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
         } else if (dma_ok && pre && nbsel > 1) {
-            // activations held across NB weight blocks per workgroup (see gemm_skinny_nb_kernel)
-            static bool attr_nb = false;
-            constexpr int smem_nb4 = 4 * 3 * 8192 + 4 * 4 * 2 * 64 * 4 * 4;
-            if (!attr_nb) {
-                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
-                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
-                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
-                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_nb4));
-                attr_nb = true;
-            }
+            // activations held across NB weight blocks per workgroup (see gemm_skinny_nb_kernel): 2 LDS-DMA stages + ping-pong partials =
+            // 64 KB + 2 x MB x 4 KB, so two workgroups share a CU
             const int mbk = g.M > 16 ? 2 : 1;
             const int grid_x = (nb + nbsel - 1) / nbsel;
-            const size_t sm = 4 * 3 * 8192 + (size_t)4 * nbsel * mbk * 64 * 4 * 4;
-            if (mbk == 2 && nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 4>), dim3(grid_x, ks), dim3(256), sm, s, a);
-            else if (mbk == 2) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
-            else if (nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 4>), dim3(grid_x, ks), dim3(256), sm, s, a);
-            else hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            const size_t sm = 4 * 2 * 8192 + (size_t)2 * 4 * mbk * 64 * 4 * 4;
+            static bool attr_nb = false;
+            if (!attr_nb) {
+                const int mx = 4 * 2 * 8192 + 2 * 4 * 2 * 64 * 4 * 4;
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_nb_kernel<1, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+                attr_nb = true;
+            }
+            if (mbk == 2 && nbsel == 8) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 8, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else if (mbk == 2 && nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 4, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else if (mbk == 2) hipLaunchKernelGGL((gemm_skinny_nb_kernel<2, 2, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else if (nbsel == 4) hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 4, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
+            else hipLaunchKernelGGL((gemm_skinny_nb_kernel<1, 2, 2>), dim3(grid_x, ks), dim3(256), sm, s, a);
         } else if (dma_ok && g.M > 16) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_dma_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);

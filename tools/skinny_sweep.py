@@ -16,13 +16,13 @@ for name, n, k in [("qkv", 7680, 2560), ("out", 2560, 2560), ("fc1", 10240, 2560
     scr = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
     outs = {}
     res = {}
-    for nbsel in (3, 1, 2, 4):
+    for nbsel in (1, 2, 4, 7):
         raw.eilev_debug_gemm_flags(nbsel << 26)
         o = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
         for w in ws: lib.eilev_linear(P(a), P(w), P(b), None, P(o), M, n, k, 0, 0, st())
         torch.cuda.synchronize(); outs[nbsel] = o.clone()
     for rd in range(4):
-        for nbsel in (3, 1, 2, 4):
+        for nbsel in (1, 2, 4, 7):
             raw.eilev_debug_gemm_flags(nbsel << 26)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -31,5 +31,5 @@ for name, n, k in [("qkv", 7680, 2560), ("out", 2560, 2560), ("fc1", 10240, 2560
             e1.record(); torch.cuda.synchronize()
             if rd: res.setdefault(nbsel, []).append(e0.elapsed_time(e1) * 1e3 / (3 * copies))
     raw.eilev_debug_gemm_flags(0)
-    same = all(torch.equal(outs[3], outs[x]) for x in (1, 2, 4))
-    print(f"{name:8s} M={M} N={n:6d} K={k:6d}: " + " | ".join(f"{('old' if x == 3 else 'NB=' + str(x))}: {statistics.median(res[x]):6.1f} us {n*k*2/statistics.median(res[x])/1e6:5.2f} TB/s" for x in (3, 1, 2, 4)) + f" | identical: {same}", flush=True)
+    same = all(torch.equal(outs[1], outs[x]) for x in (2, 4, 7))
+    print(f"{name:8s} M={M} N={n:6d} K={k:6d}: " + " | ".join(f"{('old' if x == 3 else 'NB=' + str(x))}: {statistics.median(res[x]):6.1f} us {n*k*2/statistics.median(res[x])/1e6:5.2f} TB/s" for x in (1, 2, 4, 7)) + f" | identical: {same}", flush=True)
