@@ -228,7 +228,7 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    if torch.cuda.is_available() and torch.cuda.device_count() < n:
+    if torch.cuda.is_available() and torch.cuda.device_count() < n and "--share-gpu" not in sys.argv:
         print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPUs are visible", file=sys.stderr)
         return 2
     with socket.socket() as s:  # a free rendezvous port
@@ -266,6 +266,10 @@ def main():
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 transport of the clip tokens: rccl = eilev_exchange_clip_tokens (direct RCCL send/recv on a side "
                          "stream), torch = torch.distributed.all_to_all_single (also RCCL, through the process group)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N-rank path on a box with ONE GPU: every rank uses cuda:0, the process group is gloo and the "
+                         "exchange goes through torch.distributed (RCCL refuses two ranks on one device); the value it prints is not a "
+                         "scaling number (`config.share_gpu` says so)")
     ap.add_argument("--lm", choices=["opt27", "t5xl", "opt67"], default="opt27",
                     help="opt27 = the headline configs[1]/[2]; informational: t5xl = BASELINE configs[3] (flan-t5-xl encoder-decoder LM), "
                          "opt67 = the OPT-6.7B backbone of configs[4] in bf16 (use --shots 32 for its 32-shot sequence)")
@@ -285,13 +289,19 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if args.share_gpu:
+        local = 0
+        args.exchange = "torch"
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
 
     from eilev_amd.engine import HipEngine
 
@@ -330,6 +340,8 @@ def main():
     if world == 1 or transport != "rccl":
         exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport=transport)
 
+    last = {}
+
     def stamp(name):
         if eng.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -338,7 +350,7 @@ def main():
 
     def step():
         stamp("step_begin")
-        mine_f = eng.encode_and_exchange(px, exch)  # chunks of 136 clips; each chunk's RCCL exchange runs under the next ViT
+        mine_f = last["feats"] = eng.encode_and_exchange(px, exch)  # chunks of 136 clips; each chunk's RCCL exchange runs under the next ViT
         emb = eng.embed_scatter(ids, vm, mine_f)
         stamp("encode_done")
         if is_t5:  # encoder-decoder LM: encoder + cross K/V take the place of the prefill
@@ -379,10 +391,36 @@ def main():
         phases["prefill"] += e1.elapsed_time(p1)
         phases["decode"] += p1.elapsed_time(s1)
     assert out.shape == (S, NEW_TOKENS)
+    sharded = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        rdev = "cpu" if args.share_gpu else dev
+
+        def over_ranks(x, op):
+            t = torch.tensor([x], device=rdev, dtype=torch.float64)
+            dist.all_reduce(t, op=op)
+            return float(t.item())
+
+        dt = over_ranks(dt, dist.ReduceOp.MAX)
+        if not is_t5 and not args.no_verify:
+            # outside the timed region: every rank re-encodes the clips of ITS samples itself (the pixels of a peer are its seed
+            # away) and the rows that came through the exchange must be those rows, the ids of its samples the same ids
+            first, cps = rank * S * (N_CTX + 1), N_CTX + 1
+            need = torch.arange(first, first + S * cps, device=dev)
+            ref = torch.empty_like(last["feats"]).view(S * cps, nq, Dt)
+            for q in range(world):
+                sel = (need % world) == q
+                if bool(sel.any()):
+                    pq = px if q == rank else build_inputs(cfg, S, dev, seed=1234 + q)[0]
+                    ref[sel] = eng.encode_clips(pq[need[sel] // world]).view(-1, nq, Dt)
+                    del pq
+            got_f, ref_f = last["feats"].float().view(-1), ref.float().view(-1)
+            rel = float(((got_f - ref_f).pow(2).mean().sqrt() / ref_f.pow(2).mean().sqrt()).item())
+            ids_ref = eng.greedy_decode(eng.embed_scatter(ids, vm, ref.view(-1, Dt)), am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=False)
+            match = float((ids_ref == out).float().mean().item())
+            sharded = {"what": "per rank, after the timed steps: exchanged clip rows vs the same clips encoded locally (rel-RMS, max over ranks; "
+                               "different launch compositions -> bf16 rounding), and greedy ids from both (matching fraction, min over ranks)",
+                       "feat_rel_rms_max": round(over_ranks(rel, dist.ReduceOp.MAX), 6), "ids_match_min": round(over_ranks(match, dist.ReduceOp.MIN), 4)}
+            sharded["ok"] = sharded["feat_rel_rms_max"] < 2e-2 and sharded["ids_match_min"] > 0.9
 
     # dominant kernel: the ViT GEMM family, timed with hipEvents on the launch stream during the timed region
     kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [gemm_pp4_kernel<1>, M x 6144 x 1408, M = 257 tokens x 1088 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
@@ -416,6 +454,7 @@ def main():
                                     f"{S} samples/GPU/step x {N_CTX + 1} clips x 8 frames "
                                     f"224x224, L={seq_len} prefill, 32 greedy tokens (EOS off), clips dealt round-robin + "
                                     f"{('RCCL all-to-all of the clip tokens (' + exch.transport + ')') if world > 1 else 'no collective at N=1'}"),
+                       **({"share_gpu": "all ranks on ONE GPU over gloo: a rehearsal of the N-rank path, not a scaling number"} if args.share_gpu else {}),
                        "samples_per_gpu": S, "clips_per_step": world * S * (N_CTX + 1), "seq_len": seq_len, "new_tokens": NEW_TOKENS},
             "whole_path_tflops": (round((74.75 if is_t5 else TFLOP_PER_SAMPLE) * world * S * args.steps / dt, 1)
                                   if N_CTX == 16 and args.lm != "opt67" else None),
@@ -443,6 +482,8 @@ def main():
                                "mfma_busy_frac_pmc": (tr or {}).get("mfma_busy_frac"), "effective_clock_ghz_pmc": (tr or {}).get("eff_clock_ghz"),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
+        if sharded is not None:
+            res["sharded_check"] = sharded
         if do_verify or do_cpu:  # fp32 host copy of the weights, shared by the oracle check and the stock-HF CPU baseline
             from oracle.hf_baseline import effective_cpus
 

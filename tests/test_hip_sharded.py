@@ -125,3 +125,23 @@ def test_rccl_entries_on_a_one_rank_communicator():
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows():
+    """`python bench.py --gpus 2` must start two ranks itself (`--gpus` was dead).  One GPU here, so the ranks share it
+    over gloo (`--share-gpu`); everything else — launcher, deal, exchange rounds on the side stream, LM sharding, max-over-ranks
+    timing, the one JSON line — is the path the driver's scaling run takes."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
+                        "--samples", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["clips_per_step"] == 2 * 2 * 17 and res["scaling"] == "weak"
+    assert res["sharded_check"]["ok"], res["sharded_check"]
