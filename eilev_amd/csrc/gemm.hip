@@ -14,6 +14,12 @@
 // Skinny kernel (M <= 16, the decode step): one MFMA row-block of 16 weight rows per workgroup, the K
 // range split over the 8 waves (and over gridDim.y when N is small) — HBM-bound weight streaming.
 #include "common.h"
+// Cache policy of the persistent kernel's output stores: 2 = nt (streaming).  A launch writes 0.8-3.4 GB through eight 4-MiB L2s whose
+// job is to keep the A / W panels of the ~32 tiles in flight; nothing re-reads the output from L2.  Same-box A/B at the bench shapes
+// (tools/gemm_ab.py, 2 runs): +0.2 ... +0.7 % on all five GEMMs; sc1 / sc1+nt: +-0.
+#ifndef EILEV_ST_AUX
+#define EILEV_ST_AUX 2
+#endif
 #include <type_traits>
 #include <utility>
 
@@ -58,6 +64,10 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
     }
     // rows per group: 8 x 4 tiles per XCD round; narrow N with a long K (fc2: 5.5 column tiles, K = 6144) shares better with 4 rows
     // (measured on fc2: 2 / 4 / 8 / 16 rows = 1122 / 1132 / 1093 / 1045 TFLOP/s; wide N: 8 and 16 equal, 4 and 32 worse)
+    // The half tiles of the last column (N = 1408: 5.5 columns) stay MIXED into this order.  r2, same-box: all full tiles first and the
+    // half tiles last (every XCD in step on equal work) = fc2 1090 -> 983, proj 930 -> 880, qkv 1095 -> 1084 TFLOP/s — 256 half tiles
+    // at once are fabric-bound (an A panel per 128 output columns); two half tiles as one unit = fc2 1123 -> 906-1003 (a 1.5-tile unit
+    // per ~11 doubles the imbalance of the static stride).
     const int gsel = (g.dbg >> 22) & 3;  // probe override: 1 -> 4 rows, 2 -> 8 rows, 3 -> 16 rows
     const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 8 : gsel == 3 ? 16 : (tiles_n <= 8 && g.K >= 4096 ? 4 : 8);
     const int width = GROUP_M * tiles_n, group = t / width, first = group * GROUP_M;
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff, (U * 32 + (h2 * 2 + b) * 8) * (int)(g.ldc * 2), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff, (U * 32 + (h2 * 2 + b) * 8) * (int)(g.ldc * 2), EILEV_ST_AUX);
             }
             // Measured on gfx950 (round 2): with the next unit's arithmetic scheduled between these stores, a VALU write to the data
             // registers of a 128-bit buffer store issued the cycle before corrupted the first dword of the stored chunk (the "SGPR
