@@ -47,9 +47,12 @@ QfLayer = _ptr_struct("QfLayer", QF_LAYER_FIELDS)
 OptLayer = _ptr_struct("OptLayer", OPT_LAYER_FIELDS)
 
 
+VitLayerFold = _ptr_struct("VitLayerFold", ["qkv_w", "qkv_b", "qkv_csum", "fc1_w", "fc1_b", "fc1_csum"])
+
+
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", vp), ("patch_b", vp), ("cls", vp), ("pos", vp), ("post_ln_w", vp),
-                ("post_ln_b", vp), ("layers", C.POINTER(VitLayer))]
+                ("post_ln_b", vp), ("layers", C.POINTER(VitLayer)), ("layers_fold", C.POINTER(VitLayerFold))]
 
 
 class QfWeights(C.Structure):
@@ -250,8 +253,20 @@ EXPORTS = [
     "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
     "eilev_attention_dropout_bwd", "eilev_comm_bind", "eilev_comm_unique_id", "eilev_comm_init", "eilev_comm_destroy",
-    "eilev_gather_clip_tokens", "eilev_exchange_clip_tokens",
+    "eilev_gather_clip_tokens", "eilev_exchange_clip_tokens", "eilev_fold_layernorm", "eilev_linear_stats", "eilev_ln_finalize",
+    "eilev_linear_lnfold", "eilev_debug_ln_fold_min_rows",
 ]
+
+
+def attach_vit_fold(pack, per_layer):
+    """Point ``pack.vit`` at LayerNorm-folded qkv / fc1 right-hand sides: per_layer = [{"qkv": (w_ptr, b_ptr, csum_ptr), "fc1": ...}, ...]."""
+    arr = (VitLayerFold * len(per_layer))()
+    for i, d in enumerate(per_layer):
+        for name in ("qkv", "fc1"):
+            for f, v in zip(("w", "b", "csum"), d[name]):
+                setattr(arr[i], f"{name}_{f}", v)
+    pack._vit_layers_fold = arr
+    pack.vit.layers_fold = C.cast(arr, C.POINTER(VitLayerFold))
 
 
 def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int, act_fp8: bool = False):
@@ -291,6 +306,16 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_linear_w8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
     lib.eilev_quant_rows_e4m3.restype = i32
     lib.eilev_quant_rows_e4m3.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.eilev_fold_layernorm.restype = i32
+    lib.eilev_fold_layernorm.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]
+    lib.eilev_linear_stats.restype = i32
+    lib.eilev_linear_stats.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]
+    lib.eilev_ln_finalize.restype = i32
+    lib.eilev_ln_finalize.argtypes = [vp, i64, i64, f32, vp, vp]
+    lib.eilev_linear_lnfold.restype = i32
+    lib.eilev_linear_lnfold.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
+    lib.eilev_debug_ln_fold_min_rows.restype = None
+    lib.eilev_debug_ln_fold_min_rows.argtypes = [i64]
     lib.eilev_linear_a8w8.restype = i32
     lib.eilev_linear_a8w8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.eilev_process_workspace_bytes.restype = sz
@@ -385,7 +410,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 8:
+    if lib.eilev_abi_version() != 9:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

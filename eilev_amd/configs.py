@@ -55,6 +55,29 @@ CONFIGS = {
                          word_embed_proj_dim=2560),
         num_query_tokens=32,
     ),
+    # vision towers whose widths are multiples of 64 and that have 3 blocks: what the LayerNorm-folded ViT path needs to be exercised
+    # on every block boundary (block 0's layer_norm1 comes from the patch kernel, fc2 -> next block's qkv needs a next block) —
+    # a small one, and one at the true ViT-g widths (1408 / 6144 / 16 heads, 257 tokens)
+    "fold_3l": dict(
+        vision_config=dict(hidden_size=192, intermediate_size=384, num_hidden_layers=3,
+                           num_attention_heads=3, patch_size=14, image_size=56),
+        qformer_config=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=256, encoder_hidden_size=192),
+        text_config=dict(model_type="opt", hidden_size=160, num_hidden_layers=1, ffn_dim=320,
+                         num_attention_heads=2, vocab_size=512, max_position_embeddings=128,
+                         word_embed_proj_dim=160),
+        num_query_tokens=8,
+    ),
+    "real_vit_3l": dict(
+        vision_config=dict(hidden_size=1408, intermediate_size=6144, num_hidden_layers=3,
+                           num_attention_heads=16, patch_size=14, image_size=224),
+        qformer_config=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=256, encoder_hidden_size=1408),
+        text_config=dict(model_type="opt", hidden_size=160, num_hidden_layers=1, ffn_dim=320,
+                         num_attention_heads=2, vocab_size=512, max_position_embeddings=128,
+                         word_embed_proj_dim=160),
+        num_query_tokens=8,
+    ),
     # `mid` with a text model whose K dimensions are multiples of 128 (hidden 256 = 2 heads x 128, ffn 512): the smallest
     # configuration that takes the fp8-MFMA prefill path (eilev_linear_a8w8 needs k % 128 == 0)
     "mid_k128": dict(

@@ -151,6 +151,16 @@ struct GemmArgs {
     // (v_mfma_f32_32x32x64_f8f6f4, twice the bf16 rate): C = (Aq . Wq^T) * ascale[m] * wscale[n] + bias.  lda / ldw count BYTES = k.
     const uint8_t *A8 = nullptr;    // [M, K] e4m3 bytes
     const float *ascale = nullptr;  // [M]
+    // LayerNorm folded into the GEMM that consumes it (eilev_linear_lnfold; ViT ln1 -> qkv, ln2 -> fc1): A holds the RAW residual stream,
+    // W = gamma (.) W_orig, bias = b + W_orig . beta, and C = rstd[m] * (A . W^T - mean[m] * csum[n]) + bias[n]: the accumulators start
+    // from -mean[m] * csum[n], the epilogue multiplies by rstd[m].  ln_rows = (rstd, -mean) per row, csum[n] = sum_k W[n, k].
+    const float *ln_rows = nullptr;  // [M][2] or null
+    const float *ln_csum = nullptr;  // [N]
+    // ... and the GEMM that PRODUCES the residual stream (proj / fc2 with the residual epilogue) emits, per 64-column slot and row, the
+    // partial (sum, sum of squares) of what it writes: stat_out[(slot * stat_ld + row) * 2 + {0, 1}], slot = column / 64 (fixed order
+    // of summation downstream: deterministic).  stat_ld = rows of the whole matrix (row-chunked launches shift stat_out, not stat_ld).
+    float *stat_out = nullptr;
+    int64_t stat_ld = 0;
     int k_slice = 0;                // > 0: split-K launch (gridDim.y slices of k_slice K-steps, f32 output accumulated atomically)
     // probe-only (tools/gemm_trace.py): per-tile phase timestamps of the persistent ping-pong kernel, 8 u64 per (workgroup, wave
     // group, tile): s_memrealtime at loop top / K-loop start / K-loop end / epilogue start / epilogue end, s_memtime at top / end
@@ -161,6 +171,9 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
                      int cols, float eps, hipStream_t s);
+int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,
+                          hipStream_t s);
+int launch_ln_finalize(const float *part, int slots, int64_t rows, int cols, float eps, float *out, hipStream_t s);
 
 struct AttnArgs {
     const bf16 *q, *k, *v;

@@ -82,7 +82,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
 // loop): (a) residual rows -> LDS (coalesced); (b) acc + bias, activation, + residual -> bf16 in place;
 // (c) rows -> HBM.  Only the owning wave touches its region: no workgroup barrier.  The rare variants (fp32
 // logits, q pre-scaling, patch-embedding row remap, tile tails) are wave-uniform branches around the hot path.
-template <int WM, int WN, int EPI, int IBEG = 0, int IEND = WM / 32>
+template <int WM, int WN, int EPI, int IBEG = 0, int IEND = WM / 32, int LN = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[WM / 32][WN / 32], char *smem, int m0, int n0,
                                               int wm, int wn, int wid, int lane) {
     constexpr int TN = WN / 32;
@@ -130,6 +130,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
             for (int j = 0; j < TN; ++j) keep += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
         if (keep == 123.456f) reinterpret_cast<float *>(g.C)[0] = keep;
         return;
+    }
+    float st1[LN == 2 ? IEND - IBEG : 1], st2[LN == 2 ? IEND - IBEG : 1];  // stat_out: this wave's (sum, sum of squares) per row over its 64 columns
+    if constexpr (LN == 2) {
+#pragma unroll
+        for (int i = 0; i < IEND - IBEG; ++i) st1[i] = st2[i] = 0.0f;
     }
     char *reg = smem + wid * (ROWS * RS);
     const int wrow1 = wrow0 + IBEG * 32;            // first global row of this pass
@@ -204,6 +209,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
                     for (int e = 0; e < 4; ++e) acc[IBEG + i][j][q * 4 + e] *= as;
                 }
             }
+            if (LN == 1) {  // folded LayerNorm: the accumulators started from -mean[m] * csum[n]; what is left is rstd[m]
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = wrow0 + (IBEG + i) * 32 + l31;
+                    const float la = row < g.M ? g.ln_rows[2 * (int64_t)row] : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[IBEG + i][j][q * 4 + e] *= la;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -233,8 +247,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[i][e] += (float)r4[e];
                 }
+                if (LN == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < g.N) {
+                            st1[LN == 2 ? i : 0] += v[i][e];
+                            st2[LN == 2 ? i : 0] = fmaf(v[i][e], v[i][e], st2[LN == 2 ? i : 0]);
+                        }
+                }
                 *cell = (bf16x4){(bf16)v[i][0], (bf16)v[i][1], (bf16)v[i][2], (bf16)v[i][3]};
             }
+        }
+    }
+    if (LN == 2 && wcol0 < g.N) {
+        static_assert(WN == 64, "one statistics slot per 64 columns");
+#pragma unroll
+        for (int i = 0; i < IEND - IBEG; ++i) {
+            const float t1 = st1[LN == 2 ? i : 0] + __shfl_xor(st1[LN == 2 ? i : 0], 32), t2 = st2[LN == 2 ? i : 0] + __shfl_xor(st2[LN == 2 ? i : 0], 32);
+            const int row = wrow0 + (IBEG + i) * 32 + l31;
+            if (hi == 0 && row < g.M)
+                *reinterpret_cast<float2 *>(g.stat_out + ((int64_t)(wcol0 >> 6) * g.stat_ld + row) * 2) = make_float2(t1, t2);
         }
     }
     if (g.dbg & 2048) return;  // probe: no store phase
@@ -568,7 +600,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
 // half K-steps as 16 rows x 64 B lands only 56-64 B/ns per CU, as long as the 16 MFMAs it should hide under; 128-byte rows
 // land 97-146 B/ns: tools/probes/lds_dma_rate.hip.)  Two 64-KiB step buffers; step s + 1 is issued in the read phase of
 // half 2s and waited for in the read phase of half 2s + 1.
-template <int EPI, bool F8 = false>
+// LN: 0 plain; 1 the A operand is a raw residual stream whose LayerNorm is folded into W / bias (GemmArgs::ln_rows, no residual input);
+// 2 residual epilogue that also emits the row statistics of what it writes (GemmArgs::stat_out).
+template <int EPI, bool F8 = false, int LN = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
@@ -719,8 +753,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale &&
                !(g.dbg & (1024 | 2048 | 1)) && !(g.dbg & 16777216);
     };
+    // LN == 2 (proj / fc2, residual): the unit also emits the row statistics of what it writes (g.stat_out); LN == 1 (qkv / fc1, no residual):
+    // (qkv / fc1) it finishes a folded LayerNorm (g.ln_rows / g.ln_csum): see GemmArgs.
+    float ln_rs[LN == 1 ? TM : 1];  // LN == 1: rstd of the lane's row in each of its units, fetched at the end of the K loop
     auto lean_epilogue = [&](int cm0, int cn0, auto res_c) {
         constexpr bool RES = decltype(res_c)::value;
+        constexpr bool LNC = LN == 1 && !RES, LNP = LN == 2 && RES;
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         const int r0 = cm0 + wm * WM;
         const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
@@ -747,8 +785,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 if (g.bias) biasr[j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + cn0 + wn * WN + j * 32 + q * 8 + hi * 4);
                 else biasr[j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             }
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        __amdgpu_buffer_rsrc_t rst = rr;
+        if constexpr (LNP) rst = uniform_rsrc(g.stat_out + ((int64_t)((cn0 + wn * WN) >> 6) * g.stat_ld + r0) * 2, rows * 8);
         static_for<TM>([&](auto u_c) {
             constexpr int U = decltype(u_c)::value;
+            float st1 = 0.0f, st2 = 0.0f;
             bf16x4 rcell[TN][4];
             if constexpr (RES) {  // the unit's residual rows -> staging (coalesced); every lane then fetches its 8 cells in one batch
 #pragma unroll
@@ -771,8 +813,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
+                    if constexpr (LNC) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[U][j][q * 4 + e] + (float)biasr[j][q][e];
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[U][j][q * 4 + e], ln_rs[U], (float)biasr[j][q][e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[U][j][q * 4 + e] + (float)biasr[j][q][e];
+                    }
                     if constexpr (EPI == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
@@ -782,10 +829,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rcell[j][q][e];
                     }
+                    if constexpr (LNP) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            st1 += v[e];
+                            st2 = fmaf(v[e], v[e], st2);
+                        }
+                    }
                     unsigned ca;
                     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
                     *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 }
+            if constexpr (LNP) {  // the two lane halves hold the two column halves of a row
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const f32x2_t t = (f32x2_t){st1 + __shfl_xor(st1, 32), st2 + __shfl_xor(st2, 32)};
+                if (hi == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, t), rst, (U * 32 + l31) * 8, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);  // cells of a unit first, then its read-backs and stores; nothing of the next unit in between
             bf16x8 erb[2];
 #pragma unroll
@@ -822,6 +881,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
     bool lean_cur = is_lean(n0);  // this tile runs the lean epilogue: its accumulators start from the bias
+    // folded LayerNorm (LN == 1): C = rstd * (A . W^T - mean * csum) + bias.  The rank-1 term -mean[m] * csum[n] is one more K-slice on
+    // the matrix cores: the tile's first MFMA of every 32 x 32 block multiplies (csum_hi, csum_lo, csum_hi, 0 ...) by (nm_hi, nm_hi,
+    // nm_lo, 0 ...) with nm = -mean (v_mfma_f32_32x32x8_bf16_1k: half the cost of the K = 16 form) — two bf16 pieces each, the product is good to 2^-16 of |mean * csum|, far inside the bf16 output —
+    // and starts the accumulators (C = 0); the epilogue multiplies by rstd.  8 short MFMAs per wave and tile (+0.6 % of the K loop), ~30
+    // VALU operations, 6 four-byte loads per lane fetched one tile AHEAD next to the next tile's first DMA (rows past M / columns past N
+    // read 0).  (Built and measured before this: accumulators initialised with v_mul from 32 csum registers per lane — 36 loads per
+    // lane and tile through the texture addresser and 128 VALU operations in a read phase: fc1 +4.5 %.)
+    float ln_nm[LN == 1 ? TM : 1], ln_cl[LN == 1 ? TN : 1];
+    auto ln_fetch = [&](int m0_, int n0_) {
+        if constexpr (LN == 1) {
+            const bool ht = n0_ + 128 >= g.N && !(g.dbg & 524288);
+            const int mb = m0_ + (ht ? hm * 64 : wm * WM) + l31, nb = n0_ + (ht ? hn * 64 : wn * WN) + l31;
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rcs = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_csum, 0, g.N * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ln_nm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (mb + i * 32) * 8 + 4, 0, 0));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ln_cl[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rcs, (nb + j * 32) * 4, 0, 0));
+        }
+    };
+    ln_fetch(m0, n0);
     int trace_i = 0;
     const bool tracer = g.trace != nullptr && (wid == 0 || wid == NW / 2) && lane == 0;
     auto stamp = [&](int k, bool core = false) {
@@ -832,12 +912,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     for (; t < ntiles; t += gridDim.x) {
         stamp(0);
         stamp(5, true);
+        typedef __attribute__((ext_vector_type(4))) short s16x4_t;  // operand type of the K = 8 bf16 MFMA
+        s16x4_t ln_a1[LN == 1 ? TM : 1], ln_w1[LN == 1 ? TN : 1];
+        auto acc_prep = [&]() {  // the two fragments of the rank-1 K-slice (in a read phase)
+            if constexpr (LN == 1) {
+                const bf16 z = (bf16)0.0f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    const float m = hi ? 0.0f : ln_nm[i];  // k-slots 0..3 belong to lanes 0..31
+                    const bf16 mh = (bf16)m, ml = (bf16)(m - (float)mh);
+                    ln_a1[i] = __builtin_bit_cast(s16x4_t, (bf16x4){mh, mh, ml, z});
+                }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    const float c = hi ? 0.0f : ln_cl[j];
+                    const bf16 ch = (bf16)c, cl = (bf16)(c - (float)ch);
+                    ln_w1[j] = __builtin_bit_cast(s16x4_t, (bf16x4){ch, cl, ch, z});
+                }
+            }
+        };
+        auto acc_init = [&]() {
+            if constexpr (LN == 1) {
+                f32x16 zero;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ln_w1[j], ln_a1[i], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            }
+        };
+        if constexpr (LN != 1) acc_init();
         // step 0 of this tile was issued by the prologue above or by the previous tile's tail; the wait also covers the
         // previous epilogue's stores, and the barrier its LDS staging reads (which overlay step buffer 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -851,8 +963,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             constexpr bool FIRST = decltype(first_c)::value;
             read_half(st, 0);
             if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1);
+            if constexpr (FIRST && LN == 1) acc_prep();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
+            if constexpr (FIRST && LN == 1) acc_init();
             mma_half();
             PP_BARRIER();
             read_half(st, 1);
@@ -866,8 +980,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             const bool w_mine = wid < NW / 2;
             read_half_ht(st, 0);
             if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
+            if constexpr (FIRST && LN == 1) acc_prep();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
+            if constexpr (FIRST && LN == 1) acc_init();
             mma_half_ht();
             PP_BARRIER();
             read_half_ht(st, 1);
@@ -885,6 +1001,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         }
         stamp(2);
         if (!late) PP_BARRIER();
+        if constexpr (LN == 1) {  // rstd of the lane's rows for the epilogue: issued BEFORE the next tile's DMA (retire in order)
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < TM; ++u) ln_rs[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (m0 + wm * WM + u * 32 + l31) * 8, 0, 0));
+        }
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
         const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
@@ -897,16 +1018,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             pre1 = lean && ns > 1;
             if (pre1) stage_step(1, w_piece_mine(n0));
             lean_cur = is_lean(n0);
+            ln_fetch(m0, n0);
         }
         stamp(3);
-        if (lean) {
-            if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{});
+        if (lean) {  // LN kernels: the launcher guarantees ln_rows and no residual (1), stat_out and a residual (2)
+            if constexpr (LN == 1) lean_epilogue(cm0, cn0, std::false_type{});
+            else if constexpr (LN == 2) lean_epilogue(cm0, cn0, std::true_type{});
+            else if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{});
             else lean_epilogue(cm0, cn0, std::false_type{});
         } else if (half_tile) {
-            gemm_epilogue<64, 64, EPI>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
+            gemm_epilogue<64, 64, EPI, 0, 2, LN>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
         } else {
-            gemm_epilogue<WM, WN, EPI, 0, TM / 2>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
-            gemm_epilogue<WM, WN, EPI, TM / 2, TM>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            gemm_epilogue<WM, WN, EPI, 0, TM / 2, LN>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            gemm_epilogue<WM, WN, EPI, TM / 2, TM, LN>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
         }
         stamp(4);
         stamp(6, true);
@@ -945,6 +1069,23 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
         h.K = g.K / 2; h.lda = g.lda / 2; h.ldw = g.ldw / 2;
         if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, true>), dim3(grid), dim3(512), smem, s, h);
         else hipLaunchKernelGGL((gemm_pp4_kernel<0, true>), dim3(grid), dim3(512), smem, s, h);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
+    if (g.ln_rows || g.stat_out) {  // LayerNorm-folding variants: consumer (qkv, fc1 + GELU) / producer (proj, fc2 with the residual)
+        static bool attr_ln = false;
+        if (!attr_ln) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_ln = true;
+        }
+        if (g.epi == 2 || g.out_f32 || (g.ln_rows && (g.resid || g.stat_out || !g.ln_csum || ((uintptr_t)g.ln_csum & 15) || ((uintptr_t)g.ln_rows & 7))) ||
+            (g.stat_out && (!g.resid || g.epi != 0 || g.stat_ld < g.M || ((uintptr_t)g.stat_out & 7))))
+            return EILEV_E_UNSUPPORTED;
+        if (g.stat_out) hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 2>), dim3(grid), dim3(512), smem, s, g);
+        else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp4_kernel<1, false, 1>), dim3(grid), dim3(512), smem, s, g);
+        else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 1>), dim3(grid), dim3(512), smem, s, g);
         EILEV_LAUNCH_CHECK();
         return EILEV_OK;
     }
@@ -1861,7 +2002,9 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
     const bool dma_ok = g.K % 256 == 0 && (!(g.dbg & 8) || g.W8);
-    const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0;
+    const bool ln_fold = g.ln_rows != nullptr || g.stat_out != nullptr;  // LayerNorm-folding variants: the persistent kernel only
+    if (ln_fold && (g.W8 || g.wscale || g.out_f32 || g.patch_group || g.scale_cols || g.K % BK || (int64_t)g.N * g.ldw * 2 >= 0x7fff0000ll)) return EILEV_E_UNSUPPORTED;
+    const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0 && !ln_fold;
     if (!skinny && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
                                    (g.bias && ((uintptr_t)g.bias & 7))))
         return EILEV_E_UNSUPPORTED;
@@ -1947,6 +2090,8 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
                 c.M = (int)((g.M - r0) < rows_per ? (g.M - r0) : rows_per);
                 c.A = g.A + r0 * g.lda;
                 if (g.resid) c.resid = g.resid + r0 * g.ldr;
+                if (g.stat_out) c.stat_out = g.stat_out + r0 * 2;  // stat_ld stays the row count of the whole matrix
+                if (g.ln_rows) c.ln_rows = g.ln_rows + r0 * 2;
                 c.C = g.out_f32 ? (void *)(reinterpret_cast<float *>(g.C) + r0 * g.ldc) : (void *)(reinterpret_cast<bf16 *>(g.C) + r0 * g.ldc);
                 const int rc_chunk = launch_gemm(c, prof_kind, s);
                 if (rc_chunk != 0) return rc_chunk;
@@ -1955,6 +2100,13 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         }
     }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
+    if (ln_fold) {
+        if ((int64_t)g.M * g.lda * 2 >= 0x7fff0000ll) return EILEV_E_UNSUPPORTED;
+        if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
+        const int rc_ln = launch_pp4(g, s);
+        if (prof_kind >= 0) prof_end(s);
+        return rc_ln;
+    }
     if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
     const int force = (g.dbg >> 4) & 15;  // probe-only override of the tile choice
     const int64_t tm256 = ceil_div64(g.M, 256);

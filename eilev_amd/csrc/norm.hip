@@ -127,3 +127,62 @@ int launch_rmsnorm(const bf16 *x, int64_t ldx, const bf16 *g, bf16 *y, int64_t l
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+
+// ---- LayerNorm folded into the consuming GEMM (see GemmArgs::ln_rows in common.h) ------------------------------------------
+// y = LN(x) . W^T + b  =  rstd * (x . (gamma (.) W)^T - mean * csum) + (b + W . beta),  csum[n] = sum_k gamma[k] W[n, k].
+// eilev_fold_layernorm prepares the right-hand sides once per weight; ln_finalize_kernel turns the per-slot partial sums the producing
+// GEMM wrote into (rstd, -mean) per row.  The reference computes the same product with the LayerNorm output rounded to
+// bf16 in between (hf modeling_blip_2.py:383-402 under bf16 weights); here the bf16 rounding sits on gamma (.) W instead.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const bf16 *__restrict__ w, const bf16 *__restrict__ gamma, const bf16 *__restrict__ beta,
+                                                      const bf16 *__restrict__ bias, int N, int K, bf16 *__restrict__ wf,
+                                                      float *__restrict__ csum, bf16 *__restrict__ bf) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per output channel
+    if (n >= N) return;
+    const bf16 *wr = w + (int64_t)n * K;
+    bf16 *wo = wf + (int64_t)n * K;
+    float cs = 0.0f, bs = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = (float)wr[k];
+        const bf16 f = (bf16)(wv * (float)gamma[k]);
+        wo[k] = f;
+        cs += (float)f;  // csum of what the MFMA will really multiply by
+        bs = fmaf(wv, (float)beta[k], bs);
+    }
+    cs = wave_sum(cs);
+    bs = wave_sum(bs);
+    if (lane == 0) {
+        csum[n] = cs;
+        bf[n] = (bf16)(bs + (bias ? (float)bias[n] : 0.0f));
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restrict__ part, int slots, int64_t rows, int cols, float eps,
+                                                          float *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int sl = 0; sl < slots; ++sl) {  // fixed order: the same bits on every run
+        const float2 p = *reinterpret_cast<const float2 *>(part + ((int64_t)sl * rows + r) * 2);
+        s1 += p.x;
+        s2 += p.y;
+    }
+    const float mean = s1 / (float)cols;
+    const float var = fmaxf(s2 / (float)cols - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<float2 *>(out + r * 2) = make_float2(rstd, -mean);
+}
+
+int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,
+                          hipStream_t s) {
+    if (!w || !gamma || !beta || !wf || !csum || !bf || N <= 0 || K <= 0) return EILEV_E_BADARG;
+    hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, gamma, beta, bias, N, K, wf, csum, bf);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
+int launch_ln_finalize(const float *part, int slots, int64_t rows, int cols, float eps, float *out, hipStream_t s) {
+    if (!part || !out || slots <= 0 || rows <= 0 || cols <= 0) return EILEV_E_BADARG;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, slots, rows, cols, eps, out);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}

@@ -96,6 +96,8 @@ extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms,
 
 extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
 // probe / test switch: 1 = take the unfused patch path (im2col -> GEMM -> CLS rows -> LayerNorm) even where the fused kernel applies
+static int64_t g_ln_fold_min_rows = 65536;
+extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }
 static int g_no_fused_patch = 0;
 extern "C" int eilev_debug_no_fused_patch(int on) { g_no_fused_patch = on; return 0; }
 extern "C" const char *eilev_backend(void) { return "hip-gfx950"; }
@@ -157,6 +159,7 @@ extern "C" size_t eilev_vit_workspace_bytes(const EilevDims *d, int64_t n_clips,
     b += align_up((size_t)M * d->v_hidden * 3 * 2, 256);       // qkv
     b += align_up((size_t)M * (d->v_inter > patch_kp(d) ? d->v_inter : patch_kp(d)) * 2, 256);  // mlp / patch rows
     b += align_up((size_t)d->v_hidden * patch_kp(d) * 2, 256);  // padded patch weight
+    b += align_up((size_t)M * ((d->v_hidden + 63) / 64) * 8, 256) + align_up((size_t)M * 8, 256);  // folded LayerNorm: row statistics
     return b + 256;
 }
 
@@ -243,7 +246,13 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     bf16 *qkv = cv.take<bf16>((size_t)M * 3 * D);
     bf16 *mlp = cv.take<bf16>((size_t)M * (Fi > KP ? Fi : KP));
     bf16 *wpad = cv.take<bf16>((size_t)D * KP);
+    const int slots = (D + 63) / 64;
+    float *part = cv.take<float>((size_t)M * slots * 2), *lnrows = cv.take<float>((size_t)M * 2);
     if (!cv.ok()) return EILEV_E_WORKSPACE;
+    // LayerNorm folded into qkv / fc1 (EilevVitWeights.layers_fold): the throughput path of large launches.  The debug outputs and
+    // small launches (where other GEMM kernels than the persistent one win) keep the LayerNorm kernels.
+    const bool fold = w->layers_fold && M >= g_ln_fold_min_rows && !hidden_states && !attentions && D % 64 == 0 && Fi % 64 == 0 &&
+                      (int64_t)M * D * 2 < 0x7fff0000ll && (int64_t)Fi * D * 2 < 0x7fff0000ll;
 
     // patch embedding (+ bias + position, CLS rows) fused with layer_norm1 of block 0: hf modeling_blip_2.py:243-255, :390.
     // One kernel (patch.hip); shapes it does not take fall back to im2col -> GEMM -> CLS rows (+ the separate LayerNorm below).
@@ -274,8 +283,16 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < d->v_layers; ++l) {
         const EilevVitLayer *L = &w->layers[l];
-        if (!(l == 0 && ln0_done)) RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
-        RC(launch_gemm(mk_gemm(ln, D, L->qkv_w, D, L->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0), 3, s));
+        const EilevVitLayerFold *LF = fold ? &w->layers_fold[l] : nullptr;
+        if (fold && l > 0) {  // fc2 of the previous block left the row statistics of x: qkv reads the raw stream
+            GemmArgs g = mk_gemm(x, D, LF->qkv_w, D, LF->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0);
+            g.ln_rows = lnrows;
+            g.ln_csum = LF->qkv_csum;
+            RC(launch_gemm(g, 3, s));
+        } else {
+            if (!(l == 0 && ln0_done)) RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
+            RC(launch_gemm(mk_gemm(ln, D, L->qkv_w, D, L->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0), 3, s));
+        }
         if (attentions) {
             bf16 *pr = (bf16 *)attentions + (size_t)l * F * H * tok * tok;
             attn_probs_kernel<<<dim3((unsigned)(F * H), (unsigned)((tok + 3) / 4)), 256, 0, s>>>(qkv, pr, (int)tok, H, hd, D, scale);
@@ -289,10 +306,29 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
         a.batch = (int)F; a.heads = H; a.sq = (int)tok; a.skv = (int)tok; a.hd = hd; a.scale = scale; a.causal = 0;
         a.key_mask = nullptr; a.mask_ld = 0;
         RC(launch_attention(a, s));
-        RC(launch_gemm(mk_gemm(att, D, L->proj_w, D, L->proj_b, x, D, x, D, M, D, D, 0), 4, s));
-        RC(launch_layernorm(x, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, ln, D, M, D, d->v_eps, s));
-        RC(launch_gemm(mk_gemm(ln, D, L->fc1_w, D, L->fc1_b, nullptr, 0, mlp, Fi, M, Fi, D, 1), 1, s));
-        RC(launch_gemm(mk_gemm(mlp, Fi, L->fc2_w, Fi, L->fc2_b, x, D, x, D, M, D, Fi, 0), 2, s));
+        if (fold) {
+            GemmArgs gp = mk_gemm(att, D, L->proj_w, D, L->proj_b, x, D, x, D, M, D, D, 0);
+            gp.stat_out = part;
+            gp.stat_ld = M;
+            RC(launch_gemm(gp, 4, s));
+            RC(launch_ln_finalize(part, slots, M, D, d->v_eps, lnrows, s));
+            GemmArgs g1 = mk_gemm(x, D, LF->fc1_w, D, LF->fc1_b, nullptr, 0, mlp, Fi, M, Fi, D, 1);
+            g1.ln_rows = lnrows;
+            g1.ln_csum = LF->fc1_csum;
+            RC(launch_gemm(g1, 1, s));
+            GemmArgs g2 = mk_gemm(mlp, Fi, L->fc2_w, Fi, L->fc2_b, x, D, x, D, M, D, Fi, 0);
+            if (l + 1 < d->v_layers) {  // the next block's layer_norm1 is folded too; post_layernorm below stays a kernel
+                g2.stat_out = part;
+                g2.stat_ld = M;
+            }
+            RC(launch_gemm(g2, 2, s));
+            if (l + 1 < d->v_layers) RC(launch_ln_finalize(part, slots, M, D, d->v_eps, lnrows, s));
+        } else {
+            RC(launch_gemm(mk_gemm(att, D, L->proj_w, D, L->proj_b, x, D, x, D, M, D, D, 0), 4, s));
+            RC(launch_layernorm(x, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, ln, D, M, D, d->v_eps, s));
+            RC(launch_gemm(mk_gemm(ln, D, L->fc1_w, D, L->fc1_b, nullptr, 0, mlp, Fi, M, Fi, D, 1), 1, s));
+            RC(launch_gemm(mk_gemm(mlp, Fi, L->fc2_w, Fi, L->fc2_b, x, D, x, D, M, D, Fi, 0), 2, s));
+        }
         if (hidden_states)
             RC((int)hipMemcpyAsync((char *)hidden_states + (size_t)(l + 1) * hs_bytes, x, hs_bytes, hipMemcpyDeviceToDevice, s));
     }
@@ -692,6 +728,38 @@ extern "C" int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_
         g.scratch = (float *)scratch;
         g.scratch_bytes = scratch_bytes;
     }
+    return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
+// LayerNorm folded into the consuming linear: the stages the folded ViT blocks are made of (include/eilev.h, ABI version 9)
+extern "C" int eilev_fold_layernorm(const void *w, const void *gamma, const void *beta, const void *bias, int64_t n, int64_t k, void *w_out,
+                                    float *csum, void *bias_out, void *stream) {
+    if (n > 0x7fffffff || k > 0x7fffffff) return EILEV_E_BADARG;
+    return launch_fold_layernorm((const bf16 *)w, (const bf16 *)gamma, (const bf16 *)beta, (const bf16 *)bias, (int)n, (int)k, (bf16 *)w_out,
+                                 csum, (bf16 *)bias_out, (hipStream_t)stream);
+}
+
+extern "C" int eilev_linear_stats(const void *a, const void *w, const void *bias, const void *residual, void *c, int64_t m, int64_t n,
+                                  int64_t k, float *stats, void *stream) {
+    if (!a || !w || !c || !residual || !stats || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;
+    GemmArgs g = mk_gemm((const bf16 *)a, k, w, k, bias, (const bf16 *)residual, n, c, n, m, (int)n, (int)k, 0);
+    g.stat_out = stats;
+    g.stat_ld = m;
+    return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
+extern "C" int eilev_ln_finalize(const float *stats, int64_t m, int64_t n, float eps, float *ln_rows, void *stream) {
+    if (n > 0x7fffffff) return EILEV_E_BADARG;
+    return launch_ln_finalize(stats, (int)((n + 63) / 64), m, (int)n, eps, ln_rows, (hipStream_t)stream);
+}
+
+extern "C" int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, const float *csum, const float *ln_rows, void *c,
+                                   int64_t m, int64_t n, int64_t k, int epilogue, void *stream) {
+    if (!a || !w_f || !csum || !ln_rows || !c || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;
+    if (epilogue != 0 && epilogue != 1) return EILEV_E_UNSUPPORTED;
+    GemmArgs g = mk_gemm((const bf16 *)a, k, w_f, k, bias_f, nullptr, 0, c, n, m, (int)n, (int)k, epilogue);
+    g.ln_rows = ln_rows;
+    g.ln_csum = csum;
     return launch_gemm(g, 5, (hipStream_t)stream);
 }
 

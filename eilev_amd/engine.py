@@ -48,6 +48,8 @@ class HipEngine:
         self._load(named_tensors)
         if lm_weights != "bf16":
             self._quantize_opt(act_fp8=lm_weights == "fp8_mfma")
+        if "vit" in self.parts:
+            self._fold_vit_layernorms()
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
     # ---- weights ------------------------------------------------------------------------------------
@@ -132,6 +134,30 @@ class HipEngine:
         expand = torch.empty(nb, dtype=torch.uint8, device=self.device)
         self._w8_keep = (keep, expand)
         abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb, act_fp8=act_fp8)
+
+    def _fold_vit_layernorms(self):
+        """layer_norm1 / layer_norm2 of every ViT block folded into qkv / fc1 (`eilev_fold_layernorm`, include/eilev.h ABI 9): large
+        encode launches then run without LayerNorm kernels.  +1.1 GB of device memory at ViT-g (a second copy of qkv / fc1)."""
+        d = self.dims
+        if d.v_hidden % 64 or d.v_inter % 64:
+            return
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        per_layer, keep = [], []
+        for i in range(d.v_layers):
+            k = abi.vit_layer_keys(i)
+            entry = {}
+            for name, ln in (("qkv", "ln1"), ("fc1", "ln2")):
+                w, b = self._keep[k[f"{name}_w"]], self._keep[k[f"{name}_b"]]
+                wf, bf = torch.empty_like(w), torch.empty_like(b)
+                cs = torch.empty(w.shape[0], dtype=torch.float32, device=self.device)
+                abi.check(self.lib.eilev_fold_layernorm(w.data_ptr(), self._keep[k[f"{ln}_w"]].data_ptr(), self._keep[k[f"{ln}_b"]].data_ptr(),
+                                                        b.data_ptr(), w.shape[0], w.shape[1], wf.data_ptr(), cs.data_ptr(), bf.data_ptr(), st),
+                          "eilev_fold_layernorm")
+                keep += [wf, bf, cs]
+                entry[name] = (wf.data_ptr(), bf.data_ptr(), cs.data_ptr())
+            per_layer.append(entry)
+        self._vit_fold_keep = keep
+        abi.attach_vit_fold(self.pack, per_layer)
 
     # ---- workspaces ----------------------------------------------------------------------------------
     def _workspace(self, tag, nbytes):

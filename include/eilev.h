@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 8
+#define EILEV_ABI_VERSION 9
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -70,11 +70,26 @@ typedef struct EilevVitLayer {
     const void *fc2_w, *fc2_b;     /* [Dv, Fv], [Dv] */
 } EilevVitLayer;
 
+/* ABI version 9.  layer_norm1 / layer_norm2 of a block folded into the linear that consumes them (eilev_fold_layernorm applied to
+ * qkv and fc1): w [N, Dv] bf16 = gamma (.) W, b [N] bf16 = b + W . beta, csum [N] f32 = row sums of w. */
+typedef struct EilevVitLayerFold {
+    const void *qkv_w, *qkv_b;
+    const float *qkv_csum;
+    const void *fc1_w, *fc1_b;
+    const float *fc1_csum;
+} EilevVitLayerFold;
+
 typedef struct EilevVitWeights {
     const void *patch_w, *patch_b; /* [Dv, 3, P, P], [Dv] */
     const void *cls, *pos;         /* [Dv], [1 + (image/patch)^2, Dv] */
     const void *post_ln_w, *post_ln_b;
     const EilevVitLayer *layers;   /* host array, v_layers entries */
+    /* ABI version 9.  NULL, or a host array of v_layers entries.  With it, launches of at least 65 536 token rows run the blocks
+     * WITHOUT LayerNorm kernels: proj / fc2 (+ residual) also emit per-row (sum, sum of squares) of the stream they write, and
+     * qkv / fc1 read the raw stream and compute rstd * (x . w^T - mean * csum) + b (hf modeling_blip_2.py:383-402:
+     * the same function; the bf16 rounding the reference puts on the LayerNorm output sits on gamma (.) W instead).  `layers`
+     * stays required (smaller launches, the debug outputs and block 0's layer_norm1 use it). */
+    const EilevVitLayerFold *layers_fold;
 } EilevVitWeights;
 
 /* One Q-Former block: hf Blip2QFormerLayer (modeling_blip_2.py:701-752). cross_* are NULL on
@@ -216,6 +231,26 @@ int eilev_exchange_clip_tokens(void *comm, const void *send, const int64_t *send
 size_t eilev_linear_w8_scratch_bytes(int64_t m, int64_t n, int64_t k);
 int eilev_linear_w8(const void *a, const uint8_t *w8, const float *w_scale, const void *bias, const void *residual, void *c, int64_t m,
                     int64_t n, int64_t k, int epilogue, int out_f32, void *scratch, size_t scratch_bytes, void *stream);
+
+/* LayerNorm folded into the linear that consumes it (ABI version 9; the ViT blocks with EilevVitWeights.layers_fold use these
+ * stages; exported so that each can be checked against layernorm + linear of the reference, hf modeling_blip_2.py:383-402).
+ *   eilev_fold_layernorm   w [n, k], gamma / beta [k], bias [n] or NULL -> w_out [n, k] = bf16(gamma (.) w), csum [n] = sum_k w_out
+ *                          (f32), bias_out [n] = bf16(bias + w . beta)
+ *   eilev_linear_stats     c = a . w^T + bias + residual (as eilev_linear, bf16 out) and, per 64-column slot s = column / 64 and row,
+ *                          stats[(s * m + row) * 2 + {0, 1}] = (sum, sum of squares) of the values written (before their bf16 rounding)
+ *   eilev_ln_finalize      ln_rows[row * 2 + {0, 1}] = (rstd, -mean) from the slots of `stats` summed in slot order
+ *   eilev_linear_lnfold    c = act(ln_rows[m, 0] * (a . w_f^T + ln_rows[m, 1] * csum[n]) + bias_f[n]);  epilogue 0 none, 1 erf-GELU
+ *                          (the accumulators start from ln_rows[m, 1] * csum[n]; the epilogue multiplies by ln_rows[m, 0])
+ * k % 64 == 0; operands below 2 GiB; csum 16-byte aligned.  (The oracle restates the same algebra in f32 / double.) */
+int eilev_fold_layernorm(const void *w, const void *gamma, const void *beta, const void *bias, int64_t n, int64_t k, void *w_out,
+                         float *csum, void *bias_out, void *stream);
+int eilev_linear_stats(const void *a, const void *w, const void *bias, const void *residual, void *c, int64_t m, int64_t n, int64_t k,
+                       float *stats, void *stream);
+int eilev_ln_finalize(const float *stats, int64_t m, int64_t n, float eps, float *ln_rows, void *stream);
+int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, const float *csum, const float *ln_rows, void *c, int64_t m,
+                        int64_t n, int64_t k, int epilogue, void *stream);
+/* probe / test knob: minimum token rows of a launch for the folded ViT path (default 65 536; 0 = always when layers_fold is set) */
+void eilev_debug_ln_fold_min_rows(int64_t rows);
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.

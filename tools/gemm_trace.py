@@ -21,7 +21,8 @@ raw = C.CDLL(abi.HIP_LIB_PATH)
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = {"fc1": (6144, 1408, 1, False), "fc2": (1408, 6144, 0, True), "qkv": (4224, 1408, 0, False), "proj": (1408, 1408, 0, True),
-          "fc1_noact": (6144, 1408, 0, False)}
+          "fc1_noact": (6144, 1408, 0, False), "fc1_ln": (6144, 1408, 1, False), "qkv_ln": (4224, 1408, 0, False),
+          "proj_st": (1408, 1408, 0, True), "fc2_st": (1408, 6144, 0, True)}  # _ln: folded-LayerNorm consumer, _st: statistics producer
 name = sys.argv[1] if len(sys.argv) > 1 else "fc1"
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 139808
 n, k, epi, resid = SHAPES[name]
@@ -31,13 +32,22 @@ b = torch.randn(n, device="cuda").to(torch.bfloat16)
 r = torch.randn(m, n, device="cuda").to(torch.bfloat16) if resid else None
 o = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
 TILES, WG = 64, 256
+if name.endswith("_ln"):
+    cs = torch.randn(n, device="cuda")
+    rows = torch.stack([torch.rand(m, device="cuda") + 0.5, torch.randn(m, device="cuda") * 0.1], 1).contiguous()
+    run = lambda: lib.eilev_linear_lnfold(P(a), P(w), P(b), P(cs), P(rows), P(o), m, n, k, epi, st())
+elif name.endswith("_st"):
+    stats = torch.empty(((n + 63) // 64, m, 2), device="cuda")
+    run = lambda: lib.eilev_linear_stats(P(a), P(w), P(b), P(r), P(o), m, n, k, P(stats), st())
+else:
+    run = lambda: lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
 for _ in range(3):
-    lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+    assert run() == 0
 buf = torch.zeros(WG * 2 * TILES * 8, dtype=torch.int64, device="cuda")
 raw.eilev_debug_gemm_trace(C.c_void_p(buf.data_ptr()), TILES)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+run()
 e1.record()
 torch.cuda.synchronize()
 raw.eilev_debug_gemm_trace(None, 0)
