@@ -30,7 +30,10 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        "qf_kv": (34952, 1536, 1408, 0, False), "opt_fc2": (7680, 2560, 10240, 0, True),
        "fc2_k6208": (34952, 1408, 6208, 0, True), "fc2_k6080": (34952, 1408, 6080, 0, True), "fc1_k1472": (34952, 6144, 1472, 0, False),
        "opt_out": (7680, 2560, 2560, 0, True), "qf_dense": (544, 768, 768, 0, True), "qf_fi": (544, 3072, 768, 0, False),
-       "fc1_noact": (34952, 6144, 1408, 0, False), "fc1_relu": (34952, 6144, 1408, 2, False)}
+       "fc1_noact": (34952, 6144, 1408, 0, False), "fc1_relu": (34952, 6144, 1408, 2, False),
+       # what the folded-LayerNorm ViT blocks run (eilev_linear_lnfold / eilev_linear_stats): consumer (_ln) and statistics producer (_st)
+       "fc1_ln": (34952, 6144, 1408, 1, False), "qkv_ln": (34952, 4224, 1408, 0, False), "proj_st": (34952, 1408, 1408, 0, True),
+       "fc2_st": (34952, 1408, 6144, 0, True)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
@@ -45,15 +48,28 @@ for name in names:
     b = torch.randn(n, device="cuda").to(torch.bfloat16)
     r = torch.randn(m, n, device="cuda").to(torch.bfloat16) if resid else None
     o = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+    if name.endswith("_ln"):
+        cs = torch.randn(n, device="cuda")
+        rows = torch.stack([torch.rand(m, device="cuda") + 0.5, torch.randn(m, device="cuda") * 0.1], 1).contiguous()
+        call = lambda dst: lib.eilev_linear_lnfold(P(a), P(w), P(b), P(cs), P(rows), P(dst), m, n, k, epi, st())
+    elif name.endswith("_st"):
+        stats = torch.empty(((n + 63) // 64, m, 2), device="cuda")
+        call = lambda dst: lib.eilev_linear_stats(P(a), P(w), P(b), P(r), P(dst), m, n, k, P(stats), st())
+    else:
+        call = lambda dst: lib.eilev_linear(P(a), P(w), P(b), P(r), P(dst), m, n, k, epi, 0, st())
+    fold = name.endswith(("_ln", "_st"))  # (no register-staged reference of these: tests/test_ln_fold.py checks them)
     raw.eilev_debug_gemm_flags(4)   # reference: register-staged kernel
     ref = torch.empty_like(o)
-    lib.eilev_linear(P(a), P(w), P(b), P(r), P(ref), m, n, k, epi, 0, st())
+    if not fold:
+        call(ref)
     for flags in flags_list:
+        if fold:
+            break
         if flags & 3:
             continue
         raw.eilev_debug_gemm_flags(flags)
         o.zero_()
-        lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+        call(o)
         torch.cuda.synchronize()
         d = (o.float() - ref.float()).abs().max().item()
         if d != 0.0:
@@ -65,7 +81,7 @@ for name in names:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+                call(o)
             e1.record(); torch.cuda.synchronize()
             if rd:
                 times[flags].append(e0.elapsed_time(e1) / 5)
