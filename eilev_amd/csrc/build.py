@@ -33,11 +33,16 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for src in SOURCES:
+    objs = []
+    # gemm.hip is by far the longest compile (the persistent kernel's instances): two objects, built side by side
+    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES if src != "gemm.hip"]
+    units += [("gemm.hip", "gemm.o", ["-DEILEV_GEMM_PART=1"]), ("gemm.hip", "gemm_ext.o", ["-DEILEV_GEMM_PART=2"])]
+    for src, obj, extra in units:
         s = os.path.join(HERE, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, obj)
+        objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, "-c", s, "-o", o])
+            jobs.append([_hipcc(), *FLAGS, *extra, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -47,11 +52,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn, file=sys.stderr)
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB

@@ -169,6 +169,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
+int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm.hip, object 2 (see EILEV_GEMM_PART)
 int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
                      int cols, float eps, hipStream_t s);
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,

@@ -23,12 +23,19 @@
 #include <type_traits>
 #include <utility>
 
+// This file is compiled as two objects so that its ~5 minutes of hipcc run side by side (build.py): EILEV_GEMM_PART 1 = everything
+// except the fp8-MFMA and LayerNorm-folding instances of the persistent kernel, 2 = only those (launch_pp4_ext); 0 (default) = one object.
+#ifndef EILEV_GEMM_PART
+#define EILEV_GEMM_PART 0
+#endif
+#if EILEV_GEMM_PART != 2
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
 int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
 unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
 int g_gemm_trace_tiles = 0;
 extern "C" int eilev_debug_gemm_trace(void *buf, int tiles) { g_gemm_trace = (unsigned long long *)buf; g_gemm_trace_tiles = tiles; return 0; }
+#endif
 
 namespace {
 
@@ -1039,11 +1046,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #undef PP_BARRIER
 }
 
+constexpr int PP4_SMEM = 2 * 65536 + 8 * 4096;  // two step buffers + 4 KiB of lean-epilogue staging per wave (the general epilogue
+                                                // stages 69.6 KB from step buffer 1 on: 65536 + 69632 < 163840)
+#if EILEV_GEMM_PART != 2
 int launch_pp4(const GemmArgs &g, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
-    constexpr int smem = 2 * 65536 + 8 * 4096;  // two step buffers + 4 KiB of lean-epilogue staging per wave (the general epilogue
-                                                // stages 69.6 KB from step buffer 1 on: 65536 + 69632 < 163840)
+    constexpr int smem = PP4_SMEM;
     if (!attr_set) {
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1055,47 +1064,18 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    if (g.A8) {  // fp8 x fp8 on the fp8 MFMA: byte operands, K halved so that the kernel's 2-byte strides are byte strides
-        static bool attr8 = false;
-        if (!attr8) {
-            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr8 = true;
-        }
-        if (g.epi == 1) return EILEV_E_UNSUPPORTED;
-        GemmArgs h = g;
-        h.A = reinterpret_cast<const bf16 *>(g.A8);
-        h.W = reinterpret_cast<const bf16 *>(g.W8);
-        h.K = g.K / 2; h.lda = g.lda / 2; h.ldw = g.ldw / 2;
-        if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, true>), dim3(grid), dim3(512), smem, s, h);
-        else hipLaunchKernelGGL((gemm_pp4_kernel<0, true>), dim3(grid), dim3(512), smem, s, h);
-        EILEV_LAUNCH_CHECK();
-        return EILEV_OK;
-    }
-    if (g.ln_rows || g.stat_out) {  // LayerNorm-folding variants: consumer (qkv, fc1 + GELU) / producer (proj, fc2 with the residual)
-        static bool attr_ln = false;
-        if (!attr_ln) {
-            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_ln = true;
-        }
-        if (g.epi == 2 || g.out_f32 || (g.ln_rows && (g.resid || g.stat_out || !g.ln_csum || ((uintptr_t)g.ln_csum & 15) || ((uintptr_t)g.ln_rows & 7))) ||
-            (g.stat_out && (!g.resid || g.epi != 0 || g.stat_ld < g.M || ((uintptr_t)g.stat_out & 7))))
-            return EILEV_E_UNSUPPORTED;
-        if (g.stat_out) hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 2>), dim3(grid), dim3(512), smem, s, g);
-        else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp4_kernel<1, false, 1>), dim3(grid), dim3(512), smem, s, g);
-        else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 1>), dim3(grid), dim3(512), smem, s, g);
-        EILEV_LAUNCH_CHECK();
-        return EILEV_OK;
-    }
+    if (g.A8 || g.ln_rows || g.stat_out) return launch_pp4_ext(g, grid, s);  // fp8 MFMA / LayerNorm-folding instances (the other object)
     if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);
     else hipLaunchKernelGGL(gemm_pp4_kernel<0>, dim3(grid), dim3(512), smem, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+#endif
 
+#if EILEV_GEMM_PART == 2
+}  // namespace
+#else
 // ---- w6: one wave per SIMD, continuous K-step stream, lean chunked epilogue ---------------------------------------------
 // 256 x 128 tile, 4 waves of 128 x 64, 3 LDS stages of one K-step of 64 (48 KiB each) + 4 KiB of output staging per wave.
 // Per sub-step of 16 a wave issues 8 MFMAs and, slotted between them, the 6 fragment reads of the next sub-step and its
@@ -2168,3 +2148,44 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
     if (prof_kind >= 0) prof_end(s);
     return rc;
 }
+#endif  // EILEV_GEMM_PART != 2
+
+#if EILEV_GEMM_PART != 1
+// The fp8-MFMA and LayerNorm-folding instances of the persistent kernel (called by launch_pp4 with its grid).
+int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s) {
+    constexpr int smem = PP4_SMEM;
+    if (g.A8) {  // fp8 x fp8 on the fp8 MFMA: byte operands, K halved so that the kernel's 2-byte strides are byte strides
+        static bool attr8 = false;
+        if (!attr8) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr8 = true;
+        }
+        if (g.epi == 1) return EILEV_E_UNSUPPORTED;
+        GemmArgs h = g;
+        h.A = reinterpret_cast<const bf16 *>(g.A8);
+        h.W = reinterpret_cast<const bf16 *>(g.W8);
+        h.K = g.K / 2; h.lda = g.lda / 2; h.ldw = g.ldw / 2;
+        if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, true>), dim3(grid), dim3(512), smem, s, h);
+        else hipLaunchKernelGGL((gemm_pp4_kernel<0, true>), dim3(grid), dim3(512), smem, s, h);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
+    // LayerNorm-folding variants: consumer (qkv, fc1 + GELU) / producer (proj, fc2 with the residual)
+    static bool attr_ln = false;
+    if (!attr_ln) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_ln = true;
+    }
+    if (g.epi == 2 || g.out_f32 || (g.ln_rows && (g.resid || g.stat_out || !g.ln_csum || ((uintptr_t)g.ln_csum & 15) || ((uintptr_t)g.ln_rows & 7))) ||
+        (g.stat_out && (!g.resid || g.epi != 0 || g.stat_ld < g.M || ((uintptr_t)g.stat_out & 7))))
+        return EILEV_E_UNSUPPORTED;
+    if (g.stat_out) hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 2>), dim3(grid), dim3(512), smem, s, g);
+    else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp4_kernel<1, false, 1>), dim3(grid), dim3(512), smem, s, g);
+    else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 1>), dim3(grid), dim3(512), smem, s, g);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+#endif
