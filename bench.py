@@ -297,6 +297,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        # a rank stuck in a collective (a peer that died, a fabric fault) would otherwise sit there until the caller's limit: give the
+        # multi-rank run a wall-clock budget of its own and leave with a message instead
+        import threading
+
+        limit = float(os.environ.get("EILEV_BENCH_TIMEOUT_S", str(600 + 60 * (args.steps + args.warmup))))
+
+        def _give_up():
+            print(f"[rank {rank}] bench.py: no result after {limit:.0f} s with {world} ranks (stuck collective?); exiting", file=sys.stderr, flush=True)
+            os._exit(124)
+
+        wd = threading.Timer(limit, _give_up)
+        wd.daemon = True
+        wd.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_gpu:
             dist.init_process_group("gloo")
