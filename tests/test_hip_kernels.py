@@ -209,3 +209,29 @@ def test_linear_operand_over_2gib(hip):
     for rows in (slice(0, 4096), slice(m // 2, m // 2 + 4096), slice(m - 4096, m)):
         assert (out[rows].float() - ref[rows].float()).abs().max().item() <= 2e-2
     assert torch.equal(out[::997], ref[::997]) or (out[::997].float() - ref[::997].float()).abs().max().item() <= 2e-2
+
+
+def test_attention_frame_joint_tile_variant(hip):
+    """The round-2 experimental frame kernel (probe flag 16: two query tiles per wave share every K / V fragment, the CLS row split over
+    the keys and merged from eight partial softmaxes) against the oracle and the default kernel."""
+    raw = C.CDLL(abi.HIP_LIB_PATH)
+    batch, heads, sq, hd = 18, 16, 257, 88  # 288 pairs > 256 CUs: the ring and the deferred merge run over two pairs
+    D = heads * hd
+    q, k, v = (round_bf16(det_normal(n, (batch, sq, D))) for n in ("qj", "kj", "vj"))
+    ref = np.empty((batch, sq, D), np.float32)
+    pp = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_attention(pp(q), pp(k), pp(v), pp(ref), batch, heads, sq, sq, hd, D, D, D, hd ** -0.5, 0, None, None) == 0
+    dq, dk, dv = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    outs = []
+    for flag in (0, 16):
+        raw.eilev_debug_attn_v1(flag << 1)
+        try:
+            out = torch.empty((batch, sq, D), dtype=torch.bfloat16, device="cuda")
+            assert hip.eilev_attention(P(dq), P(dk), P(dv), P(out), batch, heads, sq, sq, hd, D, D, D, hd ** -0.5, 0, None, stream_ptr()) == 0
+            torch.cuda.synchronize()
+        finally:
+            raw.eilev_debug_attn_v1(0)
+        outs.append(host(out))
+    assert np.abs(outs[1] - ref).max() <= 1e-2 * np.abs(ref).max()
+    assert np.array_equal(outs[0][:, :256], outs[1][:, :256])           # same arithmetic for the 256 patch rows
+    assert np.abs(outs[0][:, 256] - outs[1][:, 256]).max() <= 2.0 ** -7 * np.abs(ref[:, 256]).max()  # CLS row: another summation order
