@@ -843,7 +843,6 @@ __global__ __launch_bounds__(512) void attn_frame2_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_barrier();      \
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
-    const int prow = l15 < 8 ? 2 * l15 : 2 * l15 - 15;
     const int vi = 4 * g + (l15 >> 2);
     const unsigned voff_t = 2 * BUF + (vi < 8 ? 2 * vi : 2 * vi - 15) * RS + (l15 & 3) * 8;
     auto s_issue = [&](unsigned kaddr, bf16x4 (&kf)[2 * KS], auto t_c) {

@@ -161,6 +161,12 @@ struct GemmArgs {
     // of summation downstream: deterministic).  stat_ld = rows of the whole matrix (row-chunked launches shift stat_out, not stat_ld).
     float *stat_out = nullptr;
     int64_t stat_ld = 0;
+    // LayerNorm of the finished output rows, written next to them: ln_out[m] = LN(C[m]) * ln_gamma + ln_beta over the bf16 rows of C.
+    // Decode (M <= 32, split-K): done by the kernel that sums the partials (one launch instead of reduce + LayerNorm, bit-identical);
+    // every other shape: a LayerNorm launch after the GEMM.
+    const bf16 *ln_gamma = nullptr, *ln_beta = nullptr;
+    bf16 *ln_out = nullptr;  // [M, N], leading dimension N
+    float ln_eps = 0.0f;
     int k_slice = 0;                // > 0: split-K launch (gridDim.y slices of k_slice K-steps, f32 output accumulated atomically)
     // probe-only (tools/gemm_trace.py): per-tile phase timestamps of the persistent ping-pong kernel, 8 u64 per (workgroup, wave
     // group, tile): s_memrealtime at loop top / K-loop start / K-loop end / epilogue start / epilogue end, s_memtime at top / end
@@ -174,6 +180,8 @@ int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, b
                      int cols, float eps, hipStream_t s);
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,
                           hipStream_t s);
+int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
+                     int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s);
 int launch_ln_finalize(const float *part, int slots, int64_t rows, int cols, float eps, float *out, hipStream_t s);
 
 struct AttnArgs {

@@ -1941,7 +1941,19 @@ int launch_tiled(const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
+static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, bool *ln_done);
+
+// GemmArgs::ln_out: the LayerNorm of the output rows is either produced by the split-K reduction of the decode GEMV (launch_gemm_core
+// sets ln_done) or by a LayerNorm launch here.
+int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
+    bool ln_done = false;
+    const int rc = launch_gemm_core(g, prof_kind, s, &ln_done);
+    if (rc != EILEV_OK || !g.ln_out || ln_done || g.M <= 0) return rc;
+    if (g.out_f32 || g.patch_group) return EILEV_E_UNSUPPORTED;
+    return launch_layernorm(reinterpret_cast<const bf16 *>(g.C), g.ldc, g.ln_gamma, g.ln_beta, g.ln_out, g.N, g.M, g.N, g.ln_eps, s);
+}
+
+static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, bool *ln_done) {
     GemmArgs g = g_in;
     g.dbg = g_gemm_debug;
     g.trace = g_gemm_trace;
@@ -1975,7 +1987,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
             GemmArgs e = g_in;
             e.W = g.w8_scratch;
             e.W8 = nullptr;
-            return launch_gemm(e, prof_kind, s);
+            return launch_gemm_core(e, prof_kind, s, ln_done);
         }
         g.W = reinterpret_cast<const bf16 *>(g.W8);  // (never dereferenced as bf16: the skinny fp8 kernel reads W8)
     }
@@ -2053,6 +2065,14 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
         else hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nb, ks), dim3(256), 0, s, a);
         EILEV_LAUNCH_CHECK();
         if (ks > 1) {
+            if (g.ln_out && !(g.dbg & 536870912) && !g.out_f32 && g.epi == 0 && g.scale_cols == 0 && (g.N & 7) == 0 && g.N <= 4096 && (g.ldc & 7) == 0 && (!g.resid || (g.ldr & 7) == 0)) {
+                // split-K partials -> row (+ bias + residual) -> its LayerNorm in one launch (norm.hip)
+                const int rc_ln = launch_reduce_ln(a.part, ks, a.mr, g.M, g.N, g.wscale, g.bias, g.resid, g.ldr, reinterpret_cast<bf16 *>(g.C), g.ldc,
+                                                   g.ln_gamma, g.ln_beta, g.ln_out, g.ln_eps, s);
+                if (rc_ln != EILEV_OK) return rc_ln;
+                *ln_done = true;
+                return EILEV_OK;
+            }
             const int total = g.M * g.N;
             hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
             EILEV_LAUNCH_CHECK();
@@ -2073,6 +2093,7 @@ int launch_gemm(const GemmArgs &g_in, int prof_kind, hipStream_t s) {
                 if (g.stat_out) c.stat_out = g.stat_out + r0 * 2;  // stat_ld stays the row count of the whole matrix
                 if (g.ln_rows) c.ln_rows = g.ln_rows + r0 * 2;
                 c.C = g.out_f32 ? (void *)(reinterpret_cast<float *>(g.C) + r0 * g.ldc) : (void *)(reinterpret_cast<bf16 *>(g.C) + r0 * g.ldc);
+                c.ln_out = nullptr;  // (the caller normalises the whole matrix once)
                 const int rc_chunk = launch_gemm(c, prof_kind, s);
                 if (rc_chunk != 0) return rc_chunk;
             }

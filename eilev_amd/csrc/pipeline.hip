@@ -546,21 +546,28 @@ int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &
 }
 
 // out_proj + residual, LN, fc1 + ReLU, fc2 + residual (hf modeling_opt.py:178-179, 226-247)
-int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+// next_ln_w / next_ln_b (decode): the LayerNorm that consumes this block's output (the next block's self_attn_layer_norm, or
+// final_layer_norm) — then b.x leaves as that LayerNorm of b.h, and both LayerNorms of the block ride on the split-K reductions of
+// out_proj / fc2 (GemmArgs::ln_out)
+int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s, const void *next_ln_w = nullptr,
+             const void *next_ln_b = nullptr) {
     const EilevOptLayer *L = &w->layers[l];
     const EilevOptLayerW8 *Q = w->layers_w8 ? &w->layers_w8[l] : nullptr;
     const int D = d->t_hidden, Ft = d->t_ffn;
     GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    g.ln_gamma = (const bf16 *)L->ln2_w; g.ln_beta = (const bf16 *)L->ln2_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
     if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale, b, s));
     RC(launch_gemm(g, 5, s));
-    RC(launch_layernorm(b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, b.x, D, M, D, d->t_eps, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale, b, s));
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (next_ln_w) {
+        g.ln_gamma = (const bf16 *)next_ln_w; g.ln_beta = (const bf16 *)next_ln_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
+    }
     if (Q) RC(use_w8(g, w, Q->fc2_w8, Q->fc2_scale, b, s));
     return launch_gemm(g, 5, s);
 }
@@ -683,14 +690,15 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
     for (int l = 0; l < d->t_layers; ++l) {
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
-        RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
+        if (l == 0) RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
         RC(opt_qkv(d, w, l, b, batch, s));
         // the new token's K / V go into the cache inside the attention kernel (fuse_new): one launch less per layer
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
                               b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
-        RC(opt_tail(d, w, l, b, batch, s));
+        // the block's output goes straight into the LayerNorm that reads it next (the next block's, or final_layer_norm): b.x
+        const bool last = l + 1 == d->t_layers;
+        RC(opt_tail(d, w, l, b, batch, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b));
     }
-    RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, batch, D, d->t_eps, s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
