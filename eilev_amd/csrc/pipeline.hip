@@ -145,7 +145,7 @@ bool dims_ok_opt(const EilevDims *d) {
            (d->t_hidden / d->t_heads) % 8 == 0 && d->t_hidden / d->t_heads <= 128 && d->t_hidden <= 4096;
 }
 
-constexpr size_t kSkinnyScratch = 8u << 20;
+constexpr size_t kSkinnyScratch = 16u << 20;  // halves: split-K partials of the decode GEMVs | flash-decoding partials (batch 32 x 40 heads x 9 key splits x (128 + 2) floats = 6 MB)
 
 }  // namespace
 

@@ -217,3 +217,27 @@ def test_decode_batches_above_32_rows_are_chunked(golden_dir):
     assert many.shape[0] == 10
     for i in range(5):
         assert torch.equal(many[2 * i: 2 * i + 2, : beams.shape[1]], beams)
+
+
+def test_decode_at_the_configs4_shape():
+    """BASELINE configs[4] decode shape: OPT-6.7B widths (32 heads x 128), batch 32, a 32-shot sequence of 1872 positions + 32 new
+    tokens — the flash-decoding partials of that shape (32 x 32 x 8 splits x 130 floats) did not fit the workspace half they were given.
+    One block is enough: the shape, not the depth, is what is exercised; graph and eager decode must agree token for token."""
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.engine import HipEngine
+    from eilev_amd.statedict import state_dict_shapes
+    from eilev_amd.synth import synth_param
+
+    cfg = blip2_config("opt67")
+    cfg.text_config.num_hidden_layers = 1
+    named = {k: torch.from_numpy(synth_param(k, shp, "fanin")).to(torch.bfloat16).cuda()
+             for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
+    eng = HipEngine(cfg, named, device="cuda", parts=("opt",))
+    torch.manual_seed(3)
+    B, L, NEW = 32, 1872, 32
+    emb = (0.5 * torch.randn(B, L, eng.dims.t_hidden, device="cuda")).to(torch.bfloat16)
+    am = torch.ones(B, L, dtype=torch.int32, device="cuda")
+    am[1, :7] = 0
+    a = eng.greedy_decode(emb, am, NEW, eos_id=-1, pad_id=1, use_graph=True)
+    b = eng.greedy_decode(emb, am, NEW, eos_id=-1, pad_id=1, use_graph=False)
+    assert a.shape == (B, NEW) and torch.equal(a, b)
