@@ -472,7 +472,7 @@ class HipEngine:
 
 
     def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
-                    early_stopping=False, num_return_sequences=1):
+                    early_stopping=False, num_return_sequences=1, sampler=None):
         """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
 
         The prompt is prefilled ONCE per sample and its KV cache replicated to the beams; every step reorders the cache
@@ -489,7 +489,7 @@ class HipEngine:
             # independent in beam search); shorter results are padded with pad_id like HF pads finished hypotheses
             per = max(1, 32 // num_beams)
             parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
-                                      pad_id, early_stopping, num_return_sequences) for i in range(0, B, per)]
+                                      pad_id, early_stopping, num_return_sequences, sampler) for i in range(0, B, per)]
             n = max(p.shape[1] for p in parts)
             return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
         cap = L + max_new_tokens
@@ -521,8 +521,18 @@ class HipEngine:
                 self._stream()), "eilev_opt_decode_step")
             return logits
 
+        if sampler is not None:  # multinomial sampling (num_beams == 1): eilev_amd/sampling.py on the same decode step
+            from .sampling import sample_loop
+
+            return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler)
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
                            num_return_sequences)
+
+    def sample_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, temperature=1.0, top_k=50, top_p=1.0,
+                      generator=None):
+        """`generate(do_sample=True)` [hf generation/utils.py `_sample`]: prefill once, then one HIP decode step per drawn token."""
+        return self.beam_decode(inputs_embeds, attention_mask, max_new_tokens, 1, eos_id=eos_id, pad_id=pad_id,
+                                sampler=dict(temperature=temperature, top_k=top_k, top_p=top_p, generator=generator))
 
 
     # ---- encoder-decoder LM (flan-t5) ------------------------------------------------------------------------
@@ -630,7 +640,7 @@ class HipEngine:
         return torch.cat((start, ids), dim=1)
 
     def t5_beam(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1, pad_id=0, start_id=0,
-                early_stopping=False, num_return_sequences=1):
+                early_stopping=False, num_return_sequences=1, sampler=None):
         """Beam search for the encoder-decoder LM [sample default num_beams=5, length_penalty=-1; hf generation/utils.py:3208+]:
         the encoder runs once per sample, its cross K/V are replicated to the beams, every step reorders the self-attention
         cache rows by the surviving beams' parents and runs one decoder step on all rows."""
@@ -659,10 +669,22 @@ class HipEngine:
             steps[0] += 1
             return self.t5_decode(next_tokens.view(R, 1), am, steps[0], skv, cap, ckv, L)[:, 0]
 
-        ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
-                          early_stopping, num_return_sequences)
+        if sampler is not None:
+            from .sampling import sample_loop
+
+            ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler)
+        else:
+            ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
+                              early_stopping, num_return_sequences)
         head = torch.full((ids.shape[0], 1), int(start_id), dtype=torch.int64, device=self.device)
         return torch.cat((head, ids), dim=1)
+
+
+    def t5_sample(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0, temperature=1.0, top_k=50, top_p=1.0,
+                  generator=None):
+        """`generate(do_sample=True)` for the encoder-decoder LM (the decoder start token in front, like t5_greedy / t5_beam)."""
+        return self.t5_beam(inputs_embeds, attention_mask, max_new_tokens, 1, eos_id=eos_id, pad_id=pad_id, start_id=start_id,
+                            sampler=dict(temperature=temperature, top_k=top_k, top_p=top_p, generator=generator))
 
 
 def abi_dtype(t: torch.Tensor) -> int:

@@ -1,0 +1,58 @@
+"""Multinomial sampling over the HIP decode step (host-side plumbing; the step itself — one token through the language model on the
+KV cache — is the HIP kernel path).
+
+What `transformers` does for `generate(do_sample=True, num_beams=1)` [hf generation/utils.py `_sample`; the reference inherits it:
+ref:eilev/model/v2.py:312-322, exercised by ref:tests/model/test_model_v2.py:194]: per step the next-token logits go through the
+warpers in this order — temperature (logits / T), top-k (keep the k largest, rest -inf), top-p (smallest set of tokens whose
+probability mass reaches top_p, at least one kept) — then softmax and one `torch.multinomial` draw per row; rows that produced EOS
+emit the pad id from then on; the loop ends when every row has finished.  HF's defaults when only `do_sample=True` is given:
+temperature 1.0, top_k 50, top_p 1.0."""
+from __future__ import annotations
+
+import torch
+
+
+def warp_logits(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0) -> torch.Tensor:
+    """(rows, vocab) fp32 -> warped scores (filtered entries are -inf)."""
+    scores = logits.float()
+    if temperature is not None and temperature != 1.0:
+        if temperature <= 0:
+            raise ValueError("temperature must be > 0")
+        scores = scores / float(temperature)
+    if top_k and top_k > 0:
+        k = min(int(top_k), scores.shape[-1])
+        kth = torch.topk(scores, k, dim=-1).values[..., -1:]
+        scores = scores.masked_fill(scores < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        if not 0.0 < top_p:
+            raise ValueError("top_p must be in (0, 1]")
+        srt, idx = torch.sort(scores, dim=-1, descending=False)
+        cum = srt.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1.0 - float(top_p))   # the low-probability tail whose mass stays below 1 - top_p
+        remove[..., -1:] = False               # min_tokens_to_keep = 1
+        scores = scores.masked_fill(remove.scatter(-1, idx, remove), float("-inf"))
+    return scores
+
+
+def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id: int = -1, pad_id: int = 0, temperature: float = 1.0,
+                top_k: int = 50, top_p: float = 1.0, generator: torch.Generator | None = None) -> torch.Tensor:
+    """`step(next_tokens (R,), row_src (R,)) -> logits (R, vocab)` is the decode step of engine.beam_decode / t5_beam (row_src is the
+    identity here).  Returns (R, n) new tokens, n <= max_new_tokens (the loop stops once every row has produced EOS, as HF does)."""
+    R = first_logits.shape[0]
+    dev = first_logits.device
+    ident = torch.arange(R, device=dev)
+    unfinished = torch.ones(R, dtype=torch.bool, device=dev)
+    out = []
+    logits = first_logits
+    for t in range(max_new_tokens):
+        probs = warp_logits(logits, temperature, top_k, top_p).softmax(dim=-1)
+        nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, int(pad_id)))
+        out.append(nxt)
+        if eos_id is not None and eos_id >= 0:
+            unfinished = unfinished & (nxt != int(eos_id))
+            if not bool(unfinished.any()):
+                break
+        if t + 1 < max_new_tokens:
+            logits = step(nxt, ident)
+    return torch.stack(out, dim=1)

@@ -127,7 +127,7 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         m.classify(torch.ones(1, 4, dtype=torch.long), torch.ones(2, 3, dtype=torch.long))
     with pytest.raises(NotImplementedError):
-        m.generate(torch.ones(1, 4, dtype=torch.long), do_sample=True)
+        m.generate(torch.ones(1, 4, dtype=torch.long), penalty_alpha=0.1, top_k=2)  # contrastive search
 
 
 def test_c_abi_library_exports_every_declared_symbol():

@@ -1,0 +1,127 @@
+"""`generate(do_sample=True)`: multinomial sampling over the HIP decode step (eilev_amd/sampling.py; ref:tests/model/test_model_v2.py:194
+exercises it on the reference through hf generation/utils.py `_sample`).
+
+CPU: the warpers against `transformers`' own (temperature -> top-k -> top-p), the loop's EOS / pad bookkeeping on a scripted step.
+GPU: top_k = 1 sampling is greedy decoding token for token; a seeded generator reproduces; every drawn token lies in the top-k set of
+the logits the model assigns at that position (recomputed by a teacher-forced prefill)."""
+import numpy as np
+import pytest
+import torch
+
+from eilev_amd.sampling import sample_loop, warp_logits
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p", [(1.0, 50, 1.0), (0.7, 0, 0.9), (1.3, 5, 0.8), (1.0, 1, 1.0), (2.0, 0, 0.3)])
+def test_warpers_equal_transformers(temperature, top_k, top_p):
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(7, 300, generator=g) * 3
+    ref = logits.clone()
+    ids = torch.zeros(7, 1, dtype=torch.long)
+    if temperature != 1.0:
+        ref = TemperatureLogitsWarper(temperature)(ids, ref)
+    if top_k:
+        ref = TopKLogitsWarper(top_k=top_k)(ids, ref)
+    if top_p < 1.0:
+        ref = TopPLogitsWarper(top_p=top_p)(ids, ref)
+    got = warp_logits(logits, temperature, top_k, top_p)
+    assert torch.equal(torch.isinf(got), torch.isinf(ref))
+    keep = ~torch.isinf(ref)
+    assert torch.allclose(got[keep], ref[keep], rtol=1e-6, atol=1e-6)
+
+
+def test_sample_loop_eos_pad_and_greedy_limit():
+    vocab, R = 11, 3
+    script = torch.tensor([[4, 9, 2, 2], [7, 1, 5, 6], [3, 3, 9, 8]])  # row 0 emits EOS (9) at t = 1, row 2 at t = 2, row 1 never
+
+    def logits_for(t):
+        out = torch.full((R, vocab), -5.0)
+        out[torch.arange(R), script[:, t]] = 5.0
+        return out
+
+    calls = []
+
+    def step(nxt, src):
+        assert torch.equal(src, torch.arange(R))
+        calls.append(nxt.clone())
+        return logits_for(len(calls))
+
+    out = sample_loop(step, logits_for(0), 4, eos_id=9, pad_id=0, top_k=1)
+    assert out.tolist() == [[4, 9, 0, 0], [7, 1, 5, 6], [3, 3, 9, 0]]
+    assert [c.tolist() for c in calls] == [[4, 7, 3], [9, 1, 3], [0, 5, 9]]  # finished rows are fed the pad id
+    # every row finished early: the loop stops there (HF returns the shorter sequences)
+    calls.clear()
+    out = sample_loop(step, torch.full((R, vocab), -5.0).index_put((torch.arange(R), torch.tensor([9, 9, 9])), torch.tensor(5.0)), 4,
+                      eos_id=9, pad_id=0, top_k=1)
+    assert out.tolist() == [[9], [9], [9]] and not calls
+
+
+def _prompt(cfg, seed):
+    from eilev_amd.synth import synth_interleaved_ids, synth_pixels
+
+    nq, vocab = cfg.num_query_tokens, cfg.text_config.vocab_size
+    ids, vm = zip(*[synth_interleaved_ids([1, 1], [5, 4], nq, vocab, seed=seed + s) for s in range(3)])
+    px = torch.from_numpy(synth_pixels(6, 2, cfg.vision_config.image_size)).cuda()
+    return px, torch.from_numpy(np.stack(ids)).cuda(), torch.from_numpy(np.stack(vm)).cuda()
+
+
+@pytest.mark.gpu
+def test_hip_sampling_top1_is_greedy_seed_reproduces_and_tokens_are_top_k():
+    from hip_utils import models
+
+    cfg, _, eng = models("mid")
+    px, ids, vm = _prompt(cfg, 11)
+    am = torch.ones_like(ids, dtype=torch.int32)
+    emb = eng.embed_scatter(ids, vm, eng.encode_clips(px))
+    greedy = eng.greedy_decode(emb, am, 8, eos_id=-1, use_graph=False)
+    assert torch.equal(eng.sample_decode(emb, am, 8, eos_id=-1, top_k=1), greedy)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(123)
+    a = eng.sample_decode(emb, am, 8, eos_id=-1, temperature=1.5, top_k=3, generator=g)
+    g.manual_seed(123)
+    b = eng.sample_decode(emb, am, 8, eos_id=-1, temperature=1.5, top_k=3, generator=g)
+    assert torch.equal(a, b) and a.shape == (3, 8)
+    assert not torch.equal(a, greedy)  # temperature 1.5 over the top 3 of a random-weight model: 24 draws all equal to the argmax is ~1e-9
+    # teacher-forced check: token t was drawn from the top 3 of the step's logits -> it is in the top 5 of the prefill's logits there
+    # (prefill and decode kernels differ in summation order; two spare ranks absorb near-ties)
+    table = eng._keep["language_model.model.decoder.embed_tokens.weight"]
+    full = torch.cat([emb, table[a[:, :-1]]], dim=1)
+    am_full = torch.ones(full.shape[:2], dtype=torch.int32, device="cuda")
+    _, logits_all, _ = eng.prefill(full, am_full, all_logits=True, last_logits=False)
+    L = emb.shape[1]
+    top5 = logits_all[:, L - 1:].topk(5, dim=-1).indices
+    assert bool((top5 == a[:, :, None]).any(-1).all())
+
+
+@pytest.mark.gpu
+def test_generate_do_sample_through_the_model_api():
+    from eilev_amd.configs import blip2_config
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+
+    torch.manual_seed(0)
+    cfg = blip2_config("tiny")
+    model = VideoBlipForConditionalGeneration(cfg).to(torch.bfloat16).cuda().eval()
+    px, ids, vm = _prompt(cfg, 3)
+    out = model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, do_sample=True, eos_token_id=None, min_new_tokens=5)
+    assert out.shape == (3, 5) and int(out.min()) >= 0 and int(out.max()) < cfg.text_config.vocab_size
+    same = model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, do_sample=True, top_k=1, min_new_tokens=5)
+    assert torch.equal(same, model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, min_new_tokens=5))
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, num_beams=2, do_sample=True)
+
+
+@pytest.mark.gpu
+def test_t5_sampling_top1_is_beam1_decoding(golden_dir):
+    """Encoder-decoder LM: top_k = 1 sampling walks the same decode step as num_beams = 1 beam search (t5_beam), token for token, and
+    carries the decoder start token in front like t5_greedy."""
+    from hip_utils import load_case, models
+
+    g, meta, px = load_case(golden_dir, "mid_t5_b2")
+    cfg, _, eng = models(meta["config"])
+    t = lambda a: torch.from_numpy(a).cuda()
+    emb = eng.embed_scatter(t(g["input_ids"]), t(g["video_input_mask"]), eng.encode_clips(t(px)))
+    am = t(g["attention_mask"])
+    a = eng.t5_sample(emb, am, 6, eos_id=-1, top_k=1)
+    b = eng.t5_beam(emb, am, 6, 1, eos_id=-1)
+    assert torch.equal(a, b) and int(a[0, 0]) == 0 and a.shape[1] == 7
