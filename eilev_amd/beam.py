@@ -25,8 +25,12 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                eos_id: int = -1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1) -> torch.Tensor:
-    """``first_logits``: (batch, vocab) fp32 from the prefill.  Returns int64 (batch * num_return_sequences, n_generated)."""
+                eos_id: int = -1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None) -> torch.Tensor:
+    """``first_logits``: (batch, vocab) fp32 from the prefill.  Returns int64 (batch * num_return_sequences, n_generated).
+
+    ``sampler`` (``generate(num_beams > 1, do_sample=True)``, hf `_get_top_k_continuations`): the 2K continuations of a step are DRAWN
+    without replacement from softmax(warped log-probabilities + beam scores) over all beams x vocabulary instead of being the top 2K,
+    and keep their draw order (HF lets only the first K drawn finish); everything else is the same bookkeeping."""
     dev = first_logits.device
     B, nb, T = batch, num_beams, max_new_tokens
     V = first_logits.shape[-1]
@@ -47,8 +51,17 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     logits = first_logits.float().repeat_interleave(nb, dim=0)  # (B*nb, V): identical rows, like HF's expanded prefill
     cur = 0
     while True:
-        logp = torch.log_softmax(logits, dim=-1).view(B, nb, V) + run_score[:, :, None]
-        top_lp, top_ix = torch.topk(logp.view(B, nb * V), keep, dim=1)
+        logp = torch.log_softmax(logits, dim=-1)
+        if sampler is not None:
+            from .sampling import warp_logits
+
+            logp = warp_logits(logp, sampler.get("temperature", 1.0), sampler.get("top_k", 50), sampler.get("top_p", 1.0))
+        logp = logp.view(B, nb, V) + run_score[:, :, None]
+        if sampler is not None:
+            top_ix = torch.multinomial(torch.softmax(logp.view(B, nb * V), dim=-1), keep, generator=sampler.get("generator"))
+            top_lp = torch.gather(logp.view(B, nb * V), 1, top_ix)
+        else:
+            top_lp, top_ix = torch.topk(logp.view(B, nb * V), keep, dim=1)
         src = top_ix // V
         tok = top_ix % V
         cand = _take(run_seq, src)

@@ -521,12 +521,12 @@ class HipEngine:
                 self._stream()), "eilev_opt_decode_step")
             return logits
 
-        if sampler is not None:  # multinomial sampling (num_beams == 1): eilev_amd/sampling.py on the same decode step
+        if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step
             from .sampling import sample_loop
 
             return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler)
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
-                           num_return_sequences)
+                           num_return_sequences, sampler=sampler)
 
     def sample_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, temperature=1.0, top_k=50, top_p=1.0,
                       generator=None):
@@ -669,13 +669,13 @@ class HipEngine:
             steps[0] += 1
             return self.t5_decode(next_tokens.view(R, 1), am, steps[0], skv, cap, ckv, L)[:, 0]
 
-        if sampler is not None:
+        if sampler is not None and num_beams == 1:
             from .sampling import sample_loop
 
             ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler)
         else:
             ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
-                              early_stopping, num_return_sequences)
+                              early_stopping, num_return_sequences, sampler=sampler)
         head = torch.full((ids.shape[0], 1), int(start_id), dtype=torch.int64, device=self.device)
         return torch.cat((head, ids), dim=1)
 

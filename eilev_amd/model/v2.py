@@ -8,7 +8,7 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
-Not built (raise ``NotImplementedError``): contrastive / group-beam / beam-sample decoding (greedy, multinomial sampling and beam search are); ``output_attentions`` / ``output_hidden_states`` of the
+Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling are); ``output_attentions`` / ``output_hidden_states`` of the
 Q-Former and the language model inside the full model's ``forward`` (the vision wrapper serves them from a slow path).
 """
 from __future__ import annotations
@@ -428,9 +428,9 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         early_stopping = kw.pop("early_stopping", False)
         num_return = kw.pop("num_return_sequences", 1)
         num_beams = 1 if num_beams is None else int(num_beams)
-        if kw.get("penalty_alpha") or kw.get("num_beam_groups", 1) not in (None, 1) or (do_sample and num_beams > 1):
-            raise NotImplementedError("contrastive / group-beam / beam-sample decoding is not built on the HIP path (greedy, multinomial "
-                                      "sampling and beam search are)")
+        if kw.get("penalty_alpha") or kw.get("num_beam_groups", 1) not in (None, 1):
+            raise NotImplementedError("contrastive / group-beam decoding is not built on the HIP path (greedy, multinomial sampling, beam "
+                                      "search and beam-search sampling are)")
         sampler = None
         if do_sample:  # hf GenerationConfig defaults: temperature 1.0, top_k 50, top_p 1.0
             gen_cfg0 = getattr(self, "generation_config", None)
@@ -476,21 +476,21 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if self._is_t5:
             t = self.config.text_config
             start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
-            if sampler is not None:
+            if sampler is not None and num_beams == 1:
                 return self.engine().t5_sample(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
                                                start_id=int(start), **sampler)
             if num_beams > 1:
                 return self.engine().t5_beam(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
                                              eos_id=int(-1 if eos is None else eos), pad_id=int(pad), start_id=int(start),
-                                             early_stopping=early_stopping, num_return_sequences=int(num_return))
+                                             early_stopping=early_stopping, num_return_sequences=int(num_return), sampler=sampler)
             return self.engine().t5_greedy(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
                                            start_id=int(start))
-        if sampler is not None:
+        if sampler is not None and num_beams == 1:
             return self.engine().sample_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad), **sampler)
         if num_beams > 1:
             return self.engine().beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
                                              eos_id=int(-1 if eos is None else eos), pad_id=int(pad), early_stopping=early_stopping,
-                                             num_return_sequences=int(num_return))
+                                             num_return_sequences=int(num_return), sampler=sampler)
         return self.engine().greedy_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad))
 
     @torch.no_grad()

@@ -57,6 +57,30 @@ def test_sample_loop_eos_pad_and_greedy_limit():
     assert out.tolist() == [[9], [9], [9]] and not calls
 
 
+def test_beam_sampling_with_sharp_distributions_is_beam_search():
+    """Draws without replacement from a distribution whose successive candidates are e^50 apart come out in top-k order: beam-search
+    sampling then walks exactly the path of plain beam search (same bookkeeping, another way of picking the 2K continuations)."""
+    from eilev_amd.beam import beam_search
+
+    V, B, nb, T = 9, 2, 2, 4
+    g = torch.Generator().manual_seed(2)
+    table = torch.randn(64, V, generator=g) * 40.0  # logits of a toy "model": a function of the last token and the step
+
+    def make_step():
+        n = [0]
+
+        def step(tok, src):
+            n[0] += 1
+            return table[(tok * 7 + n[0]) % 64].clone()
+
+        return step
+
+    first = table[:B].clone()
+    ref = beam_search(make_step(), first, B, nb, T, 1.0, -1, 0)
+    got = beam_search(make_step(), first, B, nb, T, 1.0, -1, 0, sampler=dict(temperature=0.1, top_k=0, top_p=1.0, generator=torch.Generator().manual_seed(0)))
+    assert torch.equal(got, ref)
+
+
 def _prompt(cfg, seed):
     from eilev_amd.synth import synth_interleaved_ids, synth_pixels
 
@@ -107,8 +131,10 @@ def test_generate_do_sample_through_the_model_api():
     assert out.shape == (3, 5) and int(out.min()) >= 0 and int(out.max()) < cfg.text_config.vocab_size
     same = model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, do_sample=True, top_k=1, min_new_tokens=5)
     assert torch.equal(same, model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, min_new_tokens=5))
+    bs = model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, num_beams=2, do_sample=True, min_new_tokens=5)  # beam-search sampling
+    assert bs.shape == (3, 5) and int(bs.min()) >= 0 and int(bs.max()) < cfg.text_config.vocab_size
     with pytest.raises(NotImplementedError):
-        model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, num_beams=2, do_sample=True)
+        model.generate(ids, pixel_values=px, video_input_mask=vm, max_new_tokens=5, penalty_alpha=0.1, top_k=2)
 
 
 @pytest.mark.gpu
