@@ -183,3 +183,39 @@ def test_folded_vit_is_as_close_to_fp32_as_the_unfolded_one(cfg_name, frames):
     e_fold, e_plain = rel_rms(folded, ref), rel_rms(plain, ref)
     record_parity(f"ln_fold_vit[{cfg_name}]", folded_vs_fp32=e_fold, unfolded_vs_fp32=e_plain, folded_vs_unfolded=rel_rms(folded, plain))
     assert e_fold <= 1.25 * e_plain + 5e-4, (e_fold, e_plain)
+
+
+@pytest.mark.gpu
+def test_hip_linear_lnfold_with_a_large_row_mean_and_an_outlier_channel():
+    """The statistics are E[x^2] - mean^2 over fp32 partial sums and the mean enters as two bf16 pieces of a rank-1 MFMA slice: rows
+    whose mean is 15 standard deviations away from 0 and a channel 100x larger than the rest (the "massive activation" pattern of ViT
+    residual streams) must still come out at the bf16 noise of layernorm-then-linear."""
+    abi, lib, st, P, dev = _gpu()
+    m, n, k, eps = 520, 1408, 1408, 1e-6
+    x = _rand((m, k), 40, 2.0) + 30.0
+    x[:, 77] *= 100.0
+    x = round_bf16(x)
+    gamma, beta = round_bf16(_rand(k, 41, 0.3) + 1.0), _rand(k, 42, 0.5)
+    w, bias = _rand((n, k), 43, k ** -0.5), _rand(n, 44, 0.5)
+    # the row statistics through the HIP producer itself: x = 0 . w0 + x
+    xd = dev(x)
+    zero_a, zero_w = torch.zeros((m, 64), dtype=torch.bfloat16, device="cuda"), torch.zeros((k, 64), dtype=torch.bfloat16, device="cuda")
+    c = torch.empty((m, k), dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(((k + 63) // 64, m, 2), dtype=torch.float32, device="cuda")
+    rows = torch.empty((m, 2), dtype=torch.float32, device="cuda")
+    abi.check(lib.eilev_linear_stats(P(zero_a), P(zero_w), None, P(xd), P(c), m, k, 64, P(stats), st()), "stats")
+    abi.check(lib.eilev_ln_finalize(P(stats), m, k, C.c_float(eps), P(rows), st()), "finalize")
+    torch.cuda.synchronize()
+    assert torch.equal(c, xd)
+    x64 = x.astype(np.float64)
+    assert np.allclose(rows[:, 1].cpu().numpy(), -x64.mean(1), rtol=1e-5)
+    assert np.allclose(rows[:, 0].cpu().numpy(), 1 / np.sqrt(x64.var(1) + eps), rtol=2e-4)
+    wf, cs, bf = _oracle_fold(w, gamma, beta, bias)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    wfd, bfd, csd = dev(wf), dev(bf), torch.from_numpy(cs).cuda()
+    abi.check(lib.eilev_linear_lnfold(P(xd), P(wfd), P(bfd), P(csd), P(rows), P(out), m, n, k, 0, st()), "lnfold")
+    torch.cuda.synchronize()
+    plain = _oracle_ln_linear(x, gamma, beta, w, bias, eps, 0)
+    got = out.float().cpu().numpy()
+    rel = np.sqrt(((got - plain) ** 2).mean() / (plain ** 2).mean())
+    assert rel < 6e-3, rel
