@@ -2006,7 +2006,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         a.g = g;
         a.mr = g.M <= 16 ? 16 : 32;
         const int nb = (g.N + 15) / 16;
-        int ks = nb >= 384 ? 1 : (512 + nb - 1) / nb;  // >= 1.5 workgroups per CU: no split (and no reduce launch)
+        int ks = nb >= 384 ? 1 : (512 + nb - 1) / nb;  // >= 1.5 workgroups per CU: no split (and no reduce launch); (1024: decode 5.03 -> 5.18 ms/token)
         const int ksteps = (g.K + 31) / 32;
         if (ks > ksteps / 32) ks = ksteps / 32 > 0 ? ksteps / 32 : 1;  // >= 8 K-steps of 32 per wave
         if (ks > 1 && (!g.scratch || (size_t)ks * a.mr * g.N * sizeof(float) > g.scratch_bytes)) ks = 1;
@@ -2022,7 +2022,9 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         // fc1 (640) 2.17 -> 2.30 with 2; the 2560-row matrices and M <= 16 are best with one block: keep >= 240 workgroups
         if (nbsel == 0) {
             nbsel = g_skinny_nb_default;
-            if (g.M > 16) nbsel = nb >= 8 * 240 ? 8 : (nb >= 4 * 240 ? 4 : (nb >= 2 * 240 ? 2 : 1));
+            // (workgroups = blocks x K splits: fc2 of OPT-2.7B has 160 blocks x 4 splits; probe flag 1 << 30: count blocks only, as before)
+            const int wgs = (g.dbg & 1073741824) ? nb : nb * ks;
+            if (g.M > 16) nbsel = wgs >= 8 * 240 ? 8 : (wgs >= 4 * 240 ? 4 : (wgs >= 2 * 240 ? 2 : 1));
         }
         if (nbsel == 7) nbsel = 8;  // probe encoding
         if (nbsel != 2 && nbsel != 4 && nbsel != 8) nbsel = 1;

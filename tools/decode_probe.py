@@ -21,7 +21,7 @@ import ctypes as C
 from eilev_amd import abi
 raw = C.CDLL(abi.HIP_LIB_PATH)
 for rd in range(6):
-    flag = 536870912 if rd % 2 else 0  # odd rounds: split-K reduce and LayerNorm as two launches (the round-1 form)
+    flag = int(os.environ.get("PROBE_FLAG", "536870912")) if rd % 2 else 0  # odd rounds: the probe flag (default: split-K reduce and LayerNorm as two launches)
     raw.eilev_debug_gemm_flags(flag)
     eng._dec_cache = None  # re-capture the decode graph under this setting
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -32,5 +32,5 @@ for rd in range(6):
     torch.cuda.synchronize()
     marks = dict(eng.timing)
     pre = e0.elapsed_time(marks["prefill_done"])
-    print(f"round {rd} ({'reduce + LayerNorm' if flag else 'fused reduce-LayerNorm'}): prefill {pre:.1f} ms, decode {(e0.elapsed_time(e2) - pre) / (NEW - 1):.3f} ms/token", flush=True)
+    print(f"round {rd} ({'probe flag ' + str(flag) if flag else 'default'}): prefill {pre:.1f} ms, decode {(e0.elapsed_time(e2) - pre) / (NEW - 1):.3f} ms/token", flush=True)
 raw.eilev_debug_gemm_flags(0)
