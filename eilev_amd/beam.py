@@ -25,7 +25,8 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                eos_id: int = -1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None) -> torch.Tensor:
+                eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None,
+                min_new_tokens: int = 0) -> torch.Tensor:
     """``first_logits``: (batch, vocab) fp32 from the prefill.  Returns int64 (batch * num_return_sequences, n_generated).
 
     ``sampler`` (``generate(num_beams > 1, do_sample=True)``, hf `_get_top_k_continuations`): the 2K continuations of a step are DRAWN
@@ -34,7 +35,11 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     dev = first_logits.device
     B, nb, T = batch, num_beams, max_new_tokens
     V = first_logits.shape[-1]
-    keep = 2 * nb  # (number of EOS ids (<= 1) + 1) * num_beams, and never less than 2 * num_beams
+    from .sampling import eos_list
+
+    eos = eos_list(eos_id)  # one id, several, or none (hf: `eos_token_id` may be a list)
+    eos_t = torch.tensor(eos, dtype=torch.int64, device=dev) if eos else None
+    keep = max(2, 1 + len(eos)) * nb  # hf generation/utils.py:3285-3286 beams_to_keep
     top_mask = torch.arange(keep, device=dev) < nb
 
     run_seq = torch.full((B, nb, T), pad_id, dtype=torch.int64, device=dev)
@@ -52,6 +57,8 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     cur = 0
     while True:
         logp = torch.log_softmax(logits, dim=-1)
+        if eos_t is not None and cur < int(min_new_tokens):  # MinNewTokensLengthLogitsProcessor acts on the log-probabilities here
+            logp = logp.index_fill(-1, eos_t, float("-inf"))
         if sampler is not None:
             from .sampling import warp_logits
 
@@ -66,7 +73,7 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
         tok = top_ix % V
         cand = _take(run_seq, src)
         cand[:, :, cur] = tok
-        hit = (tok == eos_id) if eos_id >= 0 else torch.zeros_like(tok, dtype=torch.bool)
+        hit = torch.isin(tok, eos_t) if eos_t is not None else torch.zeros_like(tok, dtype=torch.bool)
         if cur + 1 >= T:
             hit = torch.ones_like(hit)
 

@@ -753,416 +753,6 @@ int launch_attn_frame(const AttnArgs &a, hipStream_t s) {
     return EILEV_OK;
 }
 
-template <class F, int... I>
-__device__ __forceinline__ void attn_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    attn_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Frame attention, round-2 EXPERIMENT (probe flag 16; not the default): S = 257 exactly (ViT-g: 256 patches + CLS), hd = 88.  Same LDS
-// images, fragments and exact single-pass softmax as attn_frame_kernel above; what changes is WHO computes what.  Motivation: the
-// phase stamps of that kernel (tools/attn_ts.py) show its S and PV phases bound by LDS bandwidth — every 16-row query tile re-reads the
-// whole K and V image (17 tiles x 2 x 47 KB = 1.6 MB per pair = 12.5 k of the pair's 25 k cycles at 128 B/clk) — and the 17th tile
-// holds ONE valid row.
-//  * 8 waves (two per SIMD, 256 VGPRs each); wave w owns query tiles w and w + 8 and runs them TOGETHER: one K (V) fragment read
-//    feeds the MFMAs of both tiles, S^T of both (2 x 68 fp32) stays in registers: half the LDS traffic;
-//  * query row 256 (tile 16) is split over the KEYS instead: wave w computes its scores against key tiles 2w, 2w + 1 (wave 0 also
-//    tile 16), a partial softmax with its own maximum and a partial O^T (6 MFMAs), leaves (max, sum, O[96]) in a 4-KiB LDS scratch,
-//    and after the next pair's first barrier every wave finishes 12 of the row's 88 outputs from the eight partials (fixed order).
-// Result (544 frames, same box): 584 us against 500 us for attn_frame_kernel, identical outputs up to the CLS row's summation order.
-// With two long phases per barrier interval instead of six short ones the 8 waves run in lock-step: per SIMD and pair the stamps add up
-// to S 6.6 k (= 2 waves x 102 MFMAs x 16 cycles + the LDS time: no overlap), softmax 4.0 k, PV 6.1 k, stores + Q prefetch + CLS part 8 k —
-// the halved LDS traffic (-4 k cycles) is more than eaten by the lost overlap between waves in different phases.  What it would need
-// is two wave groups half a period apart (K / V images of two pairs do not fit in 160 KB of LDS) or hand-interleaved MFMA / VALU
-// streams inside a wave.  Kept: zero-spill structure notes below (opaque lane ids against hoisting, unconditional Q prefetch).
-template <int HD, int NT>
-__global__ __launch_bounds__(512) void attn_frame2_kernel(const AttnArgs a) {
-    constexpr int NW = 8;
-    constexpr int CH = HD / 8, RS = HD * 2;
-    constexpr int NPIECE = (NT * 16 * CH + (12 - CH) + 63) / 64;
-    constexpr int BUF = NPIECE * 1024;
-    constexpr int PPW = (NPIECE + NW - 1) / NW;
-    constexpr int KS = 3, NKS = (NT + 1) / 2, DT = 6;
-    constexpr int SCR = 3 * BUF;  // [NW][128] floats: O[0..95], max * scale * log2 e, sum
-    static_assert(NT == 2 * NW + 1 && HD <= 96 && HD % 8 == 0 && NT * 16 * RS < 65536 - 512, "tile split / ds offset field");
-    static_assert(PPW == 6, "the counted s_waitcnt below assumes 6 DMA pieces per wave");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    lds_char_t *lds = (lds_char_t *)smem;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int S = a.sq;  // == 16 * (NT - 1) + 1 (launcher)
-    const int npairs = a.batch * a.heads;
-    const float sl2 = a.scale * 1.44269504088896340736f;
-
-    auto stage = [&](const bf16 *src, int buf) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
-        const unsigned ld2 = (unsigned)(a.ldk * 2);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));  // opaque: the piece geometry is recomputed per call (a handful of VALU ops), not kept in registers
-#pragma unroll
-        for (int k = 0; k < PPW; ++k) {
-            int i = wid + NW * k;
-            i = i < NPIECE ? i : NPIECE - 1;
-            const int pch = i * 64 + ln;
-            int key = pch / CH;
-            const int c = pch - key * CH;
-            key = key < S ? key : S - 1;
-            attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), (unsigned)key * ld2 + c * 16);
-        }
-    };
-    // Q fragments (3 x 16 bytes per lane) of tiles w, w + 8 and 16, fetched a pair ahead
-    bf16x8 qf[3][KS];
-    auto load_q = [&](int pair, int tile, bf16x8 (&dst)[KS]) {
-        const int b = pair / a.heads, h = pair - b * a.heads;
-        int l15o = l15, go = g;
-        asm volatile("" : "+v"(l15o), "+v"(go));  // (opaque: see stage)
-        const int row = tile * 16 + l15o;
-        // one descriptor per (frame, head): rows past S and head-dim slots past HD read 0 through the bounds / the offset trick below
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs), 0,
-                                                                            (int)(((int64_t)(S - 1) * a.ldq + HD) * 2), 0x00020000);
-        const unsigned rb = row < S ? (unsigned)row * (unsigned)(a.ldq * 2) : 0x7ffffff0u;  // out of bounds -> 0
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_q;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 32 + 4 * go, d1 = d0 + 16;
-            const u32x2_q lo = __builtin_amdgcn_raw_buffer_load_b64(rq, d0 + 4 <= HD ? rb + d0 * 2 : 0x7ffffff0u, 0, 0);
-            const u32x2_q hi = __builtin_amdgcn_raw_buffer_load_b64(rq, d1 + 4 <= HD ? rb + d1 * 2 : 0x7ffffff0u, 0, 0);
-            const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-            dst[ks] = (bf16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-        }
-    };
-#define FA_BARRIER()                       \
-    do {                                   \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-    const int vi = 4 * g + (l15 >> 2);
-    const unsigned voff_t = 2 * BUF + (vi < 8 ? 2 * vi : 2 * vi - 15) * RS + (l15 & 3) * 8;
-    auto s_issue = [&](unsigned kaddr, bf16x4 (&kf)[2 * KS], auto t_c) {
-        constexpr int t = decltype(t_c)::value;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(kf[ks * 2 + hf]) : "v"(kaddr), "i"(t * 16 * RS + ks * 64 + hf * 32));
-    };
-    // wait for the fragments of one key tile (NAFTER younger ds_read_b64 may stay in flight), then one MFMA chain per query tile
-    auto k_wait = [&](bf16x4 (&kf)[2 * KS], auto nafter) {
-        constexpr int NAFTER = decltype(nafter)::value;
-        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]) : "n"(NAFTER));
-    };
-    auto s_mma = [&](const bf16x8 (&q)[KS], const bf16x4 (&kf)[2 * KS]) -> f32x4 {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x4 lo = kf[ks * 2], hi = kf[ks * 2 + 1];
-            const bf16x8 k0 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[ks], acc, 0, 0, 0);
-        }
-        return acc;
-    };
-    auto mask_last = [&](f32x4 &v) {  // keys of tile NT - 1 that do not exist (A row 4 g + r -> key)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ar = 4 * g + r;
-            if ((NT - 1) * 16 + (ar < 8 ? 2 * ar : 2 * ar - 15) >= S) v[r] = -1e30f;
-        }
-    };
-    auto row_offset = [&](f32x4 (&sc)[NT]) -> float {
-        mask_last(sc[NT - 1]);
-        float m4[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
-#pragma unroll
-        for (int t = 0; t < NT; t += 2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m4[r] = t + 1 < NT ? fmaxf(fmaxf(m4[r], sc[t][r]), sc[t + 1][r]) : fmaxf(m4[r], sc[t][r]);
-        float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        return -mx * sl2;
-    };
-    auto sm_tile = [&](const f32x4 &sv, bf16x4 &pv, float nm, f32x2 &la, f32x2 &lb) {
-        const f32x2 x0 = (f32x2){sv[0], sv[1]} * sl2 + nm, x1 = (f32x2){sv[2], sv[3]} * sl2 + nm;
-        const f32x2 p0 = {__builtin_amdgcn_exp2f(x0.x), __builtin_amdgcn_exp2f(x0.y)};
-        const f32x2 p1 = {__builtin_amdgcn_exp2f(x1.x), __builtin_amdgcn_exp2f(x1.y)};
-        la += p0;
-        lb += p1;
-        pv = (bf16x4){(bf16)p0.x, (bf16)p0.y, (bf16)p1.x, (bf16)p1.y};
-    };
-    auto row_sum = [&](f32x2 la, f32x2 lb) -> float {
-        float l = (la.x + la.y) + (lb.x + lb.y);
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        return l;
-    };
-    auto softmax = [&](f32x4 (&sc)[NT], bf16x4 (&pr)[NT]) -> float {
-        const float nm = row_offset(sc);
-        f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) sm_tile(sc[t], pr[t], nm, la, lb);
-        return row_sum(la, lb);
-    };
-    const unsigned vaddr = (unsigned)(uintptr_t)lds + voff_t;
-    auto pv_issue = [&](unsigned va, bf16x4 (&vf)[2 * DT], auto k2_c, auto two_c) {
-        constexpr int k2 = decltype(k2_c)::value;
-        constexpr bool two = decltype(two_c)::value;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vf[2 * dt]) : "v"(va), "i"(2 * k2 * 16 * RS + dt * 32));
-            if constexpr (two)
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vf[2 * dt + 1]) : "v"(va), "i"((2 * k2 + 1) * 16 * RS + dt * 32));
-        }
-    };
-    auto v_wait = [&](bf16x4 (&vf)[2 * DT]) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vf[4]), "+v"(vf[5]), "+v"(vf[6]), "+v"(vf[7]), "+v"(vf[8]),
-                       "+v"(vf[9]), "+v"(vf[10]), "+v"(vf[11]));
-    };
-    auto pv_mma = [&](f32x4 (&o)[DT], bf16x4 p0, bf16x4 p1, const bf16x4 (&vf)[2 * DT], auto two_c) {
-        constexpr bool two = decltype(two_c)::value;
-        constexpr bf16x4 z4 = {0, 0, 0, 0};
-        const bf16x8 pb = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const bf16x4 lo = vf[2 * dt], hi = two ? vf[2 * dt + 1] : z4;
-            const bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, pb, o[dt], 0, 0, 0);
-        }
-    };
-    auto store_o = [&](const f32x4 (&o)[DT], float l, bf16 *ob, int tile) {
-        int l15o = l15, g = lane >> 4;
-        asm volatile("" : "+v"(l15o), "+v"(g));  // (opaque: see stage)
-        const int row = tile * 16 + l15o;
-        const float inv = 1.0f / l;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)ob, 0, (int)(((int64_t)(S - 1) * a.ldo + HD) * 2), 0x00020000);
-        const unsigned ob_off = (unsigned)row * (unsigned)(a.ldo * 2) + ((g & 1) * 16 + (g >> 1) * 8) * 2;
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_o;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            union { bf16x4 v; int w[2]; } e, odd, give, got;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e.v[r] = (bf16)(o[2 * m][r] * inv);
-                odd.v[r] = (bf16)(o[2 * m + 1][r] * inv);
-            }
-            give.v = (g & 1) ? e.v : odd.v;
-            got.w[0] = __shfl_xor(give.w[0], 16, 64);
-            got.w[1] = __shfl_xor(give.w[1], 16, 64);
-            const bf16x4 mine = (g & 1) ? odd.v : e.v;
-            const bf16x4 lo = (g & 1) ? got.v : mine, hi = (g & 1) ? mine : got.v;
-            const int d0 = 32 * m + (g & 1) * 16 + (g >> 1) * 8;
-            const bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            // rows past S and d past HD are dropped by the offset (out of the descriptor's range)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_o, v8), ro, (row < S && d0 + 8 <= HD) ? ob_off + 64 * m : 0x7ffffff0u, 0, 0);
-        }
-    };
-    // the eight partials of query row S - 1 -> its output row (wave NW - 1; the partials were written before the barrier just passed)
-    auto cls_merge = [&](bf16 *obp) {
-        int ln = threadIdx.x & 63;
-        asm volatile("" : "+v"(ln));  // (opaque: see stage)
-        const float *sp = reinterpret_cast<const float *>(smem + SCR);
-        const int d = wid * 12 + (ln < 12 ? ln : 0);  // 8 waves x 12 = 96 >= HD
-        float M = -3.0e38f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) M = fmaxf(M, sp[w * 128 + 96]);
-        float L = 0.f, o0 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float f = __builtin_amdgcn_exp2f(sp[w * 128 + 96] - M);
-            L = fmaf(sp[w * 128 + 97], f, L);
-            o0 = fmaf(sp[w * 128 + d], f, o0);
-        }
-        if (ln < 12 && d < HD) obp[(int64_t)(S - 1) * a.ldo + d] = (bf16)(o0 / L);
-    };
-
-    int pair = blockIdx.x;
-    if (pair >= npairs) return;
-    {
-        const int b = pair / a.heads, h = pair - b * a.heads;
-        stage(a.k + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs, 0);
-    }
-    load_q(pair, wid, qf[0]);
-    load_q(pair, wid + NW, qf[1]);
-    load_q(pair, NT - 1, qf[2]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bf16 *ob_prev = nullptr;
-    using I0 = std::integral_constant<int, 0>;
-    const bool ts_on = (a.dbg & 512) && blockIdx.x == 0 && lane == 0;
-#define FA_TS(ev)                                                                                  \
-    do {                                                                                           \
-        if (ts_on && it < 8) g_attn_ts[(wid * 8 + it) * 16 + (ev)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-    for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
-        const int cur = it & 1;
-        const int b = pair / a.heads, h = pair - b * a.heads;
-        const int pn = pair + gridDim.x;
-        const bool more = pn < npairs;
-        // K(pair) pieces were issued after the previous pair's second barrier; younger than them: 6 output stores and the 18 Q loads
-        // of the tiles this wave works on next: "at most 18 outstanding" = pieces and stores have completed
-        FA_TS(0);
-        if (it > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        FA_BARRIER();  // K(pair) complete in LDS; every wave is done with V / K of the previous pair and has left its partial
-        FA_TS(1);
-        if (it > 0) cls_merge(ob_prev);
-        stage(a.v + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs, 2);
-        unsigned kaddr;
-        {   // (recomputed per pair from the lane id: kept across the loop it is the first thing hipcc spills, and a scratch reload next
-            //  to the V DMA below costs a vmcnt(0))
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int l15o = ln & 15, go = ln >> 4;
-            kaddr = (unsigned)(uintptr_t)lds + cur * BUF + (l15o < 8 ? 2 * l15o : 2 * l15o - 15) * RS + go * 8;
-        }
-        bf16 *ob = a.o + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
-        // query row S - 1 against this wave's keys: tiles 2w, 2w + 1 (wave 0: + tile NT - 1)
-        f32x4 scC[3];
-        bf16x4 prC[3];
-        float mC, lC;
-        {
-            bf16x4 kf[2 * KS];
-            const unsigned kaddr_c = kaddr + (unsigned)wid * (2 * 16 * RS);
-            s_issue(kaddr_c, kf, I0{});
-            k_wait(kf, I0{});
-            scC[0] = s_mma(qf[2], kf);
-            s_issue(kaddr_c, kf, std::integral_constant<int, 1>{});
-            k_wait(kf, I0{});
-            scC[1] = s_mma(qf[2], kf);
-            scC[2] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
-            if (wid == 0) {
-                s_issue(kaddr, kf, std::integral_constant<int, NT - 1>{});
-                k_wait(kf, I0{});
-                scC[2] = s_mma(qf[2], kf);
-                mask_last(scC[2]);
-            }
-            float mx = -1e30f;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, scC[u][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            mC = mx * sl2;
-            f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 3; ++u) sm_tile(scC[u], prC[u], -mC, la, lb);
-            lC = row_sum(la, lb);
-        }
-        f32x4 scA[NT], scB[NT];
-        bf16x4 prA[NT], prB[NT];
-        {   // S^T of both tiles: every key tile's fragments are read once
-            bf16x4 kf[2][2 * KS];
-            s_issue(kaddr, kf[0], I0{});
-            static_for<NT>([&](auto t_c) {
-                constexpr int t = decltype(t_c)::value;
-                if constexpr (t + 1 < NT) {
-                    s_issue(kaddr, kf[(t + 1) & 1], std::integral_constant<int, t + 1>{});
-                    k_wait(kf[t & 1], std::integral_constant<int, 2 * KS>{});
-                } else {
-                    k_wait(kf[t & 1], I0{});
-                }
-                scA[t] = s_mma(qf[0], kf[t & 1]);
-                scB[t] = s_mma(qf[1], kf[t & 1]);
-            });
-        }
-        FA_TS(2);
-        const float lA = softmax(scA, prA);
-        const float lB = softmax(scB, prB);
-        FA_TS(3);
-        FA_TS(4);
-        // V(pair) must be complete in LDS for every wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        FA_BARRIER();
-        FA_TS(5);
-        if (more) {  // K of the next pair streams in under the rest of this pair
-            const int bn = pn / a.heads, hn = pn - bn * a.heads;
-            stage(a.k + (int64_t)bn * a.k_bs + (int64_t)hn * a.k_hs, cur ^ 1);
-        }
-        {   // O^T of both tiles: every V^T fragment is read once
-            f32x4 oA[DT], oB[DT];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oA[dt] = oB[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bf16x4 vf[2 * DT];
-            constexpr bf16x4 z4 = {0, 0, 0, 0};
-            static_for<NKS>([&](auto k_c) {
-                constexpr int k2 = decltype(k_c)::value;
-                constexpr bool two = 2 * k2 + 1 < NT;
-                pv_issue(vaddr, vf, k_c, std::integral_constant<bool, two>{});
-                v_wait(vf);
-                pv_mma(oA, prA[2 * k2], two ? prA[two ? 2 * k2 + 1 : 0] : z4, vf, std::integral_constant<bool, two>{});
-                pv_mma(oB, prB[2 * k2], two ? prB[two ? 2 * k2 + 1 : 0] : z4, vf, std::integral_constant<bool, two>{});
-            });
-            FA_TS(6);
-            store_o(oA, lA, ob, wid);
-            store_o(oB, lB, ob, wid + NW);
-            FA_TS(7);
-        }
-        {   // partial O^T of query row S - 1 over this wave's keys -> scratch
-            f32x4 oC[DT];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oC[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bf16x4 vf[2 * DT];
-            constexpr bf16x4 z4 = {0, 0, 0, 0};
-            pv_issue(vaddr + (unsigned)wid * (2 * 16 * RS), vf, I0{}, std::true_type{});
-            v_wait(vf);
-            pv_mma(oC, prC[0], prC[1], vf, std::true_type{});
-            if (wid == 0) {
-                pv_issue(vaddr, vf, std::integral_constant<int, NKS - 1>{}, std::false_type{});
-                v_wait(vf);
-                pv_mma(oC, prC[2], z4, vf, std::false_type{});
-            }
-            if (l15 == 0) {  // query row 16 (NT - 1) + 0 = S - 1: d = 16 dt + 4 g + r
-                const unsigned sa = (unsigned)(uintptr_t)lds + SCR + wid * 512 + g * 16;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(sa), "v"(oC[dt]), "i"(dt * 64) : "memory");
-                if (g == 0) {
-                    const f32x2 ml = {mC, lC};
-                    asm volatile("ds_write_b64 %0, %1 offset:384" ::"v"(sa), "v"(ml) : "memory");
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        {   // unconditional (the last pair re-reads its own rows): under `if (more)` the old fragments stay live through the whole pair
-            const int pq = more ? pn : pair;
-            load_q(pq, wid, qf[0]);
-            load_q(pq, wid + NW, qf[1]);
-            load_q(pq, NT - 1, qf[2]);
-        }
-        ob_prev = ob;
-        FA_TS(8);
-    }
-    FA_BARRIER();
-    cls_merge(ob_prev);
-#undef FA_TS
-#undef FA_BARRIER
-}
-
-template <int HD, int NT>
-int launch_attn_frame2(const AttnArgs &a, hipStream_t s) {
-    constexpr int CH = HD / 8;
-    constexpr int NPIECE = (NT * 16 * CH + (12 - CH) + 63) / 64;
-    constexpr int smem = 3 * NPIECE * 1024 + 8 * 512;
-    static bool attr_set = false;
-    static int num_cu = 0;
-    if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_frame2_kernel<HD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        int dev = 0;
-        EILEV_HIP_CHECK(hipGetDevice(&dev));
-        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
-    const int npairs = a.batch * a.heads;
-    const int grid = npairs < num_cu ? npairs : num_cu;
-    hipLaunchKernelGGL((attn_frame2_kernel<HD, NT>), dim3(grid), dim3(512), smem, s, a);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-
 template <int NWQ>
 int launch_attn_v2(const AttnArgs &a, hipStream_t s) {
     size_t smem = (size_t)4 * 64 * a.hd * 2 + 256 + (2 * 64 + 2) * sizeof(int);
@@ -1187,7 +777,6 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
     if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && !a.drop_thr && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
         a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll) {
         // probe flag 16 (512: with phase stamps): the round-2 joint-tile kernel — correct, but 17 % SLOWER than the kernel above (see its header)
-        if (a.sq == 257 && (a.dbg & (16 | 512))) return launch_attn_frame2<88, 17>(a, s);  // (probe flag 8: the round-1 kernel)
         return launch_attn_frame<88, 17>(a, s);
     }
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "patch.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "eilev.h")]
+HEADERS = ["common.h", "gemm_a4.h", "gemm_a4_loop.inc", os.path.join("..", "..", "include", "eilev.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 LIB = os.path.join(HERE, "libeilev_hip.so")
@@ -29,6 +29,10 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    gen, inc = os.path.join(HERE, "gen_a4_loop.py"), os.path.join(HERE, "gemm_a4_loop.inc")
+    if _stale(inc, [gen]):  # the hand-scheduled K loop of gemm_a4_kernel as inline-asm text
+        with open(inc, "w") as f:
+            subprocess.check_call([sys.executable, gen], stdout=f)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -36,7 +40,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     objs = []
     # gemm.hip is by far the longest compile (the persistent kernel's instances): two objects, built side by side
     units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES if src != "gemm.hip"]
-    units += [("gemm.hip", "gemm.o", ["-DEILEV_GEMM_PART=1"]), ("gemm.hip", "gemm_ext.o", ["-DEILEV_GEMM_PART=2"])]
+    units += [("gemm.hip", "gemm.o", ["-DEILEV_GEMM_PART=1"]), ("gemm.hip", "gemm_ext.o", ["-DEILEV_GEMM_PART=2"]),
+              ("gemm.hip", "gemm_a4.o", ["-DEILEV_GEMM_PART=3"])]
     for src, obj, extra in units:
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, obj)

@@ -70,30 +70,59 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Exact-erf GELU (hf ACT2FN["gelu"], Blip2MLP) = max(x, 0) - r(|x|) with r(u) = u * Phi(-u), a smooth bump (max 0.17 at u = 0.75)
-// that is below 1.3e-4 beyond u = 4.  r on [0, 4] is a degree-8 polynomial in t = u / 2 - 1 (weighted near-minimax fit, Horner
-// in fp32): max abs error of the GELU 1.1e-4 (relative 2.2e-3 where |y| > 0.05) — the stored activation is bf16 (2^-9 relative),
-// and the reference's own bf16 run evaluates GELU on a pre-activation that was itself rounded to bf16 (an input error of
-// 4e-3 |x|), so the approximation is an order of magnitude inside the reference's own noise.  12 VALU operations per element
-// (min|x|, t, 8 FMAs, max, sub); the degree-12 form used in round 1 (1.5e-6, 16 operations) cost 2 microseconds of VALU time
-// per 256 x 256 tile of the ViT fc1 GEMM with the MFMA pipe idle (tools/gemm_trace.py).  No transcendental, no division.
+// Exact-erf GELU (hf ACT2FN["gelu"], Blip2MLP) = max(x, 0) - r(|x|) with r(u) = u * Phi(-u), a smooth bump (max 0.17 at u = 0.75).
+// Two polynomial forms, no transcendental, no division, Horner in fp32:
+//  * gelu_erf / gelu_erf_pk (everything but the two persistent kernels: Q-Former, training forward, small-tile launches, decode): Phi(-u) on
+//    [0, 5] as a degree-12 polynomial in t = 0.4 u - 1 (weighted minimax fit): max abs error of the GELU 1.5e-6, i.e. below the bf16
+//    rounding of the stored activation everywhere; r < 1.5e-6 beyond u = 5 (x < -5 returns -0.0-ish, approaching 0 like the exact form).
+//  * gelu_erf_n<NP> = the FAST form of the persistent kernels' epilogues (gemm_pp4_kernel, gemm_w6_kernel, gemm_a4_kernel: with a GELU only
+//    the ViT fc1 reaches them — >= 192 tiles of 256 x 128): r itself on [0, 4] as a degree-8
+//    polynomial in t = u / 2 - 1: max abs error 1.1e-4 (relative 2.2e-3 where |y| > 0.05; a constant -1.3e-4 for x < -4).  The stored
+//    activation is bf16 (2^-9 relative) and the reference's own bf16 run evaluates GELU on a pre-activation that was itself rounded
+//    to bf16 (an input error of 4e-3 |x|), so this is an order of magnitude inside the reference's own noise; 12 VALU operations per
+//    element instead of 16: the epilogue runs with the MFMA pipe idle, the difference was worth +2.2 % on the fc1 GEMM (r2 A/B).
+//    End-to-end effect on the logits: profiles/parity_r03.json `gelu_deg8_vs_deg12`.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define EILEV_GELU12_COEFFS                                                                                                 \
+    {6.210111547e-03f, -4.381819814e-02f, 1.368895024e-01f, -2.397004068e-01f, 2.326955497e-01f, -6.489974260e-02f,       \
+     -1.311938316e-01f, 1.613862813e-01f, -2.371504903e-02f, -7.562928647e-02f, 3.900733590e-02f, 1.263864804e-02f,        \
+     -9.870870970e-03f}
+__device__ __forceinline__ float gelu_erf(float x) {
+    constexpr float c[13] = EILEV_GELU12_COEFFS;
+    const float u = fminf(fabsf(x), 5.0f);
+    const float t = fmaf(u, 0.4f, -1.0f);
+    float p = c[12];
+#pragma unroll
+    for (int k = 11; k >= 0; --k) p = fmaf(p, t, c[k]);
+    return fmaf(-u, p, fmaxf(x, 0.0f));
+}
+// 2 * NP elements at a time: independent Horner chains interleaved step by step (a dependent FMA waits ~4 cycles for its predecessor)
+__device__ __forceinline__ float gelu_erf_n1(float x);  // (the fast form on one element: below)
+template <int NP>
+__device__ __forceinline__ void gelu_erf_pk(f32x2 (&x)[NP]) {
+    constexpr float c[13] = EILEV_GELU12_COEFFS;
+    float v[2 * NP], u[2 * NP], t[2 * NP], p[2 * NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) { v[2 * n] = x[n].x; v[2 * n + 1] = x[n].y; }
+#pragma unroll
+    for (int n = 0; n < 2 * NP; ++n) {
+        u[n] = fminf(fabsf(v[n]), 5.0f);
+        t[n] = fmaf(u[n], 0.4f, -1.0f);
+        p[n] = c[12];
+    }
+#pragma unroll
+    for (int k = 11; k >= 0; --k)
+#pragma unroll
+        for (int n = 0; n < 2 * NP; ++n) p[n] = fmaf(p[n], t[n], c[k]);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) x[n] = (f32x2){fmaf(-u[2 * n], p[2 * n], fmaxf(v[2 * n], 0.0f)), fmaf(-u[2 * n + 1], p[2 * n + 1], fmaxf(v[2 * n + 1], 0.0f))};
+}
 #define EILEV_GELU_DEG 8
 #define EILEV_GELU_UMAX 4.0f
 #define EILEV_GELU_COEFFS                                                                                                   \
     {4.543383146e-02f, -1.712931058e-01f, 2.188764488e-01f, 1.158597774e-02f, -3.094834958e-01f, 2.450403219e-01f,         \
      3.056864685e-02f, -8.538186866e-02f, 1.466789586e-02f}
-__device__ __forceinline__ float gelu_erf(float x) {
-    constexpr float c[EILEV_GELU_DEG + 1] = EILEV_GELU_COEFFS;
-    const float u = fminf(fabsf(x), EILEV_GELU_UMAX);
-    const float t = fmaf(u, 2.0f / EILEV_GELU_UMAX, -1.0f);
-    float p = c[EILEV_GELU_DEG];
-#pragma unroll
-    for (int k = EILEV_GELU_DEG - 1; k >= 0; --k) p = fmaf(p, t, c[k]);
-    return fmaxf(x, 0.0f) - p;
-}
-// NP independent elements at a time: NP Horner chains interleaved step by step (a dependent FMA waits ~4 cycles for its
-// predecessor; one chain alone runs at half the VALU rate).  Plain v_fma_f32: the packed f32 forms issue at half rate.
+// NP independent elements at a time: NP Horner chains interleaved step by step.  Plain v_fma_f32: the packed f32 forms issue at half rate.
 template <int NP>
 __device__ __forceinline__ void gelu_erf_n(float (&x)[NP]) {
     constexpr float c[EILEV_GELU_DEG + 1] = EILEV_GELU_COEFFS;
@@ -110,14 +139,11 @@ __device__ __forceinline__ void gelu_erf_n(float (&x)[NP]) {
 #pragma unroll
     for (int n = 0; n < NP; ++n) x[n] = fmaxf(x[n], 0.0f) - p[n];
 }
-template <int NP>
-__device__ __forceinline__ void gelu_erf_pk(f32x2 (&x)[NP]) {
-    float v[2 * NP];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) { v[2 * n] = x[n].x; v[2 * n + 1] = x[n].y; }
-    gelu_erf_n<2 * NP>(v);
-#pragma unroll
-    for (int n = 0; n < NP; ++n) x[n] = (f32x2){v[2 * n], v[2 * n + 1]};
+
+__device__ __forceinline__ float gelu_erf_n1(float x) {
+    float v[1] = {x};
+    gelu_erf_n<1>(v);
+    return v[0];
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -176,6 +202,7 @@ struct GemmArgs {
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm.hip, object 2 (see EILEV_GEMM_PART)
+int launch_a4(const GemmArgs &g, hipStream_t s);                    // gemm.hip, object 3: gemm_a4.h
 int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
                      int cols, float eps, hipStream_t s);
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,

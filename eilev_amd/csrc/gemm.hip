@@ -28,7 +28,7 @@
 #ifndef EILEV_GEMM_PART
 #define EILEV_GEMM_PART 0
 #endif
-#if EILEV_GEMM_PART != 2
+#if EILEV_GEMM_PART < 2
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
 int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
@@ -89,7 +89,8 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
 // loop): (a) residual rows -> LDS (coalesced); (b) acc + bias, activation, + residual -> bf16 in place;
 // (c) rows -> HBM.  Only the owning wave touches its region: no workgroup barrier.  The rare variants (fp32
 // logits, q pre-scaling, patch-embedding row remap, tile tails) are wave-uniform branches around the hot path.
-template <int WM, int WN, int EPI, int IBEG = 0, int IEND = WM / 32, int LN = 0>
+// FASTG: the degree-8 GELU of the persistent ViT kernel (common.h); every other kernel evaluates the degree-12 form.
+template <int WM, int WN, int EPI, int IBEG = 0, int IEND = WM / 32, int LN = 0, bool FASTG = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[WM / 32][WN / 32], char *smem, int m0, int n0,
                                               int wm, int wn, int wid, int lane) {
     constexpr int TN = WN / 32;
@@ -240,7 +241,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
                     x[2 * i] = (f32x2){v[i][0], v[i][1]};
                     x[2 * i + 1] = (f32x2){v[i][2], v[i][3]};
                 }
-                gelu_erf_pk<2 * NI>(x);
+                if constexpr (FASTG) {
+                    float y[4 * NI];
+#pragma unroll
+                    for (int i = 0; i < 2 * NI; ++i) { y[2 * i] = x[i].x; y[2 * i + 1] = x[i].y; }
+                    gelu_erf_n<4 * NI>(y);
+#pragma unroll
+                    for (int i = 0; i < 2 * NI; ++i) x[i] = (f32x2){y[2 * i], y[2 * i + 1]};
+                } else gelu_erf_pk<2 * NI>(x);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     v[i][0] = x[2 * i].x; v[i][1] = x[2 * i].y; v[i][2] = x[2 * i + 1].x; v[i][3] = x[2 * i + 1].y;
@@ -318,6 +326,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[W
     }
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+
+#if EILEV_GEMM_PART == 3
+// ---- object 3 (gemm_a4.hip): the one-wave-per-SIMD 128 x 128 kernel with the hand-scheduled K loop ----------------------------------
+#include "gemm_a4.h"
+}  // namespace
+
+int launch_a4(const GemmArgs &g, hipStream_t s) {
+    static int num_cu = 0, var = -1;
+    if (!num_cu) {
+        int dev = 0;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    if (var < 0) {  // probe-only: schedule variant of the K loop (gen_a4_loop.py VARIANTS)
+        const char *e = getenv("EILEV_A4_VAR");
+        var = e ? atoi(e) & 3 : 1;
+    }
+    if (g.K % 64 || g.K < 192 || g.out_f32 || g.patch_group || g.A8 || g.W8 || g.ln_rows || g.stat_out) return EILEV_E_UNSUPPORTED;
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    if (g.epi == 1) return launch_a4_e<1>(g, grid, var, s);
+    if (g.epi == 2) return launch_a4_e<2>(g, grid, var, s);
+    return launch_a4_e<0>(g, grid, var, s);
+}
+#else  // EILEV_GEMM_PART != 3: everything else
 template <int BM, int BN, int NWM, int NWN, int EPI>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs g) {
     constexpr int NW = NWM * NWN, NT = 64 * NW;
@@ -423,7 +457,6 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const GemmArgs 
 // the XOR swizzle is applied to the per-lane SOURCE address instead (lane p of an 8-row x 128-byte piece
 // fetches chunk (p & 7) ^ f(row)); fragment reads use the same involution.  Rows past M / N are clamped
 // to the last valid row (their products are never stored).
-typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // One 1-KiB LDS-DMA piece through a buffer descriptor: lane i fetches 16 bytes at base + voff + soff and the wave
@@ -609,6 +642,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, MINW) void gemm_glds_kernel(const G
 // half 2s and waited for in the read phase of half 2s + 1.
 // LN: 0 plain; 1 the A operand is a raw residual stream whose LayerNorm is folded into W / bias (GemmArgs::ln_rows, no residual input);
 // 2 residual epilogue that also emits the row statistics of what it writes (GemmArgs::stat_out).
+#ifndef EILEV_PP4_DEEP
+#define EILEV_PP4_DEEP 1
+#endif
 template <int EPI, bool F8 = false, int LN = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
@@ -966,45 +1002,54 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         const int nsd = (g.dbg & 2) ? 1 : ns;
         const bool half_tile = n0 + 128 >= g.N && !(g.dbg & 524288);
         // one K-step = two half-steps; FIRST (compile-time) marks the tile's first K-step, whose first 16 MFMAs take C = bias / 0
-        auto kstep = [&](int st, auto first_c) {
+        // DMA schedule (round 3).  A step buffer is free once BOTH wave groups have read its second half; the early group (E) gets
+        // there one barrier interval before the late group (L).  r2 issued step st + 1 in the read phase of half 0 of step st and
+        // waited for it in the read phase of half 1: 3 intervals (~1500 shader clocks, 0.9 us) between issue and wait, less than a
+        // loaded L2 miss takes.  Now both groups get 4 intervals (a whole K-step): E issues as before but waits at the END of its
+        // second MFMA phase; L issues step st + 2 at the end of its read phase of (st, half 1) — the buffer of step st is free for
+        // it then — and waits for it a whole K-step later at the same place.
+        auto kstep = [&](int st, auto first_c, auto ht_c) {
             constexpr bool FIRST = decltype(first_c)::value;
-            read_half(st, 0);
-            if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1);
-            if constexpr (FIRST && LN == 1) acc_prep();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            if constexpr (FIRST && LN == 1) acc_init();
-            mma_half();
-            PP_BARRIER();
-            read_half(st, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            mma_half();
-            PP_BARRIER();
-        };
-        auto kstep_ht = [&](int st, auto first_c) {
-            constexpr bool FIRST = decltype(first_c)::value;
-            const bool w_mine = wid < NW / 2;
-            read_half_ht(st, 0);
+            constexpr bool HT = decltype(ht_c)::value;
+            const bool w_mine = !HT || wid < NW / 2;
+            if constexpr (HT) read_half_ht(st, 0); else read_half(st, 0);
+#if EILEV_PP4_DEEP
+            if (!late) {
+                if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
+            } else if (FIRST && !pre1 && ns > 1) stage_step(1, w_mine);
+#else
             if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
+#endif
             if constexpr (FIRST && LN == 1) acc_prep();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
             if constexpr (FIRST && LN == 1) acc_init();
-            mma_half_ht();
+            if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();
-            read_half_ht(st, 1);
+            if constexpr (HT) read_half_ht(st, 1); else read_half(st, 1);
+#if EILEV_PP4_DEEP
+            if (late) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                if (st + 2 < ns) stage_step(st + 2, w_mine);
+            } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            if constexpr (HT) mma_half_ht(); else mma_half();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+#else
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
             PP_BARRIER();
-            mma_half_ht();
+            if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();
+#endif
         };
         if (half_tile) {
-            kstep_ht(0, std::true_type{});
-            for (int st = 1; st < nsd; ++st) kstep_ht(st, std::false_type{});
+            kstep(0, std::true_type{}, std::true_type{});
+            for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::true_type{});
         } else {
-            kstep(0, std::true_type{});
-            for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{});
+            kstep(0, std::true_type{}, std::false_type{});
+            for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::false_type{});
         }
         stamp(2);
         if (!late) PP_BARRIER();
@@ -1034,10 +1079,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             else if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{});
             else lean_epilogue(cm0, cn0, std::false_type{});
         } else if (half_tile) {
-            gemm_epilogue<64, 64, EPI, 0, 2, LN>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
+            gemm_epilogue<64, 64, EPI, 0, 2, LN, true>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
         } else {
-            gemm_epilogue<WM, WN, EPI, 0, TM / 2, LN>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
-            gemm_epilogue<WM, WN, EPI, TM / 2, TM, LN>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            gemm_epilogue<WM, WN, EPI, 0, TM / 2, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            gemm_epilogue<WM, WN, EPI, TM / 2, TM, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
         }
         stamp(4);
         stamp(6, true);
@@ -2126,7 +2171,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     // fewer tiles (192-511 halves: 17-34 frames) the one-wave-per-SIMD kernel alone wins (fc2 at 4369 rows: 104 -> 77 us; pp4 124)
     if (cfg == 3 && g.K % BK == 0 && !(g.dbg & 16384)) { cfg = 1; wide_tiles = true; }
     if (cfg == 2 && w6_ok && force == 0 && !(g.dbg & (16384 | 2097152 | 4))) { cfg = 1; wide_tiles = true; }
-    if (force == 9) cfg = 1;  // probe: persistent kernel regardless of the shape
+    if (force == 9 || force == 10) cfg = 1;  // probe: persistent kernel regardless of the shape
     if (force == 13 || force == 14 || force == 15) cfg = 4;  // probe: 64x128 / 128x128 tiles / split-K
     else if (force >= 1 && force <= 4) cfg = force;
     // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): its smaller tiles balance better when there are fewer than
@@ -2134,7 +2179,9 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     // (qkv +5 %, OPT out_proj +3 %)
     const int64_t tiles256 = tm256 * ceil_div64(g.N, 256);
     const bool w6_pick = cfg == 1 && tiles256 < 1024;
-    if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
+    if (force == 10 && g.K % 64 == 0 && g.K >= 192 && !g.out_f32 && g.patch_group == 0)
+        rc = launch_a4(g, s);  // probe: one wave per SIMD, 128 x 128 per wave, hand-scheduled K loop (gemm_a4.h)
+    else if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
         rc = launch_w6(g, s);
     else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
@@ -2212,3 +2259,4 @@ int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s) {
     return EILEV_OK;
 }
 #endif
+#endif  // EILEV_GEMM_PART != 3

@@ -20,7 +20,7 @@ def _ptr(t):
 class HipEngine:
     """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
 
-    def __init__(self, config, named_tensors: dict, device=None, parts=None, lm_weights: str = "bf16"):
+    def __init__(self, config, named_tensors: dict, device=None, parts=None, lm_weights: str = "bf16", vit_ln_fold: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = abi.load_hip()
@@ -48,8 +48,10 @@ class HipEngine:
         self._load(named_tensors)
         if lm_weights != "bf16":
             self._quantize_opt(act_fp8=lm_weights == "fp8_mfma")
-        if "vit" in self.parts:
-            self._fold_vit_layernorms()
+        # LayerNorm folding of the ViT blocks: the folded qkv / fc1 copies (+1.1 GB at ViT-g) are built lazily by the first
+        # launch large enough to use them (>= 65536 token rows); vit_ln_fold=False keeps the LayerNorm kernels for every launch
+        self.vit_ln_fold = bool(vit_ln_fold)
+        self._vit_folded = False
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
 
     # ---- weights ------------------------------------------------------------------------------------
@@ -135,10 +137,16 @@ class HipEngine:
         self._w8_keep = (keep, expand)
         abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb, act_fp8=act_fp8)
 
+    def ensure_vit_fold(self):
+        """Build the folded qkv / fc1 copies now (normally done by the first launch of >= 65536 token rows); no-op when folding is off."""
+        if self.vit_ln_fold and not self._vit_folded:
+            self._fold_vit_layernorms()
+
     def _fold_vit_layernorms(self):
         """layer_norm1 / layer_norm2 of every ViT block folded into qkv / fc1 (`eilev_fold_layernorm`, include/eilev.h ABI 9): large
         encode launches then run without LayerNorm kernels.  +1.1 GB of device memory at ViT-g (a second copy of qkv / fc1)."""
         d = self.dims
+        self._vit_folded = True
         if d.v_hidden % 64 or d.v_inter % 64:
             return
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -185,6 +193,8 @@ class HipEngine:
         out = torch.empty((N, T * self.tokens_per_frame, d.v_hidden), dtype=torch.bfloat16, device=self.device)
         pool = torch.empty((N, T, d.v_hidden), dtype=torch.bfloat16, device=self.device) if want_pooler else None
         step = max(1, max_frames_per_call // T)
+        if min(N, step) * T * self.tokens_per_frame >= 65536:
+            self.ensure_vit_fold()
         dt = abi_dtype(px)
         for n0 in range(0, N, step):
             n1 = min(N, n0 + step)
@@ -472,7 +482,7 @@ class HipEngine:
 
 
     def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
-                    early_stopping=False, num_return_sequences=1, sampler=None):
+                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0):
         """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
 
         The prompt is prefilled ONCE per sample and its KV cache replicated to the beams; every step reorders the cache
@@ -489,7 +499,7 @@ class HipEngine:
             # independent in beam search); shorter results are padded with pad_id like HF pads finished hypotheses
             per = max(1, 32 // num_beams)
             parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
-                                      pad_id, early_stopping, num_return_sequences, sampler) for i in range(0, B, per)]
+                                      pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens) for i in range(0, B, per)]
             n = max(p.shape[1] for p in parts)
             return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
         cap = L + max_new_tokens
@@ -526,7 +536,7 @@ class HipEngine:
 
             return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler)
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
-                           num_return_sequences, sampler=sampler)
+                           num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens)
 
     def sample_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, temperature=1.0, top_k=50, top_p=1.0,
                       generator=None):
@@ -640,7 +650,7 @@ class HipEngine:
         return torch.cat((start, ids), dim=1)
 
     def t5_beam(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1, pad_id=0, start_id=0,
-                early_stopping=False, num_return_sequences=1, sampler=None):
+                early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0):
         """Beam search for the encoder-decoder LM [sample default num_beams=5, length_penalty=-1; hf generation/utils.py:3208+]:
         the encoder runs once per sample, its cross K/V are replicated to the beams, every step reorders the self-attention
         cache rows by the surviving beams' parents and runs one decoder step on all rows."""
@@ -648,8 +658,11 @@ class HipEngine:
 
         # hf generation/utils.py:3319 `output_fill_value = pad_token_id or eos_token_id[0] ...`: a pad id of 0 (T5) is falsy,
         # so finished hypotheses are padded with the EOS id
-        if pad_id == 0:
-            pad_id = eos_id if eos_id >= 0 else -1
+        if pad_id == 0 and num_beams > 1:
+            from .sampling import eos_list
+
+            e = eos_list(eos_id)
+            pad_id = e[0] if e else -1
         d = self.t5dims
         enc = self.t5_encode(inputs_embeds, attention_mask)
         B, L, _ = enc.shape
@@ -675,7 +688,7 @@ class HipEngine:
             ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler)
         else:
             ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
-                              early_stopping, num_return_sequences, sampler=sampler)
+                              early_stopping, num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens)
         head = torch.full((ids.shape[0], 1), int(start_id), dtype=torch.int64, device=self.device)
         return torch.cat((head, ids), dim=1)
 

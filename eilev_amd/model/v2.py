@@ -187,7 +187,7 @@ class VideoBlipVisionModel(nn.Module):
             last, pooled = self._engine().vit(pixel_values, want_pooler=True)
         last, pooled = last.to(dtype), pooled.to(dtype)
         if return_dict is False:
-            return tuple(v for v in (last, pooled, hidden, attn) if v is not None)
+            return (last, pooled, hidden, attn)  # fixed 4-tuple with None placeholders, as ref:eilev/model/v2.py:103
         return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=pooled, hidden_states=hidden, attentions=attn)
 
 
@@ -254,17 +254,25 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         else:
             lm.lm_head.weight = lm.model.decoder.embed_tokens.weight
 
+    def _preprocess_accelerate(self):
+        """ref:eilev/model/v2.py:276-278 calls this when `accelerate` attached an `hf_device_map`.  The HIP engine keeps ONE bf16 copy of
+        all weights on the model's device, so there is nothing to re-home: a no-op (a map that spreads the model over several devices
+        is refused when the engine is built: every parameter must live on one AMD GPU)."""
+        return None
+
     # ---- engine ------------------------------------------------------------------------------------------
     def engine(self):
         """bf16 device copy of the weights + the HIP library; rebuilt when a parameter changed (optimizer step,
         load_state_dict, .to())."""
         lm_weights = getattr(self, "hip_lm_weights", "bf16")  # "fp8": e4m3 weight-only OPT linears (set the attribute before use)
-        key = (_params_key(self), lm_weights)
+        ln_fold = bool(getattr(self, "hip_vit_ln_fold", True))  # False: large ViT launches keep their LayerNorm kernels (DESIGN 3f)
+        key = (_params_key(self), lm_weights, ln_fold)
         if self._hip is None or self._hip[0] != key:
             from ..engine import HipEngine
 
             _require_gpu(self.query_tokens, type(self).__name__)
-            self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device, lm_weights=lm_weights))
+            self._hip = (key, HipEngine(self.config, dict(self.state_dict()), device=self.query_tokens.device, lm_weights=lm_weights,
+                                        vit_ln_fold=ln_fold))
         return self._hip[1]
 
     def _encode(self, pixel_values, input_ids, video_input_mask, vision_debug=(False, False)):
@@ -291,7 +299,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
 
         With ``labels``, autograd enabled and at least one trainable parameter (what `Trainer` does for train_v2:
         ref:scripts/general/train_v2.py:124-130, 207-217) the call returns a loss with a gradient, computed by the training
-        graph of eilev_amd/train.py (logits are not materialised on that route); dropout is applied in ``train()`` mode only.
+        graph of eilev_amd/train.py (logits come from the same forward, detached); dropout is applied in ``train()`` mode only.
         Otherwise (no labels, ``torch.no_grad()``, or nothing trainable) it runs the inference kernels without autograd."""
         # the differentiable route is chosen by what the CALL needs (labels, autograd on, a train_v2-style trainable set), see
         # _wants_graph: `model.eval()` + `loss.backward()` (fine-tuning with dropout off) gets a loss with a graph too; the module
@@ -329,16 +337,20 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         seed = (torch.initial_seed() * 1000003 + self._hip_train_calls) & 0xFFFFFFFF
         graph = TrainGraph(cached[1], params, dropout=self.training and getattr(self, "hip_train_dropout", True), seed=seed)
         loss = graph.loss(input_ids, attention_mask, pixel_values, video_input_mask, labels)
+        # the reference's output always carries the logits (ref:eilev/model/v2.py:239-252): lm_head over the hidden states this very
+        # forward produced, outside the graph (one GEMM, ~0.3 ms and 96 MB per 960-token sample at OPT-2.7B);
+        # `model.hip_train_logits = False` skips them (Trainer only consumes the loss)
+        logits = graph.logits().to(self.dtype) if getattr(self, "hip_train_logits", True) else None
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
-        if not return_dict:
-            return (loss,)
         if self._is_t5:
             from transformers.modeling_outputs import Seq2SeqLMOutput
 
-            lm_out = Seq2SeqLMOutput(loss=loss, logits=None)
+            lm_out = Seq2SeqLMOutput(loss=loss, logits=logits)
         else:
-            lm_out = CausalLMOutputWithPast(loss=loss, logits=None)
-        return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=None, vision_outputs=None, qformer_outputs=None,
+            lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
+        if not return_dict:
+            return (loss, logits, None, None, lm_out)
+        return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=logits, vision_outputs=None, qformer_outputs=None,
                                                         language_model_outputs=lm_out)
 
     @torch.no_grad()
@@ -421,6 +433,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         assert not (input_ids is None and pixel_values is None)
         if pixel_values is not None:
             assert video_input_mask is not None
+        if hasattr(self, "hf_device_map"):
+            self._preprocess_accelerate()
         kw = dict(generate_kwargs)
         num_beams = kw.pop("num_beams", 1)
         do_sample = kw.pop("do_sample", False)
@@ -450,48 +464,61 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                 max_new = int(max_len) - 1  # encoder-decoder: max_length counts the decoder tokens incl. the start token
             else:
                 max_new = int(max_len) - input_ids.shape[1]
-        min_new = kw.pop("min_new_tokens", 0) or 0
+        min_new = int(kw.pop("min_new_tokens", 0) or 0)
         gen_cfg = getattr(self, "generation_config", None)
         eos = kw.pop("eos_token_id", getattr(gen_cfg, "eos_token_id", None) if gen_cfg is not None else None)
         if eos is None:
             eos = self.config.text_config.eos_token_id
-        if isinstance(eos, (list, tuple)):
-            if len(eos) != 1:
-                raise NotImplementedError("several eos_token_id values")
-            eos = eos[0]
+        from ..sampling import eos_list
+
+        eos_ids = eos_list(eos)  # hf accepts an int or a list of ids; any of them finishes a row
         pad = kw.pop("pad_token_id", None)
         if pad is None:
-            pad = self.config.text_config.pad_token_id if self.config.text_config.pad_token_id is not None else eos
+            pad = self.config.text_config.pad_token_id if self.config.text_config.pad_token_id is not None else (eos_ids[0] if eos_ids else 0)
         if min_new >= max_new:
-            eos = -1  # EOS can never fire before the budget is exhausted
-        elif min_new > 0:
-            raise NotImplementedError("0 < min_new_tokens < max_new_tokens")
+            eos_ids = []  # EOS can never fire before the budget is exhausted
+            min_new = 0
         for k in ("use_cache", "return_dict_in_generate", "output_scores"):
             kw.pop(k, None)
         if kw:
             raise NotImplementedError(f"unsupported generate() arguments on the HIP path: {sorted(kw)}")
+        if num_beams == 1 and not do_sample and int(num_return) != 1:
+            raise ValueError("Greedy methods without beam search do not support `num_return_sequences` different than 1")
+        if num_beams > 1 and int(num_return) > num_beams:
+            raise ValueError("`num_return_sequences` has to be smaller or equal to `num_beams`")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         emb, _, _ = self._encode(pixel_values, input_ids, video_input_mask)
+        if sampler is not None and num_beams == 1 and int(num_return) > 1:
+            # hf `_expand_inputs_for_generation`: every prompt is repeated num_return_sequences times (rows of one prompt adjacent)
+            emb = emb.repeat_interleave(int(num_return), dim=0)
+            attention_mask = attention_mask.repeat_interleave(int(num_return), dim=0)
+        # the captured device step knows ONE eos id and no minimum length; several ids or 0 < min_new_tokens < max_new_tokens run the
+        # same HIP decode step with the stopping rule applied by the host loop (eilev_amd/sampling.py, beam.py)
+        eos1 = eos_ids[0] if eos_ids else -1
+        host_rules = len(eos_ids) > 1 or min_new > 0
+        eng = self.engine()
         if self._is_t5:
             t = self.config.text_config
             start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
-            if sampler is not None and num_beams == 1:
-                return self.engine().t5_sample(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
-                                               start_id=int(start), **sampler)
             if num_beams > 1:
-                return self.engine().t5_beam(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
-                                             eos_id=int(-1 if eos is None else eos), pad_id=int(pad), start_id=int(start),
-                                             early_stopping=early_stopping, num_return_sequences=int(num_return), sampler=sampler)
-            return self.engine().t5_greedy(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad),
-                                           start_id=int(start))
-        if sampler is not None and num_beams == 1:
-            return self.engine().sample_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad), **sampler)
+                return eng.t5_beam(emb, attention_mask, int(max_new), num_beams, float(length_penalty), eos_id=eos_ids if host_rules else eos1,
+                                   pad_id=int(pad), start_id=int(start), early_stopping=early_stopping,
+                                   num_return_sequences=int(num_return), sampler=sampler, min_new_tokens=min_new)
+            if sampler is not None or host_rules:
+                rule = dict(sampler) if sampler is not None else dict(greedy=True)
+                return eng.t5_beam(emb, attention_mask, int(max_new), 1, eos_id=eos_ids if host_rules else eos1, pad_id=int(pad),
+                                   start_id=int(start), sampler=dict(rule, min_new_tokens=min_new))
+            return eng.t5_greedy(emb, attention_mask, int(max_new), eos_id=int(eos1), pad_id=int(pad), start_id=int(start))
         if num_beams > 1:
-            return self.engine().beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty),
-                                             eos_id=int(-1 if eos is None else eos), pad_id=int(pad), early_stopping=early_stopping,
-                                             num_return_sequences=int(num_return), sampler=sampler)
-        return self.engine().greedy_decode(emb, attention_mask, int(max_new), eos_id=int(-1 if eos is None else eos), pad_id=int(pad))
+            return eng.beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty), eos_id=eos_ids if host_rules else eos1,
+                                   pad_id=int(pad), early_stopping=early_stopping, num_return_sequences=int(num_return), sampler=sampler,
+                                   min_new_tokens=min_new)
+        if sampler is not None or host_rules:
+            rule = dict(sampler) if sampler is not None else dict(greedy=True)
+            return eng.beam_decode(emb, attention_mask, int(max_new), 1, eos_id=eos_ids if host_rules else eos1, pad_id=int(pad),
+                                   sampler=dict(rule, min_new_tokens=min_new))
+        return eng.greedy_decode(emb, attention_mask, int(max_new), eos_id=int(eos1), pad_id=int(pad))
 
     @torch.no_grad()
     def classify(self, prompt_input_ids, class_input_ids, prompt_attention_mask=None, pixel_values=None,

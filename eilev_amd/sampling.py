@@ -34,23 +34,44 @@ def warp_logits(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 0, 
     return scores
 
 
-def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id: int = -1, pad_id: int = 0, temperature: float = 1.0,
-                top_k: int = 50, top_p: float = 1.0, generator: torch.Generator | None = None) -> torch.Tensor:
+def eos_list(eos_id) -> list:
+    """`eos_token_id` as HF accepts it (None / negative = disabled, an int, or several ids) -> list of ints."""
+    if eos_id is None:
+        return []
+    if isinstance(eos_id, (list, tuple)):
+        return [int(e) for e in eos_id if e is not None and int(e) >= 0]
+    return [int(eos_id)] if int(eos_id) >= 0 else []
+
+
+def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id=-1, pad_id: int = 0, temperature: float = 1.0,
+                top_k: int = 50, top_p: float = 1.0, generator: torch.Generator | None = None, min_new_tokens: int = 0,
+                greedy: bool = False) -> torch.Tensor:
     """`step(next_tokens (R,), row_src (R,)) -> logits (R, vocab)` is the decode step of engine.beam_decode / t5_beam (row_src is the
-    identity here).  Returns (R, n) new tokens, n <= max_new_tokens (the loop stops once every row has produced EOS, as HF does)."""
+    identity here).  Returns (R, n) new tokens, n <= max_new_tokens (the loop stops once every row has produced EOS, as HF does).
+
+    ``eos_id`` may be a list (any of the ids finishes a row); ``min_new_tokens`` is HF's MinNewTokensLengthLogitsProcessor (the EOS
+    logits are -inf while fewer tokens than that have been generated; applied before the warpers); ``greedy=True`` takes the argmax
+    instead of drawing (the host-side form of greedy search used for the stopping rules the captured device step does not cover)."""
     R = first_logits.shape[0]
     dev = first_logits.device
     ident = torch.arange(R, device=dev)
     unfinished = torch.ones(R, dtype=torch.bool, device=dev)
+    eos = eos_list(eos_id)
+    eos_t = torch.tensor(eos, dtype=torch.int64, device=dev) if eos else None
     out = []
     logits = first_logits
     for t in range(max_new_tokens):
-        probs = warp_logits(logits, temperature, top_k, top_p).softmax(dim=-1)
-        nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+        if eos_t is not None and t < int(min_new_tokens):
+            logits = logits.float().index_fill(-1, eos_t, float("-inf"))
+        if greedy:
+            nxt = logits.argmax(dim=-1)
+        else:
+            probs = warp_logits(logits, temperature, top_k, top_p).softmax(dim=-1)
+            nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, int(pad_id)))
         out.append(nxt)
-        if eos_id is not None and eos_id >= 0:
-            unfinished = unfinished & (nxt != int(eos_id))
+        if eos_t is not None:
+            unfinished = unfinished & ~torch.isin(nxt, eos_t)
             if not bool(unfinished.any()):
                 break
         if t + 1 < max_new_tokens:

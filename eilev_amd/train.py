@@ -242,7 +242,16 @@ class TrainGraph:
         head = self.params.get("language_model.lm_head.weight")
         if head is None:
             head = self.eng._keep.get("language_model.lm_head.weight", self.eng._keep["language_model.shared.weight"])
+        self._last = (out.detach().view(B, Lt, D), head.detach())
         return ag.lm_head_ce(out[sel].contiguous(), head, lab.reshape(-1)[sel])
+
+    @torch.no_grad()
+    def logits(self) -> torch.Tensor:
+        """Logits (B, L, vocab) bf16 of the batch `loss` just ran — `lm_head(hidden states)` of the SAME forward (dropout included in
+        train() mode), outside the autograd graph: the reference's output object always carries them (ref:eilev/model/v2.py:239-252)."""
+        hid, head = self._last
+        B, L, D = hid.shape
+        return ag.linear(hid.reshape(B * L, D).contiguous(), head).view(B, L, -1)
 
     def loss(self, input_ids, attention_mask, pixel_values, video_input_mask, labels) -> torch.Tensor:
         """Token cross-entropy (ignore_index -100; shifted for the decoder-only LM), differentiable w.r.t. ``params``."""
@@ -265,6 +274,7 @@ class TrainGraph:
         if eng.is_t5:
             return self.t5_loss(emb, attention_mask, labels)
         hid = self.opt_hidden(emb, attention_mask)
+        self._last = (hid.detach(), self.W("language_model.model.decoder.embed_tokens.weight").detach())
         tgt = labels.to(dev)[:, 1:]
         sel = tgt >= 0  # position t predicts labels[t + 1]
         rows = hid[:, :-1][sel]

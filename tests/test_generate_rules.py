@@ -1,0 +1,77 @@
+"""Stopping rules of `generate` that the captured device step does not cover — several `eos_token_id`s and
+`0 < min_new_tokens < max_new_tokens` — run through the host loops of eilev_amd/sampling.py (greedy / sampling) and eilev_amd/beam.py.
+CPU: both loops are driven by a tiny random `transformers` OPT (the language model the reference wraps, ref:eilev/model/v2.py:318-322)
+and must reproduce that model's own `generate()` token for token."""
+import pytest
+import torch
+
+from eilev_amd.beam import beam_search
+from eilev_amd.sampling import eos_list, sample_loop
+
+
+@pytest.fixture(scope="module")
+def tiny_opt():
+    from transformers import OPTConfig, OPTForCausalLM
+
+    torch.manual_seed(0)
+    cfg = OPTConfig(vocab_size=40, hidden_size=32, num_hidden_layers=2, ffn_dim=64, num_attention_heads=4, max_position_embeddings=64,
+                    word_embed_proj_dim=32, pad_token_id=1, bos_token_id=2, eos_token_id=3, do_layer_norm_before=True)
+    m = OPTForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(8.0)  # sharper distributions: EOS ids actually win some steps
+    return m
+
+
+def _stepper(model, prompt, rows):
+    """step(tokens, row_src) over a stateless full forward: keeps every row's sequence, reorders it like a KV cache would be."""
+    state = {"seq": prompt.repeat_interleave(rows // prompt.shape[0], dim=0)}
+
+    @torch.no_grad()
+    def step(tokens, src):
+        state["seq"] = torch.cat((state["seq"].index_select(0, src), tokens.view(-1, 1)), dim=1)
+        return model(state["seq"]).logits[:, -1].float()
+
+    with torch.no_grad():
+        first = model(prompt).logits[:, -1].float()
+    return step, first
+
+
+def _hf(model, prompt, **kw):
+    with torch.no_grad():
+        out = model.generate(prompt, attention_mask=torch.ones_like(prompt), pad_token_id=1, **kw)
+    return out[:, prompt.shape[1]:]
+
+
+def _eq(ours, hf, pad=1):
+    n = max(ours.shape[1], hf.shape[1])
+    f = lambda t: torch.nn.functional.pad(t, (0, n - t.shape[1]), value=pad)
+    assert torch.equal(f(ours), f(hf)), (ours.tolist(), hf.tolist())
+
+
+def test_eos_list_forms():
+    assert eos_list(None) == [] and eos_list(-1) == [] and eos_list(5) == [5] and eos_list([5, 7]) == [5, 7] and eos_list((4,)) == [4]
+
+
+@pytest.mark.parametrize("eos,min_new", [([3, 7, 11], 0), (3, 4), ([5, 9], 3), ([3, 7, 11, 13, 17, 19, 23, 29], 0)])
+def test_greedy_host_rules_equal_transformers(tiny_opt, eos, min_new):
+    torch.manual_seed(1)
+    prompt = torch.randint(4, 40, (3, 5))
+    step, first = _stepper(tiny_opt, prompt, 3)
+    ours = sample_loop(step, first, 10, eos_id=eos, pad_id=1, greedy=True, min_new_tokens=min_new)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=10, do_sample=False, num_beams=1, eos_token_id=eos, min_new_tokens=min_new or None)
+    _eq(ours, hf)
+    if min_new:
+        e = torch.tensor(eos_list(eos))
+        assert not torch.isin(ours[:, :min_new], e).any()
+
+
+@pytest.mark.parametrize("eos,min_new,nb,lp", [([3, 7, 11], 0, 3, 1.0), (3, 4, 4, -1.0), ([5, 9, 12, 30], 2, 3, 1.0), (3, 0, 5, -1.0)])
+def test_beam_host_rules_equal_transformers(tiny_opt, eos, min_new, nb, lp):
+    torch.manual_seed(2)
+    prompt = torch.randint(4, 40, (2, 6))
+    step, first = _stepper(tiny_opt, prompt, 2 * nb)
+    ours = beam_search(step, first, 2, nb, 9, lp, eos, 1, False, 1, min_new_tokens=min_new)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=9, do_sample=False, num_beams=nb, length_penalty=lp, eos_token_id=eos,
+             min_new_tokens=min_new or None, early_stopping=False)
+    _eq(ours, hf)

@@ -157,6 +157,7 @@ def _vit_three_ways(cfg_name, frames):
     from hip_utils import models, rel_rms
 
     cfg, oracle, eng = models(cfg_name)
+    eng.ensure_vit_fold()  # (built lazily by the first launch of >= 65536 token rows; these fixtures are smaller)
     assert bool(eng.pack.vit.layers_fold)
     px = synth_pixels(1, frames, cfg.vision_config.image_size)
     ref = oracle.vit(px)

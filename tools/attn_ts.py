@@ -17,7 +17,7 @@ D = h * hd
 qkv = torch.randn(b, sq, 3 * D, device="cuda").to(torch.bfloat16)
 o = torch.empty(b, sq, D, device="cuda", dtype=torch.bfloat16)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-new = len(sys.argv) > 1 and sys.argv[1] == "2"  # the round-2 kernel (attn_frame2_kernel)
+new = False  # (the round-2 attn_frame2_kernel experiment was removed from the library in round 3: git history)
 raw.eilev_debug_attn_v1((512 if new else 256) << 1)
 for _ in range(3):
     assert lib.eilev_attention(C.c_void_p(qkv.data_ptr()), C.c_void_p(qkv.data_ptr() + 2 * D), C.c_void_p(qkv.data_ptr() + 4 * D),

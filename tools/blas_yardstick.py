@@ -18,7 +18,8 @@ SHAPES = {"fc1": (M, 6144, 1408), "fc2": (M, 1408, 6144), "qkv": (M, 4224, 1408)
           "opt_fc1": (30720, 10240, 2560), "opt_qkv": (30720, 7680, 2560), "opt_fc2": (30720, 2560, 10240)}
 
 
-def timeit(fn, n=5, rounds=4):
+def timeit(fn, n=5, rounds=None):
+    rounds = rounds or ROUNDS
     best = 1e9
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,6 +31,9 @@ def timeit(fn, n=5, rounds=4):
     return best
 
 
+if os.environ.get("YARD_SHAPES"):
+    SHAPES = {k: SHAPES[k] for k in os.environ["YARD_SHAPES"].split(",")}
+ROUNDS = int(os.environ.get("YARD_ROUNDS", 4))
 for name, (m, n, k) in SHAPES.items():
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
