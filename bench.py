@@ -100,8 +100,11 @@ def cpu_baseline(cfg, host_weights):
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": hf["c2_clips_per_s"], "unit": "clips/s", "cores": hf["cores"], "kind": "hf",
-            "sample": (f"stock transformers Blip2VisionModel + Blip2QFormerModel + OPTForCausalLM (torch {hf['torch']}, fp32, {hf['threads']} threads, "
+    # `cores` = the threads the timed run really used (the probe picks them under the container's CPU quota), not the logical CPUs the
+    # box reports; `value` is EXTRAPOLATED from a bounded sample (BASELINE.md 3 wanted C2 timed once in full: ~20 min of CPU per sample)
+    return {"value": hf["c2_clips_per_s"], "unit": "clips/s", "cores": hf["threads"], "logical_cpus": hf["cores"],
+            "effective_cpus": hf.get("effective_cpus"), "kind": "hf", "extrapolated": True,
+            "sample": (f"EXTRAPOLATED from a bounded sample, not a full C2 run: stock transformers Blip2VisionModel + Blip2QFormerModel + OPTForCausalLM (torch {hf['torch']}, fp32, {hf['threads']} threads, "
                        f"{cpu_model}) on the same random-init weights: C1 = 1 clip x 8 frames, L=48, 32 greedy tokens end to end in {hf['c1_seconds']} s; "
                        f"headline workload sampled as 1 clip encode ({hf['clip_encode_seconds']} s) x 17 + one 16-shot sample's L=960 prefill + 32 "
                        f"decode steps ({hf['lm_16shot_seconds']} s)"),
@@ -148,7 +151,7 @@ def cpu_baseline_port(cfg, seconds_budget=30.0):
     # scale: per sample = 17 clips x (39 ViT blocks + 6 Q-Former pairs) + 32 OPT blocks prefill + 31 decode steps x 32 blocks
     # (the lm_head inside t_pre1 / t_dec1 is counted 32x too often: a CPU-favourable... no, CPU-UNfavourable bias < 3 %)
     per_sample = 17 * (39 * t_vit1 + 6 * t_qf2) + 32 * t_pre1 + 31 * 32 * t_dec1
-    return {"value": round(17.0 / per_sample, 5), "unit": "clips/s", "cores": cores, "kind": "port",
+    return {"value": round(17.0 / per_sample, 5), "unit": "clips/s", "cores": cores, "kind": "port", "extrapolated": True,
             "sample": (f"oracle/libeilev_ref.so fp32, {cores} threads: 1 ViT-g block on 8 frames ({t_vit1:.2f}s), 2 Q-Former blocks "
                        f"on 1 clip ({t_qf2:.2f}s), 1 OPT-2.7B block prefill L={L} ({t_pre1:.2f}s), 1 block decode step "
                        f"({t_dec1:.3f}s); scaled to 17 clips x (39 ViT + 12 Q-Former blocks) + 32 blocks prefill + 31 x 32 decode")}
@@ -216,6 +219,10 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     return ok, {"query_tokens_rel_rms_vs_fp32": round(q_rel, 5), "bf16_storage_noise_query_tokens": round(q_noise, 5),
                 "prefill_logits_rel_rms_vs_fp32": round(p_rel, 5), "bf16_storage_noise_prefill_logits": round(p_noise, 5),
                 "ids_equal_oracle_argmax": f"{exact}/{new_tokens}",
+                "ids_exact_required": False,
+                "ids_exact_note": "random-init N(0, 0.02) weights at full depth give nearly flat logits: a HIP id may differ from the fp32 oracle's argmax at "
+                                  "a near-tie (margin <= 5 % of the logit std) and still pass; exact greedy ids are pinned by the tests' fan-in-scaled "
+                                  "fixtures against the reference's own runs (tests/test_hip_stages.py, tests/golden/*)",
                 "max_margin_over_logit_std": round(max(margins), 5), "seconds": round(time.perf_counter() - t0, 1),
                 "what": "oracle/libeilev_ref.so fp32 (and its bf16-storage emulation as the noise floor) on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
                         "sample 0 inputs_embeds -> prefill last-row logits + teacher-forced decode on the HIP ids (batch-32 prefill, hipGraph decode)"}
@@ -255,6 +262,69 @@ def launch_ranks(n: int) -> int:
     return max(abs(c) for c in codes)
 
 
+def strong_scaling_phase(eng, cfg, world, rank, dev, exch_weak, is_t5, global_samples, steps=3, warmup=1):
+    """SURVEY 8(d)'s configuration, measured in the same job right after the headline steps: `global_samples` (8) 16-shot samples per
+    GLOBAL step whatever the rank count — 136 clips dealt round-robin (17 per GPU at N = 8), the language model data-parallel over
+    samples (ONE sample per rank at N = 8: batch-1 prefill and decode).  Total work is fixed, so value(N) / value(1) is the
+    strong-scaling speed-up.  Same barrier + synchronize bracket and max-over-ranks time as the headline number."""
+    from eilev_amd.comm import ClipExchange
+    from eilev_amd.sharding import my_samples
+
+    nq, Dt = cfg.num_query_tokens, cfg.text_config.hidden_size
+    cps = N_CTX + 1
+    plan = ExchangePlan(global_samples, cps, world, rank, chunk_clips=max(1, 1088 // FRAMES))
+    mine = my_samples(global_samples, world, rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + rank)
+    size = cfg.vision_config.image_size
+    px = torch.randn((plan.n_local, 3, FRAMES, size, size), device=dev, generator=g).clamp_(-2.5, 2.5).to(torch.bfloat16)
+    ids, vm = [], []
+    for s_ in mine:
+        i, m = synth_interleaved_ids([1] * cps, [24] * N_CTX + [14], nq, cfg.text_config.vocab_size, seed=100 + s_)
+        ids.append(i)
+        vm.append(m)
+    if mine:
+        ids = torch.from_numpy(np.stack(ids)).to(dev)
+        vm = torch.from_numpy(np.stack(vm)).to(dev)
+        am = torch.ones_like(ids, dtype=torch.int32)
+    exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport=exch_weak.transport if world > 1 else "local", comm=exch_weak.comm)
+
+    def step():
+        feats = eng.encode_and_exchange(px, exch)
+        if not mine:
+            return None
+        emb = eng.embed_scatter(ids, vm, feats)
+        if is_t5:
+            return eng.t5_greedy(emb, am, NEW_TOKENS, eos_id=-1, pad_id=0)[:, 1:]
+        return eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out is None or out.shape == (len(mine), NEW_TOKENS)
+    clips = global_samples * cps
+    return {"what": f"SURVEY 8(d): {global_samples} samples per GLOBAL step x {cps} clips = {clips} clips dealt over {world} rank(s), language model "
+                    f"data-parallel over samples; fixed total work, same timing bracket as the headline number",
+            "scaling": "strong", "global_samples": global_samples, "clips_per_step": clips, "steps": steps, "warmup": warmup,
+            "value": round(clips * steps / dt, 3), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3),
+            "clips_encoded_rank0": plan.n_local, "samples_decoded_rank0": len(mine)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +332,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling phase (SURVEY 8(d): 8 samples per GLOBAL step) that "
+                    "runs after the headline weak-scaling steps and is reported as `strong_scaling` in the same JSON line")
+    ap.add_argument("--strong-samples", type=int, default=8, help="samples per GLOBAL step of the strong-scaling phase")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed kernels (outside the timed region)")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 transport of the clip tokens: rccl = eilev_exchange_clip_tokens (direct RCCL send/recv on a side "
@@ -384,6 +457,7 @@ def main():
     sync()
     eng.lib.eilev_prof_enable(1)
     eng.timing = []
+    exch.timing = [] if world > 1 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -451,6 +525,25 @@ def main():
             best = (nm, n.value, ms.value, fl.value)
     eng.lib.eilev_prof_enable(0)
 
+    # the exchange of the timed steps: bytes, time on the side stream, and the part of it the ViT did not cover (rank 0's view)
+    exchange_info = None
+    if world > 1:
+        marks_x = exch.timing or []
+        rounds = [m_ for m_ in marks_x if m_[0] == "round"]
+        waits = [m_ for m_ in marks_x if m_[0] == "wait"]
+        exchange_info = {"rccl_ranks": world, "transport": exch.transport,
+                         "rounds_per_step": len(rounds) // max(1, args.steps),
+                         "sent_MB_per_step": round(sum(m_[3] for m_ in rounds) / args.steps / 1e6, 2),
+                         "received_MB_per_step": round(sum(m_[4] for m_ in rounds) / args.steps / 1e6, 2),
+                         "exchange_ms_per_step_side_stream": round(sum(m_[1].elapsed_time(m_[2]) for m_ in rounds) / args.steps, 3),
+                         "exposed_ms_per_step": round(sum(m_[1].elapsed_time(m_[2]) for m_ in waits) / args.steps, 3),
+                         "overlap": "every encode chunk's exchange runs on a side stream under the next chunk's ViT; exposed = the main stream's "
+                                    "wait for the side stream before the language model"}
+    exch.timing = None
+    strong = None
+    if not args.no_strong and args.shots == 16:
+        strong = strong_scaling_phase(eng, cfg, world, rank, dev, exch, is_t5, args.strong_samples)
+
     if rank == 0:
         clips = world * S * (N_CTX + 1) * args.steps
         value = clips / dt
@@ -497,6 +590,10 @@ def main():
                                "vit_gemm_us_and_tflops": per_kind}
         if sharded is not None:
             res["sharded_check"] = sharded
+        if exchange_info is not None:
+            res["exchange"] = exchange_info
+        if strong is not None:
+            res["strong_scaling"] = strong
         if do_verify or do_cpu:  # fp32 host copy of the weights, shared by the oracle check and the stock-HF CPU baseline
             from oracle.hf_baseline import effective_cpus
 

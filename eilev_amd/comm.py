@@ -86,6 +86,9 @@ class ClipExchange:
         self.lib = abi.load_hip() if (self.gpu and transport != "torch") else None
         self.side = torch.cuda.Stream(self.device) if (self.gpu and plan.world > 1) else None
         self.row_bytes = width * torch.empty((), dtype=dtype).element_size()
+        # optional timing (bench.py): per round an event pair on the SIDE stream around the transfer, per step an event pair on the
+        # main stream around the final wait for the side stream (= the part of the exchange the ViT did not cover)
+        self.timing = None
         self._new_staging()
 
     def _new_staging(self):
@@ -114,12 +117,20 @@ class ClipExchange:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             chunk_rows.record_stream(self.side)
         self._held.append(chunk_rows)
+        t_on = self.timing is not None and self.side is not None
+        if t_on:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.side)
         if self.transport == "rccl":
             with torch.cuda.stream(self.side):
                 abi.check(self.lib.eilev_exchange_clip_tokens(
                     self.comm.handle, C.c_void_p(chunk_rows.data_ptr()) if chunk_rows.numel() else None, _i64(srows), _i64(soff),
                     C.c_void_p(self.staging.data_ptr()) if self.staging.numel() else None, _i64(rrows), _i64(roff), p.world, p.rank,
                     self.row_bytes, C.c_void_p(self.side.cuda_stream)), "eilev_exchange_clip_tokens")
+            if t_on:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(self.side)
+                self.timing.append(("round", e0, e1, sum(srows) * self.row_bytes, sum(rrows) * self.row_bytes))
             return
         # torch.distributed transport: blocks per peer are contiguous and in rank order on both sides
         first = min((o for o, n in zip(soff, srows) if n), default=0)
@@ -129,11 +140,22 @@ class ClipExchange:
         ctx = torch.cuda.stream(self.side) if self.side is not None else _null()
         with ctx:
             dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rrows, input_split_sizes=srows, group=self.group)
+        if t_on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.side)
+            self.timing.append(("round", e0, e1, sum(srows) * self.row_bytes, sum(rrows) * self.row_bytes))
 
     def finish(self) -> torch.Tensor:
         """Rows of the clips this rank consumes, in global clip order: (n_consumed * rows_per_clip, width)."""
         if self.side is not None:
+            if self.timing is not None:
+                w0 = torch.cuda.Event(enable_timing=True)
+                w0.record()
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+            if self.timing is not None:
+                w1 = torch.cuda.Event(enable_timing=True)
+                w1.record()
+                self.timing.append(("wait", w0, w1, 0, 0))
         out = self.staging
         if not self.plan.identity:
             idx = torch.tensor(self.plan.order, device=self.device)

@@ -340,16 +340,23 @@ int launch_a4(const GemmArgs &g, hipStream_t s) {
         EILEV_HIP_CHECK(hipGetDevice(&dev));
         EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    if (var < 0) {  // probe-only: schedule variant of the K loop (gen_a4_loop.py VARIANTS)
+    if (var < 0) {  // probe-only: schedule variant of the K loop (gen_a4_loop.py VARIANTS; bias-only launches)
         const char *e = getenv("EILEV_A4_VAR");
-        var = e ? atoi(e) & 3 : 1;
+        var = e ? atoi(e) & 1 : 0;
     }
-    if (g.K % 64 || g.K < 192 || g.out_f32 || g.patch_group || g.A8 || g.W8 || g.ln_rows || g.stat_out) return EILEV_E_UNSUPPORTED;
+    if (g.K % 64 || g.K < 192 || g.N % 128 || g.out_f32 || g.patch_group || g.A8 || g.W8 || g.wscale || g.ascale || g.scale_cols || g.ln_rows || (g.ldc & 7) ||
+        ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) || (g.bias && ((uintptr_t)g.bias & 7)) ||
+        (g.stat_out && (!g.resid || g.epi != 0 || g.stat_ld < g.M || ((uintptr_t)g.stat_out & 7))))
+        return EILEV_E_UNSUPPORTED;
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
-    if (g.epi == 1) return launch_a4_e<1>(g, grid, var, s);
-    if (g.epi == 2) return launch_a4_e<2>(g, grid, var, s);
-    return launch_a4_e<0>(g, grid, var, s);
+    if (g.resid && g.epi != 0) return EILEV_E_UNSUPPORTED;  // (no caller: activation + residual)
+    if (g.stat_out) return launch_a4_i<0, 0, 2, true>(g, grid, s);
+    if (g.resid) return launch_a4_i<0, 0, 0, true>(g, grid, s);
+    if (g.epi == 1) return launch_a4_i<1, 0, 0, false>(g, grid, s);
+    if (g.epi == 2) return launch_a4_i<2, 0, 0, false>(g, grid, s);
+    if (var == 1) return launch_a4_i<0, 1, 0, false>(g, grid, s);
+    return launch_a4_i<0, 0, 0, false>(g, grid, s);
 }
 #else  // EILEV_GEMM_PART != 3: everything else
 template <int BM, int BN, int NWM, int NWN, int EPI>
@@ -2126,6 +2133,25 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         }
         return EILEV_OK;
     }
+    // One wave per SIMD, 128 x 128 per wave, hand-scheduled K loop (gemm_a4.h; per-tile descriptors: no 2 GiB limit, so before the chunking
+    // below).  OPT-IN (probe flag 10 << 4; tests/test_gemm_a4.py): same-box against the ping-pong kernel at the ViT launch shapes (round 3,
+    // profiles/r03_a4_vs_pp4.log) its K loop is 5 % faster (1400-1450 vs 1340-1370 TFLOP/s) and bias-only GEMMs gain 1.7-3.5 % (fc1 without
+    // GELU 1239 vs 1218, qkv 1207 vs 1178), but every residual epilogue loses (fc2 1141-1152 vs 1162, proj 954 vs 1020): with one wave per
+    // SIMD nothing covers the residual loads that queue behind the next tile's LDS-DMA pieces.  The bench path runs the LayerNorm-folded
+    // forms (consumer variant not built for this kernel), so nothing dispatches here by default.
+    {
+        const int force0 = (g.dbg >> 4) & 15;
+        const bool a4_ok = g.K % BK == 0 && g.K >= 192 && g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale &&
+                           !g.W8 && !g.ln_rows && !g.ln_out && g.k_slice == 0 && g.M > 32 && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                           (!g.resid || ((g.ldr & 7) == 0 && ((uintptr_t)g.resid & 15) == 0)) && (!g.bias || ((uintptr_t)g.bias & 7) == 0) &&
+                           (!g.stat_out || g.resid) && (!g.resid || g.epi == 0) && (int64_t)256 * g.lda * 2 < 0x7fff0000ll && !(g.dbg & (4 | 1 | 2048 | 2));
+        if (a4_ok && force0 == 10) {
+            if (prof_kind >= 0) prof_begin(prof_kind, 2.0 * g.M * (double)g.N * g.K, s);
+            const int rc_a4 = launch_a4(g, s);
+            if (prof_kind >= 0) prof_end(s);
+            return rc_a4;
+        }
+    }
     // The LDS-DMA kernels address A through a 32-bit buffer offset: an A operand of 2 GiB or more (the Q-Former k|v
     // projection of a whole step: 1.1 M rows x 1408) is processed as row chunks that fit, each with the fast kernels
     const int64_t a_bytes = (int64_t)g.M * g.lda * 2;
@@ -2179,9 +2205,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     // (qkv +5 %, OPT out_proj +3 %)
     const int64_t tiles256 = tm256 * ceil_div64(g.N, 256);
     const bool w6_pick = cfg == 1 && tiles256 < 1024;
-    if (force == 10 && g.K % 64 == 0 && g.K >= 192 && !g.out_f32 && g.patch_group == 0)
-        rc = launch_a4(g, s);  // probe: one wave per SIMD, 128 x 128 per wave, hand-scheduled K loop (gemm_a4.h)
-    else if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
+    if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
         rc = launch_w6(g, s);
     else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
         (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)

@@ -13,7 +13,11 @@
 // + 8 KiB of epilogue staging per wave = 160 KiB.  Both first K-steps of the NEXT tile are staged before the epilogue starts.
 #include "gemm_a4_loop.inc"
 
-template <int EPI, int VAR>
+// EPI: 0 none, 1 GELU (fast form), 2 ReLU.  VAR: schedule variant of the K loop (probe).  LN: 0 plain; 2 residual epilogue that also emits the
+// row statistics of what it writes (GemmArgs::stat_out: per 64-column slot (sum, sum of squares), the LayerNorm-folding producer of proj / fc2).
+// Requires N % 128 == 0 (a last column tile is whole or exactly its first 128 columns) and K % 64 == 0, K >= 192.
+// RES: the launch has a residual (compile-time: each epilogue form the kernel carries costs registers across the K loop).
+template <int EPI, int VAR, int LN, bool RES>
 __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, WM = 128, WN = 128, TM = 4;
     constexpr int STEP = 65536;
@@ -39,6 +43,8 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
     // fragment reads: lane (l31, hi) reads row l31 of a 32-row block, 16-byte chunk (k-slice * 2 + hi) ^ swizzle: k-slice k = XOR with k << 5
     const unsigned va_rd = lds0 + (unsigned)((wm * WM + l31) * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
     const unsigned vw_rd = lds0 + (unsigned)(BM * 128 + (wn * WN + l31) * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
+    // half tiles (only columns 0..127 of the tile exist): every wave owns 128 rows x 64 columns, W rows wn * 64 ..
+    const unsigned vw_rd_ht = lds0 + (unsigned)(BM * 128 + (wn * 64 + l31) * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
 
     auto uniform_rsrc = [&](const void *ptr, int bytes) {
         const uint64_t base = (uint64_t)ptr;
@@ -76,58 +82,77 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
     // Lean epilogue (interior column tiles; rows past M are dropped by the output descriptor): the design of gemm_pp4_kernel's — units
     // of 32 rows x 64 columns through 4 KiB of private LDS staging OUTSIDE the step buffers (16-byte chunk c of row r at c ^ (r & 7)),
     // bias / activation / residual in registers, read back as 128-byte row segments, 16-byte buffer stores — here 8 units per wave.
-    char *const stg = smem + 2 * STEP + wid * 4096;
-    const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
+    char *const stg = smem + 2 * STEP + wid * 8192;  // two staging units of 4 KiB: unit X uses X & 1
+    const unsigned stg_sw = (unsigned)(2 * STEP + wid * 8192 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
     const int srow = lane >> 3, schunk = lane & 7;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    auto lean_half = [&](int cm0, int cn0, auto jh_c, auto res_c) {
-        constexpr int JH = decltype(jh_c)::value;
-        constexpr bool RES = decltype(res_c)::value;
-        const int r0 = cm0 + wm * WM, c0 = cn0 + wn * WN + JH * 64;
+    // 8 units per wave (X = jh * 4 + U: column half jh, rows U * 32 ..), SOFTWARE-PIPELINED over the two staging units: the cells of unit
+    // X + 1 are computed and written while the row segments of unit X come back from LDS and leave — with one wave per SIMD nothing else
+    // would cover the LDS write -> read -> store chain of a unit.
+    auto lean_epilogue = [&](int cm0, int cn0, auto ht_c) {
+        constexpr bool HT = decltype(ht_c)::value;  // half tile: 4 units (jh = 0), the wave's columns are wn * 64 ..
+        constexpr int NU = HT ? 4 : 8;
+        constexpr bool LNP = LN == 2 && RES;
+        const int r0 = cm0 + wm * WM, c0 = cn0 + wn * (HT ? 64 : WN);
         const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
         const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + c0, rows * (int)(g.ldc * 2));
         const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + c0 : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
         const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
-        u32x4_t rv[4];
-        auto res_load = [&](int u) {
+        // residual rows of two units in flight.  (Measured alternatives, both slower through register pressure: all eight units requested
+        // before the next tile's LDS-DMA pieces (128 VGPRs, 220 spills: fc2 1072 TFLOP/s), four up front + four as they free (64 VGPRs, 155
+        // spills: 1141) against 1152 for this form — whose loads queue behind the 32 pieces: vector-memory returns are in order.  The
+        // residual epilogue is where this kernel loses to the ping-pong kernel, whose second wave per SIMD covers that wait.)
+        u32x4_t rv[2][4];
+        auto res_load = [&](auto x_c) {
+            constexpr int X = decltype(x_c)::value, JH = X >> 2, U = X & 3;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (u * 32 + it * 8) * (int)(g.ldr * 2), 0);
+            for (int it = 0; it < 4; ++it)
+                rv[X & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff + JH * 128, (U * 32 + it * 8) * (int)(g.ldr * 2), 0);
         };
-        if constexpr (RES) res_load(0);
-        bf16x4 biasr[2][4];  // columns j*32 + q*8 + hi*4 + (0..3) of the half's 64: the accumulator layout
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        __amdgpu_buffer_rsrc_t rst[2] = {rc, rc};  // LN == 2: one statistics slot per 64 columns, rows past M dropped
+        if constexpr (LNP) {
+            rst[0] = uniform_rsrc(g.stat_out + ((int64_t)(c0 >> 6) * g.stat_ld + r0) * 2, rows * 8);
+            rst[1] = uniform_rsrc(g.stat_out + ((int64_t)((c0 >> 6) + 1) * g.stat_ld + r0) * 2, rows * 8);
+        }
+        bf16x4 biasr[2][2][4];  // [jh][j][q]: columns jh*64 + j*32 + q*8 + hi*4 + (0..3): the accumulator layout
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (g.bias) biasr[j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + c0 + j * 32 + q * 8 + hi * 4);
-                else biasr[j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-            }
-        static_for<TM>([&](auto u_c) {
-            constexpr int U = decltype(u_c)::value;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (g.bias && !(HT && jh == 1)) biasr[jh][j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + c0 + jh * 64 + j * 32 + q * 8 + hi * 4);
+                    else biasr[jh][j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                }
+        auto cells = [&](auto x_c) {
+            constexpr int X = decltype(x_c)::value, JH = X >> 2, U = X & 3, SB = (X & 1) * 4096;
             bf16x4 rcell[2][4];
             if constexpr (RES) {  // the unit's residual rows -> staging (coalesced); every lane then fetches its 8 cells in one batch
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + srow;
-                    *reinterpret_cast<u32x4_t *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[it];
+                    *reinterpret_cast<u32x4_t *>(stg + SB + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[X & 1][it];
                 }
-                if constexpr (U + 1 < TM) res_load(U + 1);  // the next unit's rows arrive under this unit's arithmetic
+                if constexpr (X + 2 < NU) res_load(std::integral_constant<int, X + 2>{});
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         unsigned ca;
-                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(((j * 4 + q) << 4) + SB), "v"(stg_sw));
                         rcell[j][q] = *reinterpret_cast<const bf16x4 *>(smem + ca);
                     }
             }
+            float st1 = 0.0f, st2 = 0.0f;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[JH][U][j][q * 4 + e] + (float)biasr[j][q][e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[JH][U][j][q * 4 + e] + (float)biasr[JH][j][q][e];
                     if constexpr (EPI == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
@@ -137,65 +162,50 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rcell[j][q][e];
                     }
+                    if constexpr (LNP) {  // statistics of the fp32 values (gemm_pp4_kernel's producer: same values, same order)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            st1 += v[e];
+                            st2 = fmaf(v[e], v[e], st2);
+                        }
+                    }
                     unsigned ca;
-                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(((j * 4 + q) << 4) + SB), "v"(stg_sw));
                     *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 }
-            __builtin_amdgcn_sched_barrier(0);  // cells of a unit first, then its read-backs and stores; nothing of the next unit in between
-            bf16x8 erb[2];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int row = (h2 * 2 + b) * 8 + srow;
-                    erb[b] = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff, (U * 32 + (h2 * 2 + b) * 8) * (int)(g.ldc * 2), EILEV_ST_AUX);
+            if constexpr (LNP) {  // the two lane halves hold the two column halves of a row
+                const f32x2_t t2 = (f32x2_t){st1 + __shfl_xor(st1, 32), st2 + __shfl_xor(st2, 32)};
+                if (hi == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, t2), rst[JH], (U * 32 + l31) * 8, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto flush = [&](auto x_c) {
+            constexpr int X = decltype(x_c)::value, JH = X >> 2, U = X & 3, SB = (X & 1) * 4096;
+            bf16x8 erb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int row = b * 8 + srow;
+                erb[b] = *reinterpret_cast<const bf16x8 *>(stg + SB + row * 128 + ((schunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff + JH * 128, (U * 32 + b * 8) * (int)(g.ldc * 2), EILEV_ST_AUX);
             // (gfx950, r2: a VALU write to the data registers of a 128-bit buffer store issued the cycle before corrupted the stored chunk:
             // keep the scheduler out, two idle states between the last store and whatever reuses its registers — see gemm_pp4_kernel)
             asm volatile("s_nop 1" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (RES) {
+            res_load(std::integral_constant<int, 0>{});
+            res_load(std::integral_constant<int, 1>{});
+        }
+        cells(std::integral_constant<int, 0>{});
+        static_for<NU>([&](auto x_c) {
+            constexpr int X = decltype(x_c)::value;
+            if constexpr (X + 1 < NU) cells(std::integral_constant<int, X + 1>{});
+            flush(x_c);
         });
     };
-    // Edge tiles (last column tile when N % 256 != 0; probes): every cell guarded, 8-byte stores straight from the accumulator layout
-    auto edge_epilogue = [&](int cm0, int cn0) {
-        static_for<2>([&](auto jh_c) {
-            constexpr int JH = decltype(jh_c)::value;
-            static_for<TM>([&](auto u_c) {
-                constexpr int U = decltype(u_c)::value;
-                const int row = cm0 + wm * WM + U * 32 + l31;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = cn0 + wn * WN + JH * 64 + j * 32 + q * 8 + hi * 4;
-                        if (row < g.M && col < g.N) {  // (N % 4 == 0: the four columns of a cell are in or out together)
-                            float v[4];
-                            bf16x4 b4 = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-                            if (g.bias) b4 = *reinterpret_cast<const bf16x4 *>(g.bias + col);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[e] = acc[JH][U][j][q * 4 + e] + (float)b4[e];
-                                if (EPI == 1) v[e] = gelu_erf_n1(v[e]);
-                                else if (EPI == 2) v[e] = fmaxf(v[e], 0.0f);
-                            }
-                            if (g.resid) {
-                                const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(g.resid + (int64_t)row * g.ldr + col);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                            }
-                            if (!(g.dbg & 1))
-                                *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(g.C) + (int64_t)row * g.ldc + col) =
-                                    (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        }
-                    }
-            });
-        });
-    };
-
     int t = blockIdx.x, m0, n0;
     if (t >= ntiles) return;
     tile_origin(t, m0, n0);
@@ -208,13 +218,15 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
                  : "=a"(acc[0][0][0]), "=a"(acc[0][0][1]), "=a"(acc[1][0][0]), "=a"(acc[1][0][1]), "=a"(acc[0][1][0]), "=a"(acc[0][1][1]),       \
                    "=a"(acc[1][1][0]), "=a"(acc[1][1][1]), "=a"(acc[0][2][0]), "=a"(acc[0][2][1]), "=a"(acc[1][2][0]), "=a"(acc[1][2][1]),     \
                    "=a"(acc[0][3][0]), "=a"(acc[0][3][1]), "=a"(acc[1][3][0]), "=a"(acc[1][3][1])                                               \
-                 : "v"(va_rd), "v"(vw_rd), "v"(va_e), "v"(va_o), "v"(vw_e), "v"(vw_o), "s"(ra), "s"(rw), "s"(stride_a), "s"(stride_w), "s"(ns), \
-                   "s"(dst0)                                                                                                                      \
+                 : "v"(va_rd), "v"(vw_sel), "v"(va_e), "v"(va_o), "v"(vw_e), "v"(vw_o), "s"(ra), "s"(rw), "s"(stride_a), "s"(stride_w),         \
+                   "s"(ns), "s"(dst0), "s"(form)                                                                                                  \
                  : A4_LOOP_CLOBBERS)
+        const bool half = n0 + 128 >= g.N;  // N % 128 == 0: the last column tile is whole or exactly its first half
+        // half tile: every wave 128 x 64 (operands i*4 + j, j < 2 = acc[0]); waves 2, 3 own W rows that do not exist: no W pieces
+        const int form = half ? (wid >= 2 ? 2 : 1) : 0;
+        const unsigned vw_sel = half ? vw_rd_ht : vw_rd;
         if constexpr (VAR == 0) A4_ASM(A4_LOOP_V0);
-        else if constexpr (VAR == 1) A4_ASM(A4_LOOP_V1);
-        else if constexpr (VAR == 2) A4_ASM(A4_LOOP_V2);
-        else A4_ASM(A4_LOOP_V3);
+        else A4_ASM(A4_LOOP_V1);
 #undef A4_ASM
         // the loop ends with every wave's own fragment reads complete; the barrier makes that true of all four before a buffer is re-staged
         __builtin_amdgcn_s_barrier();
@@ -235,33 +247,20 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) keep += acc[jh][i][j][0] + acc[jh][i][j][7] + acc[jh][i][j][15];
             if (keep == 123.456f) reinterpret_cast<float *>(g.C)[0] = keep;
-        } else if (cn0 + BN <= g.N && !(g.dbg & 1)) {
-            if (g.resid != nullptr) {
-                lean_half(cm0, cn0, std::integral_constant<int, 0>{}, std::true_type{});
-                lean_half(cm0, cn0, std::integral_constant<int, 1>{}, std::true_type{});
-            } else {
-                lean_half(cm0, cn0, std::integral_constant<int, 0>{}, std::false_type{});
-                lean_half(cm0, cn0, std::integral_constant<int, 1>{}, std::false_type{});
-            }
-        } else edge_epilogue(cm0, cn0);
+        } else if (half) lean_epilogue(cm0, cn0, std::true_type{});
+        else lean_epilogue(cm0, cn0, std::false_type{});
     }
 }
 
-template <int EPI>
-static int launch_a4_e(const GemmArgs &g, int grid, int var, hipStream_t s) {
+template <int EPI, int VAR, int LN, bool RES>
+static int launch_a4_i(const GemmArgs &g, int grid, hipStream_t s) {
     constexpr int smem = 2 * 65536 + 4 * 8192;
     static bool attr_set = false;
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_a4_kernel<EPI, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_a4_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_a4_kernel<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_a4_kernel<EPI, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_a4_kernel<EPI, VAR, LN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    if (var == 0) hipLaunchKernelGGL((gemm_a4_kernel<EPI, 0>), dim3(grid), dim3(256), smem, s, g);
-    else if (var == 1) hipLaunchKernelGGL((gemm_a4_kernel<EPI, 1>), dim3(grid), dim3(256), smem, s, g);
-    else if (var == 2) hipLaunchKernelGGL((gemm_a4_kernel<EPI, 2>), dim3(grid), dim3(256), smem, s, g);
-    else hipLaunchKernelGGL((gemm_a4_kernel<EPI, 3>), dim3(grid), dim3(256), smem, s, g);
+    hipLaunchKernelGGL((gemm_a4_kernel<EPI, VAR, LN, RES>), dim3(grid), dim3(256), smem, s, g);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -22,7 +22,8 @@ so a DMA has ~1.2 K-steps (~2500 shader clocks) between issue and first use, wit
 Operands of the asm statement (gemm_a4.h): %0..%15 accumulators acc[i][j] ("=a": written only — the first k-slice of a tile takes C = 0; index i*4 + j); %16 / %17 LDS read address of the lane's
 A / W row (buffer 0, k-slice 0); %18 / %19 DMA offset of the lane in an even / odd A piece, %20 / %21 same for W; %22 / %23 buffer
 descriptors of the A / W tile; %24 / %25 bytes between consecutive pieces (8 rows) of A / W; %26 number of K-steps (>= 3); %27 LDS byte
-address of the wave's first A piece in buffer 0 (its W pieces: + 32768; buffer 1: + 65536).
+address of the wave's first A piece in buffer 0 (its W pieces: + 32768; buffer 1: + 65536); %28 form of the loop (0 full tile, 1 half tile, 2 half
+tile without W pieces: see main()).
 
     python gen_a4_loop.py [> gemm_a4_loop.inc]     knobs: see VARIANTS
 """
@@ -64,13 +65,25 @@ def group(k16, tm=4, tn=4, zero_c=False):
     return [mfma(i, j, k16, zero_c) for i in range(tm) for j in range(tn)]
 
 
-def dma_pieces(na=8, nw=8):
-    """[(m0 setup, load)] for the wave's pieces of the step at byte offset S_KOFF"""
+def dma_pieces(na=8, nw=8, kind="lds"):
+    """[(m0 setup, load)] for the wave's pieces of the step at byte offset S_KOFF.  kind (probe variants, results are garbage): "vgpr" =
+    the same loads into scratch VGPRs instead of LDS, "nop" = an s_nop in place of the load (issue cost of the LDS-DMA by difference)"""
     out = []
-    for i in range(na):
-        out.append((f"s_add_u32 m0, {S_DA}, {i * 1024}", f"buffer_load_dwordx4 v{DA[i]}, %22, {S_KOFF} offen lds"))
-    for i in range(nw):
-        out.append((f"s_add_u32 m0, {S_DW}, {i * 1024}", f"buffer_load_dwordx4 v{DW[i]}, %23, {S_KOFF} offen lds"))
+    for i in range(na + nw):
+        a = i < na
+        ii = i if a else i - na
+        m0 = f"s_add_u32 m0, {S_DA if a else S_DW}, {ii * 1024}"
+        off, rs = (DA[i] if a else DW[i - na]), ("%22" if a else "%23")
+        if kind == "lds4":  # four pieces per M0 value: the instruction offset (added to BOTH addresses) walks the 4 KiB; the prologue
+            # subtracted it from the pieces' global offsets
+            m0 = f"s_add_u32 m0, {S_DA if a else S_DW}, {(ii // 4) * 4096}" if ii % 4 == 0 else None
+            out.append((m0, f"buffer_load_dwordx4 v{off}, {rs}, {S_KOFF} offen offset:{(ii % 4) * 1024} lds"))
+        elif kind == "lds":
+            out.append((m0, f"buffer_load_dwordx4 v{off}, {rs}, {S_KOFF} offen lds"))
+        elif kind == "vgpr":
+            out.append((m0, f"buffer_load_dwordx4 v[{152 + 4 * (i % 4)}:{155 + 4 * (i % 4)}], v{off}, {rs}, {S_KOFF} offen"))
+        else:
+            out.append((m0, "s_nop 0"))
     return out
 
 
@@ -85,6 +98,8 @@ def body(dma, nxt, v, tm=4, tn=4, na=8, nw=8, first=False):
     only: no zero fill, nothing live across the tile boundary).  Returns a list of instructions."""
     mm = group(0, tm, tn, zero_c=first) + group(1, tm, tn) + group(2, tm, tn) + group(3, tm, tn)
     n = len(mm)
+    if n != 64:  # half tiles (tn = 2: 32 MFMAs per step): the same schedule on the shorter stream
+        v = dict(v, **v.get("half", {}))
     pre = [[] for _ in mm]   # before MFMA m (M0 setup: a SALU write of M0 wants an instruction between it and its user)
     post = [[] for _ in mm]  # after MFMA m
     clamp = lambda x: max(0, min(n - 1, x))
@@ -98,18 +113,20 @@ def body(dma, nxt, v, tm=4, tn=4, na=8, nw=8, first=False):
     h = clamp(v["h_at"] if dma else v["h_at_tail"])
     issued_before_h = 0
     if dma:
-        for q, (m0set, ld) in enumerate(dma_pieces(na, nw)):
+        for q, (m0set, ld) in enumerate(dma_pieces(na, nw, v.get("dma_kind", "lds"))):
             at = clamp(max(b1 + 1, v["d_at"] + (q * v["d_num"]) // v["d_den"]))
             if at <= h:
                 issued_before_h += 1
-            if not any(x.startswith("buffer_load") for x in post[at]):
+            if m0set is None:
+                post[at].append(ld)
+            elif not any(x.startswith(("buffer_load", "s_nop")) for x in post[at]):
                 pre[at].append(m0set)
                 post[at].append(ld)
             else:  # further pieces in one slot: M0 write, one wait state (SALU write of M0 -> LDS-DMA), load
                 post[at] += [m0set, "s_nop 0", ld]
     if nxt:
         # handover: the h-slot's own pieces are issued first (they precede this in the slot), everything older has landed
-        post[h].append(f"s_waitcnt vmcnt({issued_before_h})")
+        post[h].append(f"s_waitcnt vmcnt({issued_before_h if v.get('dma_kind', 'lds') != 'nop' else 0})")
         post[h].append("s_barrier")
         for r in RA + RW:
             post[h].append(f"v_xor_b32 v{r}, 0x10000, v{r}")
@@ -121,7 +138,7 @@ def body(dma, nxt, v, tm=4, tn=4, na=8, nw=8, first=False):
         L.append(m)
         L += b
     if dma:
-        L += [f"s_add_u32 {S_KOFF}, {S_KOFF}, 128", f"s_xor_b32 {S_DA}, {S_DA}, 0x10000", f"s_xor_b32 {S_DW}, {S_DW}, 0x10000"]
+        L += [f"s_add_u32 {S_KOFF}, {S_KOFF}, {0 if v.get('freeze_k') else 128}", f"s_xor_b32 {S_DA}, {S_DA}, 0x10000", f"s_xor_b32 {S_DW}, {S_DW}, 0x10000"]
     if nxt:
         L.append("s_waitcnt lgkmcnt(0)")
     return L
@@ -129,12 +146,17 @@ def body(dma, nxt, v, tm=4, tn=4, na=8, nw=8, first=False):
 
 def loop_text(v, tm=4, tn=4, na=8, nw=8):
     L = []
+    share = v.get("dma_kind", "lds") == "lds4"
     # ---- prologue: per-piece DMA offsets, per-k-slice read addresses, counters
     for i in range(8):
         L.append(f"s_mul_i32 {S_T}, %24, {i}")
+        if share and i % 4:
+            L.append(f"s_sub_u32 {S_T}, {S_T}, {(i % 4) * 1024}")
         L.append(f"v_add_u32 v{DA[i]}, {S_T}, {'%18' if i % 2 == 0 else '%19'}")
     for i in range(8):
         L.append(f"s_mul_i32 {S_T}, %25, {i}")
+        if share and i % 4:
+            L.append(f"s_sub_u32 {S_T}, {S_T}, {(i % 4) * 1024}")
         L.append(f"v_add_u32 v{DW[i]}, {S_T}, {'%20' if i % 2 == 0 else '%21'}")
     for k in range(4):
         L.append(f"v_xor_b32 v{RA[k]}, {k << 5}, %16")
@@ -156,7 +178,7 @@ def loop_text(v, tm=4, tn=4, na=8, nw=8):
     return L
 
 
-CLOBBER = ['"memory"', '"scc"', '"vcc"'] + [f'"s{n}"' for n in range(84, 89)] + [f'"v{n}"' for n in range(152)]
+CLOBBER = ['"memory"', '"scc"', '"vcc"'] + [f'"s{n}"' for n in range(84, 89)] + [f'"v{n}"' for n in range(168)]  # (v152..167: probe variants)
 
 # schedule knobs (see body): positions are MFMA indices 0..63 of the K-step
 def K(r1_at=0, r1=(1, 1), b1_at=31, d_at=32, d=(1, 1), h_at=47, h_at_tail=39, r0=(1, 1)):
@@ -164,11 +186,14 @@ def K(r1_at=0, r1=(1, 1), b1_at=31, d_at=32, d=(1, 1), h_at=47, h_at_tail=39, r0
                 r0_num=r0[0], r0_den=r0[1])
 
 
+HALF = dict(r1_at=0, r1_num=1, r1_den=1, b1_at=12, d_at=13, d_num=1, d_den=1, h_at=19, h_at_tail=15, r0_num=1, r0_den=1)
 VARIANTS = {
-    "V0": K(),                                                   # the first measured schedule: DMA one per MFMA in 32..47, reads of the next step one per MFMA in 48..63
-    "V1": K(b1_at=19, d_at=20, d=(2, 1), h_at=47, r0=(1, 1)),   # buffer freed after MFMA 19, DMA one per two MFMAs in 20..50
-    "V2": K(b1_at=19, d_at=20, d=(3, 1), h_at=43, r0=(1, 1)),   # DMA one per three MFMAs in 20..63, hand-over after MFMA 43 (8 pieces issued)
-    "V3": K(b1_at=23, d_at=24, d=(5, 2), h_at=44, r0=(1, 1)),   # DMA 2 per 5 MFMAs in 24..61
+    # measured (profiles/r03_a4_schedule.md): DMA pieces bunched one per MFMA (the first schedule) 1266-1300 TFLOP/s main loop on fc1; one
+    # per two MFMAs 1386; one per three 1398-1450; 2 per 5: 1397; one per four 1381.  What the pieces cost is their ISSUE (12 % of the loop:
+    # the same loads into VGPRs cost the same, loads that always hit the cache cost the same, no loads at all: 1642), not M0 traffic
+    # (four pieces per M0 write: no change) and not memory latency.
+    "V0": dict(K(b1_at=17, d_at=18, d=(3, 1), h_at=43), half=HALF),
+    "V1": dict(K(b1_at=17, d_at=18, d=(3, 1), h_at=43), half=HALF),   # (experiment slot)
 }
 
 
@@ -183,7 +208,14 @@ def emit(name, lines):
 def main():
     print("// Generated by gen_a4_loop.py — do not edit.  See that file for the register plan and the pipeline.")
     for vn, v in VARIANTS.items():
-        print(emit(f"A4_LOOP_{vn}", loop_text(v)))
+        # ONE asm statement holds the three forms of the loop, selected by operand %28 (one statement = one definition of the accumulators:
+        # three statements made hipcc merge their 16 x 16 output registers through 256 v_accvgpr_read / write per tile):
+        #   0  full tile: 128 x 128 per wave
+        #   1  half tile (N % 256 = 128: only columns 0..127 of the tile exist): every wave owns 128 rows x 64 columns (operands i*4 + j, j < 2)
+        #   2  half tile, a wave whose W rows (128..255 of the tile) do not exist: stages no W pieces
+        L = ["s_cmp_eq_u32 %28, 0", "s_cbranch_scc0 7f"] + loop_text(v) + ["s_branch 9f", "7:", "s_cmp_eq_u32 %28, 1", "s_cbranch_scc0 8f"]
+        L += loop_text(v, tn=2) + ["s_branch 9f", "8:"] + loop_text(v, tn=2, nw=0) + ["9:"]
+        print(emit(f"A4_LOOP_{vn}", L))
         print()
     print("#define A4_LOOP_CLOBBERS " + ", ".join(CLOBBER))
 

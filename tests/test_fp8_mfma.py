@@ -95,6 +95,11 @@ def _a8w8_case(m, n, k, epi, bias, resid, out_f32=False, seed=0):
     (960, 2560, 10240, 0, True, True),        # fc2: long K
     (2000, 1408, 512, 0, False, False),       # N = 1408: the half-tile path of the persistent kernel on fp8 operands
     (40, 384, 128, 2, True, True),            # a single partial tile, minimum K
+    # BASELINE configs[4] (OPT-6.7B: d = 4096, ffn = 16384): q|k|v, out_proj, fc1 + ReLU, fc2 at a prefill row count
+    (1904, 12288, 4096, 0, True, False),
+    (1904, 4096, 4096, 0, True, True),
+    (700, 16384, 4096, 2, True, False),
+    (700, 4096, 16384, 0, True, True),
 ])
 def test_linear_a8w8_against_oracle_on_the_same_bytes(m, n, k, epi, bias, resid):
     _a8w8_case(m, n, k, epi, bias, resid)

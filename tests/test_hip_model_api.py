@@ -163,3 +163,71 @@ def test_vision_model_debug_outputs_like_the_reference(golden_dir):
     assert torch.equal(fused.last_hidden_state, o.last_hidden_state) and torch.equal(fused.pooler_output, o.pooler_output)
     tup = vm(px, output_hidden_states=True, return_dict=False)
     assert len(tup) == 3 and len(tup[2]) == L + 1
+
+
+def test_c1_workload_through_the_model_class():
+    """BASELINE configs[0] (C1) on the GPU path through the drop-in class: ONE clip x 8 frames of 224 x 224, no in-context examples, a
+    prompt of 48 positions (32 video slots + text), 32 greedy tokens — at the real ViT-g / Q-Former / OPT-2.7B widths (one block per
+    stack: `real_1l`), checked against the CPU oracle on the same weights: ids exact, logits at the bf16 noise level."""
+    from eilev_amd.synth import synth_interleaved_ids, synth_pixels
+    from oracle.runner import OracleModel
+
+    cfg = blip2_config("real_1l")
+    m = build("real_1l", torch.bfloat16)
+    sd = synth_state_dict(cfg)
+    ora = OracleModel(cfg, sd)
+    nq = cfg.num_query_tokens
+    ids, vm = synth_interleaved_ids([1], [48 - 1 - nq - 1], nq, cfg.text_config.vocab_size)
+    assert ids.shape[0] == 48
+    ids, vm = ids[None], vm[None]
+    am = np.ones_like(ids)
+    px = synth_pixels(1, 8, cfg.vision_config.image_size)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = m(input_ids=t(ids), attention_mask=t(am), pixel_values=t(px).to(torch.bfloat16), video_input_mask=t(vm), return_dict=True)
+    ref_logits = ora.forward_logits(px, ids, am, vm)
+    assert rel_rms(host(out.logits), ref_logits) <= 1.2e-2
+    got = m.generate(input_ids=t(ids), pixel_values=t(px).to(torch.bfloat16), video_input_mask=t(vm), attention_mask=t(am),
+                     max_new_tokens=32, min_new_tokens=32, num_beams=1, do_sample=False)
+    ref = ora.generate(px, ids, am, vm, 32, eos_id=-1)
+    assert got.shape == (1, 32) and np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_generate_stopping_rules_and_return_sequences(golden_dir):
+    """generate() kwargs of round 3 on the HIP decode step: several eos ids and 0 < min_new_tokens < max_new_tokens (host-side stopping
+    rule over the same decode step: must agree with the captured greedy path wherever both apply), num_return_sequences with sampling
+    (hf `_expand_inputs_for_generation`: rows of one prompt adjacent), and HF's errors."""
+    g, meta, px = load_case(golden_dir, "mid_b2")
+    m = build(meta["config"], torch.bfloat16)
+    t = lambda a: torch.from_numpy(a).cuda()
+    kw = dict(input_ids=t(g["input_ids"]), pixel_values=t(px).to(torch.bfloat16), video_input_mask=t(g["video_input_mask"]),
+              attention_mask=t(g["attention_mask"]))
+    n = meta["new_tokens"]
+    eos = int(g["fp32_eos_id"])
+    base = m.generate(**kw, max_new_tokens=n, eos_token_id=eos).cpu().numpy()
+    assert np.array_equal(base, g["fp32_greedy_eos"])
+    # a list whose extra id never occurs changes nothing (host rule == device rule)
+    never = int(np.setdiff1d(np.arange(3, 200), g["fp32_greedy_free"].ravel())[0])
+    assert np.array_equal(m.generate(**kw, max_new_tokens=n, eos_token_id=[eos, never]).cpu().numpy(), base)
+    # two live ids: every row stops at its first occurrence of either, pads after it
+    free = g["fp32_greedy_free"]
+    second = int(free[0, 1])
+    both = m.generate(**kw, max_new_tokens=n, eos_token_id=[eos, second], pad_token_id=1).cpu().numpy()
+    for r in range(free.shape[0]):
+        hits = np.nonzero(np.isin(free[r], [eos, second]))[0]
+        stop = (int(hits[0]) + 1) if len(hits) else n
+        assert np.array_equal(both[r, :min(stop, both.shape[1])], free[r, :min(stop, both.shape[1])])
+        assert (both[r, stop:] == 1).all()
+    # min_new_tokens: an eos that greedy would emit earlier cannot fire before that many tokens
+    first = int(free[0, 0])
+    late = m.generate(**kw, max_new_tokens=n, min_new_tokens=3, eos_token_id=first).cpu().numpy()
+    assert late.shape[1] >= 3 and not (late[:, :3] == first).any()
+    # sampling: N sequences per prompt, rows of a prompt adjacent; greedy refuses N > 1 like HF
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    smp = m.generate(**kw, max_new_tokens=4, min_new_tokens=4, do_sample=True, top_k=1, num_return_sequences=3, generator=gen).cpu().numpy()
+    assert smp.shape == (3 * free.shape[0], 4)
+    for r in range(free.shape[0]):  # top_k = 1 is greedy: the three rows of a prompt are that prompt's greedy continuation
+        assert (smp[3 * r: 3 * r + 3] == free[r, :4]).all()
+    with pytest.raises(ValueError):
+        m.generate(**kw, max_new_tokens=4, num_return_sequences=2)
+    m.hf_device_map = {"": 0}  # accelerate's hook is a no-op on the single-device HIP engine
+    assert np.array_equal(m.generate(**kw, max_new_tokens=n, eos_token_id=eos).cpu().numpy(), base)
