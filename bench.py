@@ -523,6 +523,19 @@ def main():
             per_kind[nm.split(" [")[0].replace("gemm_nt ViT ", "")] = [round(1e3 * ms.value / n.value, 1), round(fl.value / ms.value / 1e9, 1)]
         if n.value and (best is None or ms.value > best[2]):
             best = (nm, n.value, ms.value, fl.value)
+    # the pixel read of the frame tensor (north star: "coalesced HBM loads of the frame tensor evidenced by achieved GB/s"): im2col_strip_kernel,
+    # timed with hipEvents inside the timed region (prof kind 6: its "flops" field carries the pixel BYTES read)
+    pixel_read = None
+    n6, ms6, by6 = C.c_int64(), C.c_double(), C.c_double()
+    eng.lib.eilev_prof_collect(6, C.byref(n6), C.byref(ms6), C.byref(by6))
+    if n6.value and ms6.value > 0:
+        rd = by6.value / (ms6.value * 1e-3) / 1e9
+        wr = rd * (640.0 / 588.0)  # the patch rows it writes (K = 3 x 14 x 14 = 588 padded to 640 bf16), same element size as bf16 pixels
+        pixel_read = {"kernel": "im2col_strip_kernel (frame tensor (N,3,T,224,224) -> patch rows; one workgroup per (frame, patch row), coalesced 16-byte loads)",
+                      "launches": int(n6.value), "avg_launch_us": round(1e3 * ms6.value / n6.value, 1),
+                      "pixel_bytes_per_launch": int(by6.value / n6.value), "achieved_read_GB_s": round(rd, 1),
+                      "achieved_read_plus_write_GB_s": round(rd + wr, 1), "hbm_peak_GB_s": 8000.0,
+                      "frac_of_hbm_peak_read_plus_write": round((rd + wr) / 8000.0, 4)}
     eng.lib.eilev_prof_enable(0)
 
     # the exchange of the timed steps: bytes, time on the side stream, and the part of it the ViT did not cover (rank 0's view)
@@ -588,6 +601,8 @@ def main():
                                "mfma_busy_frac_pmc": (tr or {}).get("mfma_busy_frac"), "effective_clock_ghz_pmc": (tr or {}).get("eff_clock_ghz"),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}
+        if pixel_read is not None:
+            res["pixel_read"] = pixel_read
         if sharded is not None:
             res["sharded_check"] = sharded
         if exchange_info is not None:

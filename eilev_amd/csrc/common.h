@@ -202,7 +202,12 @@ struct GemmArgs {
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm.hip, object 2 (see EILEV_GEMM_PART)
-int launch_a4(const GemmArgs &g, hipStream_t s);                    // gemm.hip, object 3: gemm_a4.h
+int launch_a4(const GemmArgs &g, hipStream_t s);
+// gemv.hip: nn.Linear on M <= 8 rows as row dot products with the LayerNorm / flash-decoding merge in its prologue
+bool gemv_rows_ok(int M, int N, int K);
+int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const float *part, int heads, int hd,
+                     int nsplit, const bf16 *W, const bf16 *bias, const bf16 *resid, int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N,
+                     int K, int epi, float scale, int scale_cols, hipStream_t s);                    // gemm.hip, object 3: gemm_a4.h
 int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
                      int cols, float eps, hipStream_t s);
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,

@@ -1,0 +1,264 @@
+// gemv.hip — the language-model decode step at SMALL batch (M <= 8 rows: latency mode, beam search, one sample per GPU when a
+// global step is strong-scaled over 8 GPUs): nn.Linear as row dot products, one output row per wave pass, with the work of the
+// kernels AROUND the linear folded into its prologue / epilogue so that an OPT block is 5 launches instead of 8-9.
+//
+// Replaces, for one decode step of hf OPTDecoderLayer (modeling_opt.py:151-179, 226-247) via GenerationMixin._sample
+// (ref:eilev/model/v2.py:318-322):
+//   self_attn_layer_norm + q|k|v         -> gemv_rows_kernel<PRO_LN>            (LayerNorm recomputed per workgroup: M x 2560 values)
+//   flash-decoding merge + out_proj + x  -> gemv_rows_kernel<PRO_MERGE / PRO_X> (no split-K, no reduce launch)
+//   final_layer_norm + fc1 + ReLU        -> gemv_rows_kernel<PRO_LN>
+//   fc2 + residual                       -> gemv_rows_kernel<PRO_X>
+//   final_layer_norm + lm_head           -> gemv_rows_kernel<PRO_LN>, fp32 logits
+// Round 2 measured the batch-1 step at 2.64 ms per token: per block 43.6 us of weight streaming and 40 us in seven small kernels, each
+// at its 4.5-6 us launch floor.  The MFMA weight-streaming kernels (gemm.hip) stay for 9 <= M <= 32.
+//
+// Arithmetic: weights [N, K] row-major bf16; a wave owns output rows; lane l reads 16-byte chunks l, l + 64, ... of the row (1 KiB per
+// load instruction, fully coalesced) and the matching chunks of the M activation rows from LDS (staged once per workgroup, bf16 — the
+// values the separate LayerNorm / merge kernels would have stored); v_dot2c_f32_bf16 accumulates in fp32; 6 xor-shuffle steps reduce
+// the 64 lane partials; the epilogue (bias, q scaling, ReLU, residual) runs on lane 0..M-1.
+// HBM-bound: the weight bytes are read exactly once; the activations (M x K x 2 B) come from L2 once per workgroup.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+enum { PRO_X = 0, PRO_LN = 1, PRO_MERGE = 2 };
+
+struct GemvArgs {
+    const bf16 *x;  // PRO_X / PRO_LN: (M, K) rows, leading dimension ldx
+    int64_t ldx;
+    const bf16 *gamma, *beta;  // PRO_LN
+    float eps;
+    const float *part;  // PRO_MERGE: flash-decoding partials (M, heads, nsplit, hd + 2): [max, sum, o[hd]]  (K = heads * hd)
+    int heads, hd, nsplit;
+    const bf16 *W;  // (N, K) row-major
+    const bf16 *bias, *resid;
+    int64_t ldr;
+    void *out;  // bf16 or f32 (M, N), leading dimension ldo
+    int64_t ldo;
+    int out_f32;
+    int M, N, K, KB;  // (KB = K: the whole rows are staged)
+    int rows_per_wave;
+    int epi;  // 0 none, 2 ReLU
+    float scale;  // columns [0, scale_cols) are multiplied by scale after the bias (q pre-scaling)
+    int scale_cols;
+};
+
+__device__ __forceinline__ float dot8(const u32x4_t &w, const u32x4_t &x, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // (copies first: __builtin_bit_cast applied directly to the vector element w[e] read element 0 for every e under hipcc 7.2)
+        const unsigned we = w[e], xe = x[e];
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, we), __builtin_bit_cast(bf16x2_t, xe), acc, false);
+    }
+    return acc;
+}
+
+// MR: the number of rows M, compile-time (1..8: a run-time bound made hipcc branch around every row's dot products).  The rows [M][K] are staged ONCE in LDS as bf16 (host: M * K * 2 <= 150 KB), the
+// wave then streams its output rows' weights one row after the other in sub-blocks of up to 8 chunks (8 KiB per wave) through a register
+// double buffer: the next sub-block's loads are in flight while the current one is multiplied.  The first sub-block is requested BEFORE
+// the prologue (the weights do not depend on the activations), so LayerNorm / merge latency hides under the first loads.
+// CPS: chunks (of 512 elements) per sub-block — compile-time, so that the loads and dot products of a sub-block are straight-line code
+// (with a run-time count hipcc branched around every load and drained the queue between them); K / 512 is a multiple of CPS.
+template <int MR, int PRO, int CPS>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16 *xs = reinterpret_cast<bf16 *>(smem);  // [M][K]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int M = MR;
+    const int K = a.K, nch = K >> 9;  // 512-element chunks per row
+    const int nsb = nch / CPS;                 // sub-blocks of CPS chunks per row
+    const int rpw = a.rows_per_wave;
+    const int n_first = (blockIdx.x * 4 + wid) * rpw;
+    const int items = rpw * nsb;
+    u32x4_t wv[2][CPS];
+    auto load_item = [&](int it, auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+        const int r = it / nsb, sb = it - r * nsb;
+        const int n = n_first + r;
+        const bf16 *wrow = a.W + (int64_t)(n < a.N ? n : a.N - 1) * K + sb * (CPS * 512) + lane * 8;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) wv[B][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wrow + c * 512));
+    };
+    load_item(0, std::integral_constant<int, 0>{});
+
+    // ---- prologue: the activation rows -> LDS (bf16) ------------------------------------------------------------------------------
+    if constexpr (PRO == PRO_LN) {
+        // one wave per row (rows wid, wid + 4), the row held in registers: mean, then the centred second moment, like layernorm_kernel
+        for (int m = wid; m < M; m += 4) {
+            const bf16 *row = a.x + (int64_t)m * a.ldx;
+            float f[8][8];  // K <= 4096: up to 8 chunks of 8 per lane
+            float s1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nch) {
+                    unpack8(*reinterpret_cast<const bf16x8 *>(row + c * 512 + lane * 8), f[c]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1 += f[c][e];
+                }
+            const float mean = wave_sum(s1) / (float)K;
+            float s2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s2 = fmaf(f[c][e] - mean, f[c][e] - mean, s2);
+                }
+            const float rstd = rsqrtf(wave_sum(s2) / (float)K + a.eps);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nch) {
+                    float gm[8], bt[8];
+                    unpack8(*reinterpret_cast<const bf16x8 *>(a.gamma + c * 512 + lane * 8), gm);
+                    unpack8(*reinterpret_cast<const bf16x8 *>(a.beta + c * 512 + lane * 8), bt);
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)((f[c][e] - mean) * rstd * gm[e] + bt[e]);
+                    *reinterpret_cast<bf16x8 *>(xs + (int64_t)m * K + c * 512 + lane * 8) = v;
+                }
+        }
+    } else if constexpr (PRO == PRO_MERGE) {
+        // merged attention rows: o = sum_s w_s o_s / sum_s w_s l_s, w_s = exp(max_s - max) (attn_decode_merge_kernel's arithmetic)
+        for (int idx = tid * 8; idx < M * K; idx += 2048) {
+            const int m = idx / K, k = idx - m * K;
+            const int h = k / a.hd, t0 = k - h * a.hd;
+            const float *pp = a.part + ((int64_t)m * a.heads + h) * a.nsplit * (a.hd + 2);
+            float mx = -1e30f;
+            for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, pp[s * (a.hd + 2)]);
+            float l = 0.0f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.nsplit; ++s) {
+                const float *ps = pp + s * (a.hd + 2);
+                const float wgt = ps[1] > 0.0f ? __expf(ps[0] - mx) : 0.0f;
+                l += wgt * ps[1];
+                if (wgt > 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += wgt * ps[2 + t0 + e];
+                }
+            }
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)(l > 0.0f ? o[e] / l : 0.0f);
+            *reinterpret_cast<bf16x8 *>(xs + idx) = v;
+        }
+    } else {
+        for (int idx = tid * 8; idx < M * K; idx += 2048) {
+            const int m = idx / K, k = idx - m * K;
+            *reinterpret_cast<bf16x8 *>(xs + idx) = *reinterpret_cast<const bf16x8 *>(a.x + (int64_t)m * a.ldx + k);
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop: item = (row of this wave, sub-block of the row) ------------------------------------------------------------------
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.0f;
+    auto compute_item = [&](int it, auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+        const int r = it / nsb, sb = it - r * nsb;
+        const bf16 *xb = xs + sb * (CPS * 512) + lane * 8;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                acc[m] = dot8(wv[B][c], *reinterpret_cast<const u32x4_t *>(xb + m * K + c * 512), acc[m]);
+        }
+        if (sb + 1 == nsb) {  // the row is complete: reduce over lanes, epilogue on lane m
+            const int n = n_first + r;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float t = wave_sum(acc[m]);
+                acc[m] = 0.0f;
+                if (lane == m && n < a.N) {
+                    float v = t;
+                    if (a.bias) v += (float)a.bias[n];
+                    if (n < a.scale_cols) v *= a.scale;
+                    if (a.epi == 2) v = fmaxf(v, 0.0f);
+                    if (a.resid) v += (float)a.resid[(int64_t)m * a.ldr + n];
+                    if (a.out_f32) reinterpret_cast<float *>(a.out)[(int64_t)m * a.ldo + n] = v;
+                    else reinterpret_cast<bf16 *>(a.out)[(int64_t)m * a.ldo + n] = (bf16)v;
+                }
+            }
+        }
+    };
+    for (int it = 0; it < items; it += 2) {
+        if (it + 1 < items) load_item(it + 1, std::integral_constant<int, 1>{});
+        compute_item(it, std::integral_constant<int, 0>{});
+        if (it + 1 < items) {
+            if (it + 2 < items) load_item(it + 2, std::integral_constant<int, 0>{});
+            compute_item(it + 1, std::integral_constant<int, 1>{});
+        }
+    }
+}
+
+template <int MR, int PRO, int CPS>
+int launch_rows_c(const GemvArgs &a, int grid, size_t smem, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemv_rows_kernel<MR, PRO, CPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemv_rows_kernel<MR, PRO, CPS>), dim3(grid), dim3(256), smem, s, a);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
+template <int MR, int PRO>
+int launch_rows_m(const GemvArgs &a, int grid, size_t smem, hipStream_t s) {
+    const int nch = a.K >> 9;  // sub-block = 8 or 5 chunks, whichever divides the row (2560: 5, 10240: 4 x 5, 4096: 8, 16384: 4 x 8); else 1
+    if (nch % 8 == 0) return launch_rows_c<MR, PRO, 8>(a, grid, smem, s);
+    if (nch % 5 == 0) return launch_rows_c<MR, PRO, 5>(a, grid, smem, s);
+    return launch_rows_c<MR, PRO, 1>(a, grid, smem, s);
+}
+
+template <int PRO>
+int launch_rows_p(const GemvArgs &a, int grid, size_t smem, hipStream_t s) {
+    switch (a.M) {
+        case 1: return launch_rows_m<1, PRO>(a, grid, smem, s);
+        case 2: return launch_rows_m<2, PRO>(a, grid, smem, s);
+        case 3: return launch_rows_m<3, PRO>(a, grid, smem, s);
+        case 4: return launch_rows_m<4, PRO>(a, grid, smem, s);
+        case 5: return launch_rows_m<5, PRO>(a, grid, smem, s);
+        case 6: return launch_rows_m<6, PRO>(a, grid, smem, s);
+        case 7: return launch_rows_m<7, PRO>(a, grid, smem, s);
+        default: return launch_rows_m<8, PRO>(a, grid, smem, s);
+    }
+}
+
+}  // namespace
+
+// M rows of K bf16 must fit the LDS staging (150 KB): M = 8 with K = 10240 (160 KB) does not — those shapes keep the MFMA kernels
+bool gemv_rows_ok(int M, int N, int K) { return M >= 1 && M <= 8 && K % 512 == 0 && K >= 512 && N >= 1 && (int64_t)M * K * 2 <= 150 * 1024; }
+
+// C[M, N] = epi((pro(x) . W^T + bias) [* scale on the first scale_cols columns]) (+ resid), M <= 8.  pro: 0 = x as given, 1 = LayerNorm
+// (gamma, beta, eps) of x, 2 = merge of the flash-decoding partials `part` (heads x nsplit x (hd + 2) floats per row).
+int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const float *part, int heads, int hd,
+                     int nsplit, const bf16 *W, const bf16 *bias, const bf16 *resid, int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N,
+                     int K, int epi, float scale, int scale_cols, hipStream_t s) {
+    if (!gemv_rows_ok(M, N, K) || !W || !out) return EILEV_E_UNSUPPORTED;
+    if ((pro != PRO_MERGE && (!x || (ldx & 7) || ((uintptr_t)x & 15))) || (pro == PRO_LN && (!gamma || !beta)) ||
+        (pro == PRO_MERGE && (!part || heads * hd != K || (hd & 7))) || ((uintptr_t)W & 15))
+        return EILEV_E_BADARG;
+    GemvArgs a;
+    a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.part = part; a.heads = heads; a.hd = hd; a.nsplit = nsplit;
+    a.W = W; a.bias = bias; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo; a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K;
+    a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;
+    if (pro == PRO_LN && K > 4096) return EILEV_E_UNSUPPORTED;  // the LayerNorm prologue holds a row in registers: 8 chunks of 512
+    a.KB = K;
+    // rows per wave: enough workgroups to cover the CUs a few times over, two rows in flight per wave pass
+    const int waves_target = 256 * 4 * 2;
+    int rpw = (N + waves_target - 1) / waves_target;
+    rpw = rpw < 2 ? 2 : rpw;
+    a.rows_per_wave = rpw;
+    const int grid = (N + 4 * rpw - 1) / (4 * rpw);
+    const size_t smem = (size_t)M * K * sizeof(bf16);
+    if (pro == PRO_LN) return launch_rows_p<PRO_LN>(a, grid, smem, s);
+    if (pro == PRO_MERGE) {  // (every workgroup repeats the merge: M <= 2 only)
+        if (M == 1) return launch_rows_m<1, PRO_MERGE>(a, grid, smem, s);
+        if (M == 2) return launch_rows_m<2, PRO_MERGE>(a, grid, smem, s);
+        return EILEV_E_UNSUPPORTED;
+    }
+    return launch_rows_p<PRO_X>(a, grid, smem, s);
+}

@@ -258,7 +258,14 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
                                                                 const int32_t *__restrict__ attn_mask,
                                                                 const int32_t *__restrict__ state, int seq_len, int cap,
                                                                 int heads, int hd, int64_t ldq, const float *__restrict__ rel_tab,
-                                                                int64_t rel_hs, int rel_off, int fuse_new) {
+                                                                int64_t rel_hs, int rel_off, int fuse_new,
+                                                                const bf16 *__restrict__ kg = nullptr, const bf16 *__restrict__ vg = nullptr,
+                                                                const int32_t *__restrict__ anc = nullptr, int beams = 1, int cap_g = 0,
+                                                                int rows = 0) {
+    // Beam search without moving the cache (anc != nullptr; eilev_opt_decode_step_beam): row b is beam b % beams of sample b / beams.
+    // Keys [0, seq_len) are the sample's PROMPT, held once in the prefill cache (kc / vc: `cap` = its capacity, row = sample); key
+    // seq_len + g is the g-th generated token of the hypothesis, written by whichever row held that hypothesis when it was generated:
+    // physical row anc[g * rows + b] of the generation cache (kg / vg, capacity cap_g).  The new token goes to this row's own slot.
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float sc[DEC_KEYS];
     __shared__ float red[DEC_KEYS * 17];  // per-key chunk partials (stride 17), later the p.V partials (nks * hd <= 2048)
@@ -267,8 +274,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
     const int d = heads * hd, nch = hd >> 3;
-    const int kv_total = min(cap, seq_len + (state ? state[0] : 0));
+    const int kv_total = anc ? min(seq_len + cap_g, seq_len + state[0]) : min(cap, seq_len + (state ? state[0] : 0));
     const int k0 = sp * DEC_KEYS, k1 = min(kv_total, k0 + DEC_KEYS);
+    const int srow = anc ? b / beams : b;  // row of the prompt cache and of the attention mask
     float *po = part + (((int64_t)b * heads + h) * nsplit + sp) * (hd + 2);
     if (k0 >= kv_total) {  // nothing in this split yet
         if (tid == 0) {
@@ -277,8 +285,13 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
         }
         return;
     }
-    const bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd;
-    const bf16 *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    const bf16 *kbase = kc + ((int64_t)srow * heads + h) * cap * hd;
+    const bf16 *vbase = vc + ((int64_t)srow * heads + h) * cap * hd;
+    auto key_row = [&](const bf16 *base, const bf16 *gen, int j) -> const bf16 * {
+        if (!anc || j < seq_len) return base + (int64_t)j * hd;
+        const int gi = j - seq_len;
+        return gen + (((int64_t)anc[(int64_t)gi * rows + b] * heads + h) * cap_g + gi) * hd;
+    };
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
     // fuse_new: the newest key / value (slot kv_total - 1) is still only in the q|k|v row of this step.  The split that owns the
     // slot reads it from there and stores it into the cache (what a separate kv_write launch did before the attention).
@@ -286,7 +299,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
     if (slot_new >= k0 && slot_new < k1 && tid < 2 * nch) {
         const int which = tid / nch, cc = tid - which * nch;
-        bf16 *dst = const_cast<bf16 *>(which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8;
+        bf16 *dst = anc ? const_cast<bf16 *>(which ? vg : kg) + (((int64_t)b * heads + h) * cap_g + (slot_new - seq_len)) * hd + cc * 8
+                        : const_cast<bf16 *>(which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8;
         *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
     }
     __syncthreads();
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
 #pragma unroll 4
         for (int jj = ks; jj < nkeys; jj += nks) {
             float kv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? knew : kbase + (int64_t)(k0 + jj) * hd) + c * 8), kv);
+            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? knew : key_row(kbase, kg, k0 + jj)) + c * 8), kv);
             red[jj * 17 + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
         }
     }
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     if (j < k1) {
         float acc = 0.0f;
         for (int cc = 0; cc < nch; ++cc) acc += red[tid * 17 + cc];
-        const bool vis = j >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + j] != 0;
+        const bool vis = j >= seq_len || !attn_mask || attn_mask[(int64_t)srow * seq_len + j] != 0;
         if (rel_tab) acc += rel_tab[(int64_t)h * rel_hs + (rel_off >= 0 ? (j - (kv_total - 1)) + rel_off : j)];  // rel_off < 0: table of this query row
         s = vis ? acc : -1e30f;
     }
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
 #pragma unroll 4
         for (int jj = ks; jj < nkeys; jj += nks) {
             float vv[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? vnew : vbase + (int64_t)(k0 + jj) * hd) + c * 8), vv);
+            unpack8(*reinterpret_cast<const bf16x8 *>((k0 + jj == slot_new ? vnew : key_row(vbase, vg, k0 + jj)) + c * 8), vv);
             const float pj = sc[jj];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
@@ -607,14 +621,17 @@ size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
 }
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
-                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0) {
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0,
+                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0) {
     if (ldq == 0) ldq = 3 * (int64_t)heads * hd;  // q | k | v rows
     if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
-    const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
-    if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap)) return EILEV_E_WORKSPACE;
+    const int cap_all = anc ? seq_len + cap_g : cap;  // beam form: prompt keys (prefill cache) + generated keys (generation cache)
+    const int nsplit = (cap_all + DEC_KEYS - 1) / DEC_KEYS;
+    if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap_all)) return EILEV_E_WORKSPACE;
     hipLaunchKernelGGL(attn_decode_split_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, kc, vc, scratch, attn_mask, state,
-                       seq_len, cap, heads, hd, ldq, rel_tab, rel_hs, rel_off, fuse_new);
+                       seq_len, cap, heads, hd, ldq, rel_tab, rel_hs, rel_off, fuse_new, kg, vg, anc, beams, cap_g, batch);
     EILEV_LAUNCH_CHECK();
+    if (!out) return EILEV_OK;  // the caller merges the partials itself (gemv.hip: in the prologue of out_proj)
     hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, nsplit);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;

@@ -24,7 +24,8 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
                     const int32_t *state, hipStream_t s, int slot0 = 0);
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
-                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0);
+                       int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0,
+                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0);
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
@@ -98,8 +99,13 @@ extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
 // probe / test switch: 1 = take the unfused patch path (im2col -> GEMM -> CLS rows -> LayerNorm) even where the fused kernel applies
 static int64_t g_ln_fold_min_rows = 65536;
 extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }
-static int g_no_fused_patch = 0;
-extern "C" int eilev_debug_no_fused_patch(int on) { g_no_fused_patch = on; return 0; }
+// Round 3: the UNFUSED patch path is the default — im2col_strip_kernel reads the frame tensor with coalesced 16-byte loads at 3.9 TB/s
+// (168 us per 1088 frames) and im2col + GEMM + CLS rows + LayerNorm take 0.93 ms per launch, while the fused patch_embed_ln_kernel takes
+// 2.74 ms (0.69 TB/s on the pixels: 50 spilled VGPRs in its K loop, W re-streamed from L2 by every workgroup).  The fused kernel
+// stays selectable (eilev_debug_fused_patch(1)) and parity-tested against this path.
+static int g_fused_patch = 0;
+extern "C" int eilev_debug_fused_patch(int on) { g_fused_patch = on; return 0; }
+extern "C" int eilev_debug_no_fused_patch(int on) { g_fused_patch = on ? 0 : g_fused_patch; return 0; }  // (kept for older probes: 1 = unfused)
 extern "C" const char *eilev_backend(void) { return "hip-gfx950"; }
 
 namespace {
@@ -260,7 +266,7 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     bool ln0_done = false;
     {
         const EilevVitLayer *L0 = d->v_layers > 0 ? &w->layers[0] : nullptr;
-        const int rc_ = g_no_fused_patch ? EILEV_E_UNSUPPORTED
+        const int rc_ = !g_fused_patch ? EILEV_E_UNSUPPORTED
                                          : launch_patch_embed_ln(pixels, pixels_dtype, wpad, (const bf16 *)w->patch_b, (const bf16 *)w->pos,
                                                                  (const bf16 *)w->cls, L0 ? (const bf16 *)L0->ln1_w : nullptr,
                                                                  L0 ? (const bf16 *)L0->ln1_b : nullptr, x, L0 ? ln : nullptr, F, (int)frames,
@@ -268,7 +274,10 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
         if (rc_ == EILEV_OK) {
             ln0_done = L0 != nullptr;
         } else if (rc_ == EILEV_E_UNSUPPORTED) {
+            // prof kind 6: the pixel read of the frame tensor ("flops" carries the BYTES of pixels read: bench.py reports GB/s)
+            prof_begin(6, (double)F * 3.0 * d->image_size * d->image_size * (pixels_dtype == 0 ? 4.0 : 2.0), s);
             RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
+            prof_end(s);
             GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
             g.patch_group = (int)G2;
             RC(launch_gemm(g, 5, s));
@@ -572,7 +581,57 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     return launch_gemm(g, 5, s);
 }
 
+// ---- small-batch decode (M <= 8 rows): the block as 5 launches of gemv.hip + the attention split ---------------------------------------
+int g_decode_rows = 1;  // probe / test switch (eilev_debug_decode_rows): 0 = the MFMA weight-streaming kernels at every batch size
+constexpr int kDecodeKeys = 256;  // keys per flash-decoding split (misc.hip DEC_KEYS)
+
+// Measured (tools/beam_probe.py, OPT-2.7B, L = 960, ms per token under hipGraph): rows 1: 2.27 against 2.64 for the MFMA weight-streaming
+// kernels, 2: 2.67 (~2.7), 3: 2.89 (~2.8), 5: 4.07 against 2.87 — every extra row costs the dot-product kernel a pass of LDS reads and
+// v_dot2c per weight chunk, the MFMA kernels nothing up to 16 rows.  So: M <= 2 (latency mode; one sample per GPU of a strong-scaled step).
+bool opt_rows_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M) {
+    if (!g_decode_rows || w->layers_w8 || M > 2) return false;
+    const int D = d->t_hidden;
+    if (!gemv_rows_ok((int)M, D, D) || !gemv_rows_ok((int)M, D, d->t_ffn) || (D / d->t_heads) % 8) return false;
+    for (int l = 0; l < d->t_layers; ++l) {  // q | k | v must be ONE [3 D, D] matrix with one bias vector (the engine packs them so)
+        const EilevOptLayer *L = &w->layers[l];
+        const bf16 *qw = (const bf16 *)L->q_w, *qb = (const bf16 *)L->q_b;
+        if ((const bf16 *)L->k_w != qw + (size_t)D * D || (const bf16 *)L->v_w != qw + 2 * (size_t)D * D || !qb || (const bf16 *)L->k_b != qb + D ||
+            (const bf16 *)L->v_b != qb + 2 * D)
+            return false;
+    }
+    return true;
+}
+// self_attn_layer_norm + q|k|v of block l from b.h into b.qkv (q pre-scaled)
+int opt_rows_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
+    const int D = d->t_hidden;
+    return launch_gemv_rows(1, b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, d->t_eps, nullptr, 0, 0, 0, (const bf16 *)L->q_w, (const bf16 *)L->q_b,
+                            nullptr, 0, b.qkv, 3 * D, 0, (int)M, 3 * D, D, 0, 1.0f / sqrtf((float)(D / d->t_heads)), D, s);
+}
+// (merge +) out_proj + residual, final_layer_norm + fc1 + ReLU, fc2 + residual: b.h -> b.h.  part != nullptr: the attention partials are
+// merged in the prologue of out_proj (M <= 2: every workgroup repeats the merge); otherwise b.att holds the merged rows.
+int opt_rows_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, const float *part, int nsplit, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
+    const int D = d->t_hidden, Ft = d->t_ffn, H = d->t_heads;
+    if (part) RC(launch_gemv_rows(2, nullptr, 0, nullptr, nullptr, 0.f, part, H, D / H, nsplit, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, D, b.h, D, 0,
+                                  (int)M, D, D, 0, 1.0f, 0, s));
+    else RC(launch_gemv_rows(0, b.att, D, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, D, b.h, D, 0, (int)M, D, D, 0,
+                             1.0f, 0, s));
+    RC(launch_gemv_rows(1, b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, d->t_eps, nullptr, 0, 0, 0, (const bf16 *)L->fc1_w, (const bf16 *)L->fc1_b, nullptr,
+                        0, b.ffn, Ft, 0, (int)M, Ft, D, 2, 1.0f, 0, s));
+    return launch_gemv_rows(0, b.ffn, Ft, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, (const bf16 *)L->fc2_w, (const bf16 *)L->fc2_b, b.h, D, b.h, D, 0, (int)M, D, Ft,
+                            0, 1.0f, 0, s);
+}
+// final_layer_norm + lm_head -> fp32 logits
+int opt_rows_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b, int64_t M, float *logits, hipStream_t s) {
+    const int D = d->t_hidden;
+    return launch_gemv_rows(1, b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, d->t_eps, nullptr, 0, 0, 0, (const bf16 *)w->embed_tokens, nullptr,
+                            nullptr, 0, logits, d->vocab, 1, (int)M, d->vocab, D, 0, 1.0f, 0, s);
+}
+
 }  // namespace
+
+extern "C" int eilev_debug_decode_rows(int on) { g_decode_rows = on; return 0; }
 
 extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
                                  const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
@@ -687,6 +746,20 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
     RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab,
                            d->max_pos + 1, b.h, (int)batch, D, s));
     const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    if (opt_rows_usable(d, w, batch)) {  // M <= 8: row-dot kernels with LayerNorm / merge in their prologues (gemv.hip): 5 launches + attention per block
+        float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
+        const int nsplit = (int)((kv_capacity + kDecodeKeys - 1) / kDecodeKeys);
+        const bool fuse_merge = batch <= 2;
+        for (int l = 0; l < d->t_layers; ++l) {
+            bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+            RC(opt_rows_qkv(d, w, l, b, batch, s));
+            RC(launch_attn_decode(b.qkv, kc, vc, fuse_merge ? nullptr : b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd, part,
+                                  kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
+            RC(opt_rows_tail(d, w, l, b, batch, fuse_merge ? part : nullptr, nsplit, s));
+        }
+        RC(opt_rows_head(d, w, b, batch, logits, s));
+        return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
+    }
     for (int l = 0; l < d->t_layers; ++l) {
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
@@ -703,6 +776,69 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));
     return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
+}
+
+namespace {
+__global__ void bump_step_kernel(int32_t *state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
+}
+}  // namespace
+
+// One decode step of beam search WITHOUT moving the KV cache (include/eilev.h): the prompt's keys / values stay in the prefill cache, one
+// row per SAMPLE; the generated tokens' in a generation cache, one row per beam SLOT; `ancestors[g][r]` names the slot that holds the g-th
+// generated token of the hypothesis now living in row r.  (Before: torch index_select of the whole cache per step — 1.6 GB at 5 beams.)
+extern "C" int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeights *w, const int64_t *tokens, int32_t *state,
+                                          const int32_t *attn_mask, const int32_t *n_valid, int64_t rows, int64_t beams, int64_t seq_len,
+                                          const void *kv_prompt, void *kv_gen, int64_t gen_capacity, const int32_t *ancestors, float *logits,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d || !w || !tokens || !state || !attn_mask || !n_valid || !kv_prompt || !kv_gen || !ancestors || !logits || !workspace) return EILEV_E_BADARG;
+    if (rows <= 0 || beams <= 0 || rows % beams || seq_len <= 0 || gen_capacity <= 0 || rows > 32) return EILEV_E_BADARG;
+    if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
+    if (workspace_bytes < eilev_opt_workspace_bytes(d, rows, 1)) return EILEV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->t_hidden, H = d->t_heads, hd = D / H;
+    const int64_t samples = rows / beams;
+    OptBufs b;
+    if (!carve_opt(d, rows, workspace, workspace_bytes, b)) return EILEV_E_WORKSPACE;
+    if (attn_decode_scratch_bytes((int)rows, H, hd, (int)(seq_len + gen_capacity)) > kSkinnyScratch / 2) return EILEV_E_WORKSPACE;
+    RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab, d->max_pos + 1, b.h,
+                           (int)rows, D, s));
+    const size_t per_p = (size_t)2 * samples * H * seq_len * hd, per_g = (size_t)2 * rows * H * gen_capacity * hd;
+    if (opt_rows_usable(d, w, rows)) {  // <= 8 rows (the sample script: 5 beams of one sample): the small-batch block of gemv.hip
+        float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
+        const int nsplit = (int)((seq_len + gen_capacity + kDecodeKeys - 1) / kDecodeKeys);
+        const bool fuse_merge = rows <= 2;
+        for (int l = 0; l < d->t_layers; ++l) {
+            const bf16 *kc = (const bf16 *)kv_prompt + l * per_p, *vc = kc + per_p / 2;
+            bf16 *kg = (bf16 *)kv_gen + l * per_g, *vg = kg + per_g / 2;
+            RC(opt_rows_qkv(d, w, l, b, rows, s));
+            RC(launch_attn_decode(b.qkv, kc, vc, fuse_merge ? nullptr : b.att, attn_mask, state, (int)rows, (int)seq_len, (int)seq_len, H, hd, part,
+                                  kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1, kg, vg, ancestors, (int)beams, (int)gen_capacity));
+            RC(opt_rows_tail(d, w, l, b, rows, fuse_merge ? part : nullptr, nsplit, s));
+        }
+        RC(opt_rows_head(d, w, b, rows, logits, s));
+        bump_step_kernel<<<1, 64, 0, s>>>(state);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
+    for (int l = 0; l < d->t_layers; ++l) {
+        const EilevOptLayer *L = &w->layers[l];
+        const bf16 *kc = (const bf16 *)kv_prompt + l * per_p, *vc = kc + per_p / 2;
+        bf16 *kg = (bf16 *)kv_gen + l * per_g, *vg = kg + per_g / 2;
+        if (l == 0) RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, rows, D, d->t_eps, s));
+        RC(opt_qkv(d, w, l, b, rows, s));
+        RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)rows, (int)seq_len, (int)seq_len, H, hd,
+                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1, kg, vg, ancestors, (int)beams,
+                              (int)gen_capacity));
+        const bool last = l + 1 == d->t_layers;
+        RC(opt_tail(d, w, l, b, rows, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b));
+    }
+    GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, rows, d->vocab, D, 0);
+    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    RC(launch_gemm(g, 5, s));
+    bump_step_kernel<<<1, 64, 0, s>>>(state);  // the step counter lives on the device: a captured step replays for every step
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
 }
 
 // =====================================================================================================
@@ -784,6 +920,14 @@ extern "C" int eilev_linear_a8w8(const uint8_t *a8, const float *a_scale, const 
     g.out_f32 = out_f32;
     g.A8 = a8; g.ascale = a_scale; g.W8 = w8; g.wscale = w_scale;
     return launch_gemm(g, 5, (hipStream_t)stream);
+}
+
+extern "C" int eilev_linear_rows(const void *x, const void *ln_gamma, const void *ln_beta, float eps, const void *w, const void *bias,
+                                 const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
+    if (!x || !w || !c || m <= 0 || n <= 0 || k <= 0 || n > 0x7fffffff || k > 0x7fffffff || (ln_gamma != nullptr) != (ln_beta != nullptr)) return EILEV_E_BADARG;
+    if (m > 8 || !gemv_rows_ok((int)m, (int)n, (int)k) || (epilogue != 0 && epilogue != 2)) return EILEV_E_UNSUPPORTED;
+    return launch_gemv_rows(ln_gamma ? 1 : 0, (const bf16 *)x, k, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, nullptr, 0, 0, 0, (const bf16 *)w,
+                            (const bf16 *)bias, (const bf16 *)residual, n, c, n, out_f32, (int)m, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
 }
 
 extern "C" int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y, int64_t rows, int64_t cols,

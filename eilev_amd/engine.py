@@ -494,11 +494,11 @@ class HipEngine:
 
 
     def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
-                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0):
+                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, use_graph=True):
         """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
 
-        The prompt is prefilled ONCE per sample and its KV cache replicated to the beams; every step reorders the cache
-        rows by the surviving beams' parents (torch index_select: plumbing) and runs one HIP decode step on all rows."""
+        The prompt is prefilled ONCE per sample; no cache row is ever copied (see below); one HIP decode step on all rows per
+        generated token, captured into a hipGraph and replayed."""
         from .beam import beam_search
 
         d = self.dims
@@ -511,36 +511,60 @@ class HipEngine:
             # independent in beam search); shorter results are padded with pad_id like HF pads finished hypotheses
             per = max(1, 32 // num_beams)
             parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
-                                      pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens) for i in range(0, B, per)]
+                                      pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens, use_graph) for i in range(0, B, per)]
             n = max(p.shape[1] for p in parts)
             return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
-        cap = L + max_new_tokens
         am = attention_mask.to(self.device, torch.int32).contiguous()
-        last, _, kv_small = self.prefill(inputs_embeds, am, kv_capacity=cap)
-        planes = 2 * d.t_layers
-        kv = kv_small.view(planes, B, -1).repeat_interleave(num_beams, dim=1).contiguous()
-        del kv_small
-        am_r = am.repeat_interleave(num_beams, dim=0).contiguous()
-        n_valid = am_r.sum(dim=1).to(torch.int32).contiguous()
+        # The KV cache is never moved (round 3; before: a torch index_select of the whole cache per step, 1.6 GB at 5 beams x L = 960):
+        # the prompt's keys / values stay in the prefill cache (one row per SAMPLE, capacity L), generated tokens go to a generation
+        # cache (one row per beam slot, capacity max_new_tokens) and `anc[g][r]` names the slot holding token g of the hypothesis now in
+        # row r — include/eilev.h eilev_opt_decode_step_beam.  A step = gather of that small table by the parents + one captured launch.
+        last, _, kv_prompt = self.prefill(inputs_embeds, am, kv_capacity=L)
+        gen_cap = max(1, max_new_tokens)
+        kv_gen = torch.empty(int(self.lib.eilev_opt_kv_cache_bytes(C.byref(d), R, gen_cap)), dtype=torch.uint8, device=self.device)
+        anc = torch.zeros((gen_cap, R), dtype=torch.int32, device=self.device)
+        ident32 = torch.arange(R, dtype=torch.int32, device=self.device)
+        n_valid = am.sum(dim=1).to(torch.int32).repeat_interleave(num_beams).contiguous()
         state = torch.zeros(2, dtype=torch.int32, device=self.device)
-        finished = torch.zeros(R, dtype=torch.uint8, device=self.device)
         tokens = torch.zeros(R, dtype=torch.int64, device=self.device)
-        scratch_out = torch.zeros((R, max_new_tokens), dtype=torch.int64, device=self.device)
         logits = torch.empty((R, d.vocab), dtype=torch.float32, device=self.device)
         nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), R, 1)
         ws = self._workspace("dec", nb)
         steps = [0]
+        graph = [None]
+
+        def launch():
+            abi.check(self.lib.eilev_opt_decode_step_beam(
+                C.byref(d), C.byref(self.pack.opt), _ptr(tokens), _ptr(state), _ptr(am), _ptr(n_valid), R, num_beams, L, _ptr(kv_prompt), _ptr(kv_gen),
+                gen_cap, _ptr(anc), _ptr(logits), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_decode_step_beam")
 
         def step(next_tokens, beam_src):
-            nonlocal kv
-            kv = kv.index_select(1, beam_src)  # row r continues the hypothesis that lived in row beam_src[r]
-            steps[0] += 1
-            state[0] = steps[0]               # tokens generated so far (the library reads it on the device)
+            t = steps[0]  # tokens generated before this one
+            if t > 0:
+                anc[:t] = anc[:t].index_select(1, beam_src)  # row r continues the hypothesis that lived in row beam_src[r]
+            anc[t] = ident32                                   # the token fed now: its K / V go to row r's own slot t
+            steps[0] = t + 1
             tokens.copy_(next_tokens)
-            abi.check(self.lib.eilev_opt_decode_step(
-                C.byref(d), C.byref(self.pack.opt), _ptr(tokens), _ptr(state), _ptr(am_r), _ptr(n_valid), R, L, _ptr(kv), cap,
-                _ptr(logits), _ptr(finished), -1, pad_id, _ptr(scratch_out), max_new_tokens, _ptr(ws), ws.numel(),
-                self._stream()), "eilev_opt_decode_step")
+            if t == 0:
+                state[0] = 1  # (the call increments it: every per-step quantity is on the device, so ONE captured step replays)
+            if use_graph and max_new_tokens > 2:
+                if graph[0] is None:
+                    if not self._decode_warm:
+                        keep = state.clone()
+                        launch()  # once per engine outside capture (lazy module loading); it rewrote this step's slot only
+                        state.copy_(keep)
+                        self._decode_warm = True
+                    gph = torch.cuda.CUDAGraph()
+                    side = torch.cuda.Stream(self.device)
+                    side.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(gph, stream=side):
+                            launch()
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                    graph[0] = gph
+                graph[0].replay()
+            else:
+                launch()
             return logits
 
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step

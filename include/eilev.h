@@ -384,6 +384,23 @@ int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *w, int64_t 
                           uint8_t *finished, int64_t eos_id, int64_t pad_id, int64_t *out_tokens,
                           int64_t max_new, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Beam search (the sample script's default call, ref:samples/eilev_generate_action_narration.py:60-73 -> hf
+ * GenerationMixin._beam_search generation/utils.py:3208-3560, which reorders the KV cache by the surviving beams' parents every
+ * step: `_temporary_reorder_cache`).  Here the cache is NOT moved: row r = beam r % beams of sample r / beams;
+ *   kv_prompt   the cache eilev_opt_prefill filled for the `rows / beams` SAMPLES with kv_capacity == seq_len (read only);
+ *   kv_gen      eilev_opt_kv_cache_bytes(d, rows, gen_capacity) bytes: slot g of row r = the g-th generated token that row r produced;
+ *   ancestors   (gen_capacity, rows) int32, device: ancestors[g][r] = the row whose slot g belongs to the hypothesis now in row r
+ *               (the caller gathers it by the step's parent indices: a few hundred integers instead of the cache);
+ *   attn_mask   (rows / beams, seq_len): the prompts' masks; n_valid (rows): number of visible prompt tokens per row;
+ *   state[0]    number of tokens generated so far (>= 1: tokens[r] is the state[0]-th, its K / V go to slot state[0] - 1 of row r;
+ *               the caller sets ancestors[state[0] - 1][r] = r); incremented by the call, so a captured step replays.
+ * logits (rows, vocab) f32.  Selection (top-2K, length penalty) stays with the caller. */
+int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeights *w, const int64_t *tokens, int32_t *state,
+                               const int32_t *attn_mask, const int32_t *n_valid, int64_t rows, int64_t beams,
+                               int64_t seq_len, const void *kv_prompt, void *kv_gen, int64_t gen_capacity,
+                               const int32_t *ancestors, float *logits, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* ---- building blocks exported for unit parity tests and the roofline probe --------------------
  * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]); epilogue: 0 none, 1 GELU(erf),
  * 2 ReLU.  out_f32 != 0 writes f32 instead of bf16 (HIP library). */
@@ -391,6 +408,13 @@ int eilev_linear(const void *a, const void *w, const void *bias, const void *res
                  int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream);
 int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y, int64_t rows,
                     int64_t cols, float eps, void *stream);
+/* The small-batch form of the decode step's linears (m <= 8 rows, k % 512 == 0): C = epilogue(LN(x) . W^T + bias) (+ residual)
+ * with the LayerNorm that feeds the linear (hf OPTDecoderLayer self_attn_layer_norm -> q|k|v, final_layer_norm -> fc1, decoder
+ * final_layer_norm -> lm_head: modeling_opt.py:226-247, 386) evaluated in the same launch; ln_gamma == NULL: plain linear.  The
+ * normalised rows are rounded to bf16 before the product (HIP library), as the separate LayerNorm kernel stores them.
+ * epilogue: 0 none, 2 ReLU.  Other shapes: EILEV_E_UNSUPPORTED (HIP library; eilev_linear / eilev_layernorm serve them). */
+int eilev_linear_rows(const void *x, const void *ln_gamma, const void *ln_beta, float eps, const void *w, const void *bias,
+                      const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream);
 /* Multi-head attention over packed projections. q: rows of length ldq with head h at column
  * h*head_dim (same for k, v with ldk, ldv); o: (batch, sq, heads*head_dim).  causal != 0 applies
  * key <= query + (skv - sq); key_mask: nullable (batch, skv) int32. scale multiplies q.k. */

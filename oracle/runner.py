@@ -311,8 +311,10 @@ class OracleModel:
         return np.concatenate((np.full((ids.shape[0], 1), start_id, np.int64), ids), axis=1)
 
     def generate_beam(self, pixels, input_ids, attn_mask, video_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1,
-                      pad_id=1, early_stopping=False):
-        """Beam search = reference generate(num_beams=k) with the oracle as the language model (eilev_amd.beam drives it)."""
+                      pad_id=1, early_stopping=False, no_move=False, trace=None):
+        """Beam search = reference generate(num_beams=k) with the oracle as the language model (eilev_amd.beam drives it).
+        no_move=True runs the steps through eilev_opt_decode_step_beam (the cache is never reordered: prompt cache + generation cache +
+        ancestor table, include/eilev.h) instead of reordering the cache rows like hf does; trace: a list that receives every step's logits."""
         import torch
 
         from eilev_amd.beam import beam_search
@@ -322,6 +324,36 @@ class OracleModel:
         B, L, _ = emb.shape
         R, cap = B * num_beams, L + max_new_tokens
         am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        if no_move:
+            last, _, kv_prompt = self.prefill(emb, am, kv_capacity=L, all_logits=False)
+            gen_cap = max(1, max_new_tokens)
+            kv_gen = np.zeros(int(self.lib.eilev_opt_kv_cache_bytes(C.byref(d), R, gen_cap)) // 4 + 1, np.float32)
+            anc = np.zeros((gen_cap, R), np.int32)
+            n_valid = np.repeat(am.sum(axis=1), num_beams).astype(np.int32)
+            state, tokens = np.zeros(2, np.int32), np.zeros(R, np.int64)
+            logits = np.empty((R, d.vocab), np.float32)
+            nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), R, 1)
+            ws = np.empty(nbytes // 4 + 1, np.float32)
+            steps = [0]
+
+            def step_nm(next_tokens, beam_src):
+                t = steps[0]
+                if t > 0:
+                    anc[:t] = anc[:t][:, beam_src.numpy()]
+                anc[t] = np.arange(R, dtype=np.int32)
+                steps[0] = t + 1
+                state[0] = t + 1
+                tokens[:] = next_tokens.numpy()
+                abi.check(self.lib.eilev_opt_decode_step_beam(C.byref(d), C.byref(self.pack.opt), _p(tokens), _p(state), _p(am), _p(n_valid), R,
+                                                              num_beams, L, _p(kv_prompt), _p(kv_gen), gen_cap, _p(anc), _p(logits), _p(ws), nbytes,
+                                                              None), "oracle beam decode")
+                assert state[0] == t + 2
+                if trace is not None:
+                    trace.append(logits.copy())
+                return torch.from_numpy(logits.copy())
+
+            return beam_search(step_nm, torch.from_numpy(last.copy()), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
+                               early_stopping).numpy()
         last, _, kv_small = self.prefill(emb, am, kv_capacity=cap, all_logits=False)
         planes = 2 * d.t_layers
         kv = [np.repeat(kv_small.reshape(planes, B, -1), num_beams, axis=1).copy()]
@@ -344,6 +376,8 @@ class OracleModel:
             abi.check(self.lib.eilev_opt_decode_step(C.byref(d), C.byref(self.pack.opt), _p(tokens), _p(state), _p(am_r), _p(n_valid),
                                                      R, L, _p(kv[0]), cap, _p(logits), _p(finished), -1, pad_id, _p(out),
                                                      max_new_tokens, _p(ws), nbytes, None), "oracle decode")
+            if trace is not None:
+                trace.append(logits.copy())
             return torch.from_numpy(logits.copy())
 
         ids = beam_search(step, torch.from_numpy(last.copy()), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping)

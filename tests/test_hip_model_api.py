@@ -162,7 +162,7 @@ def test_vision_model_debug_outputs_like_the_reference(golden_dir):
     fused = vm(px, return_dict=True)
     assert torch.equal(fused.last_hidden_state, o.last_hidden_state) and torch.equal(fused.pooler_output, o.pooler_output)
     tup = vm(px, output_hidden_states=True, return_dict=False)
-    assert len(tup) == 3 and len(tup[2]) == L + 1
+    assert len(tup) == 4 and tup[3] is None and len(tup[2]) == L + 1  # the fixed 4-tuple of ref:eilev/model/v2.py:103 (None placeholders)
 
 
 def test_c1_workload_through_the_model_class():

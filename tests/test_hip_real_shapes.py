@@ -138,16 +138,16 @@ def test_fused_patch_embed_layernorm_equals_unfused_path(cfg_name, frames, dtype
     raw = C.CDLL(abi.HIP_LIB_PATH)
     cfg, _, eng = models(cfg_name)
     px = torch.from_numpy(synth_pixels(3, frames, cfg.vision_config.image_size)).cuda().to(dtype)
+    ref, ref_pool = eng.vit(px, want_pooler=True)          # the default since round 3: im2col -> GEMM -> CLS rows -> LayerNorm
+    _, _, ref_hid, _ = eng.vit_debug(px, want_hidden=True, want_attn=False)
+    torch.cuda.synchronize()
     try:
-        raw.eilev_debug_no_fused_patch(1)
-        ref, ref_pool = eng.vit(px, want_pooler=True)
-        _, _, ref_hid, _ = eng.vit_debug(px, want_hidden=True, want_attn=False)
+        raw.eilev_debug_fused_patch(1)
+        got, pool = eng.vit(px, want_pooler=True)
+        _, _, hid, _ = eng.vit_debug(px, want_hidden=True, want_attn=False)
         torch.cuda.synchronize()
     finally:
-        raw.eilev_debug_no_fused_patch(0)
-    got, pool = eng.vit(px, want_pooler=True)
-    _, _, hid, _ = eng.vit_debug(px, want_hidden=True, want_attn=False)
-    torch.cuda.synchronize()
+        raw.eilev_debug_fused_patch(0)
     # hidden_states[0] = the embedding output x itself: identical up to one bf16 ulp of rare rounding ties (different K order)
     e0, r0 = host(hid[0]), host(ref_hid[0])
     assert np.abs(e0 - r0).max() <= 2.0 ** -7 * max(1.0, float(np.abs(r0).max())), float(np.abs(e0 - r0).max())

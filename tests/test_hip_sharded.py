@@ -145,3 +145,31 @@ def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["clips_per_step"] == 2 * 2 * 17 and res["scaling"] == "weak"
     assert res["sharded_check"]["ok"], res["sharded_check"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the direct-RCCL exchange between two REAL ranks")
+def test_two_real_rccl_ranks():
+    """When the box has at least two GPUs: one process per GPU, the ExchangePlan's all-to-all-v through eilev_exchange_clip_tokens
+    (grouped ncclSend / ncclRecv over xGMI), the all-gather form and the gradient all-reduce — tests/rccl_worker.py checks every
+    received row.  (The 1-GPU boxes of the round's GPU tier skip this; the driver's 8-GPU scaling run exercises the same entries.)"""
+    import subprocess
+    import sys
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker], env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                                                                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

@@ -119,6 +119,27 @@ def test_beam_search_matches_reference(golden_dir, models, name, tag, nb, lp):
 
 
 @pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tag,nb,lp", BEAMS)
+def test_beam_step_without_cache_moves_matches_reference(golden_dir, models, name, tag, nb, lp):
+    """eilev_opt_decode_step_beam (include/eilev.h: prompt cache + generation cache + ancestor table, nothing reordered) pins to the
+    reference's `generate(num_beams=k)` token for token, and its per-step logits are those of the cache-reordering form hf implements
+    (bit for bit in the fp32 oracle: the same dot products in the same order)."""
+    g, meta, cfg, px = load_case(golden_dir, name)
+    if f"fp32_{tag}" not in g.files:
+        pytest.skip("batch * beams > 16 rows")
+    m = models(meta["config"])
+    n = meta["new_tokens"]
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"], n, nb, lp)
+    t_move, t_nomove = [], []
+    ids = m.generate_beam(*args, eos_id=int(g["fp32_eos_id"]), no_move=True)
+    assert np.array_equal(ids, g[f"fp32_{tag}"]), (ids, g[f"fp32_{tag}"])
+    free = m.generate_beam(*args, eos_id=-1, no_move=True, trace=t_nomove)
+    assert np.array_equal(free, g[f"fp32_{tag}_free"])
+    m.generate_beam(*args, eos_id=-1, trace=t_move)
+    assert len(t_move) == len(t_nomove) and all(np.array_equal(a, b) for a, b in zip(t_move, t_nomove))
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_classify_matches_reference(golden_dir, models, name):
     """eilev_opt_extend + the class log-likelihood bookkeeping == reference classify() (ref:eilev/model/v2.py:326-501),
     chunked or not; and the KV-cache continuation == one full forward over prompt + class tokens."""
