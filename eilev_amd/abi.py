@@ -414,7 +414,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 9:
+    if lib.eilev_abi_version() != 10:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

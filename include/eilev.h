@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 9
+#define EILEV_ABI_VERSION 10  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows (round 3) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Turn the text tools/prof_round2.sh writes (gpurun_out/r02_gemm_pmc.txt: one rocpd_pmc.py table per shape and counter group) into
-profiles/r02_gemm_traffic.json, the file bench.py reads `roofline.traffic` from.
+"""Turn the text tools/prof_round3.sh writes (gpurun_out/r03_gemm_pmc.txt: one rocpd_pmc.py table per shape and counter group) into
+profiles/r03_gemm_traffic.json, the file bench.py reads `roofline.traffic` from.
 
-    python tools/pmc_to_traffic.py gpurun_out/r02_gemm_pmc.txt > profiles/r02_gemm_traffic.json
+    python tools/pmc_to_traffic.py gpurun_out/r03_gemm_pmc.txt > profiles/r03_gemm_traffic.json
 """
 import json
 import re
@@ -27,9 +27,9 @@ for line in open(sys.argv[1]):
     if m and cur and not (m.group(1) == "_dur_us" and "_dur_us" in vals[cur]):  # duration of the first (SQ / GRBM) pass
         vals[cur][m.group(1)] = float(m.group(2))
 out = {"_comment": "HBM/fabric traffic and MFMA-busy counters of the ViT GEMM kernels the bench runs (the LayerNorm-folded blocks: fc1 / qkv = "
-                   "consumer kernels gemm_pp4_kernel<EPI,false,1>, proj / fc2 = statistics producers gemm_pp4_kernel<0,false,2>), round 2: "
+                   "consumer kernels gemm_pp4_kernel<EPI,false,1>, proj / fc2 = statistics producers gemm_pp4_kernel<0,false,2>), round 3: "
                    "rocprofv3 --pmc, one counter group per pass with --kernel-trace only; PROBE_M=279616 tools/gemm_probe.py 0 <shape> 1 = the "
-                   "bench launch shape, random bf16 operands; tools/prof_round2.sh; raw: profiles/r02_gemm_pmc.txt.  bytes = (2*FETCH_SIZE + "
+                   "bench launch shape, random bf16 operands; tools/prof_round3.sh; raw: profiles/r03_gemm_pmc.txt.  bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream).  These are "
                    "L2 <-> fabric bytes: re-reads of an A / W panel by another XCD or a later tile batch that the 256-MB Infinity Cache serves "
                    "are counted, so the figure is an UPPER bound of the HBM bytes (DESIGN 3c).  fc2's A operand exceeds the 32-bit DMA offset "
