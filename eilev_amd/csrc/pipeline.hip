@@ -581,6 +581,51 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     return launch_gemm(g, 5, s);
 }
 
+// ---- decode: weight prefetch into the Infinity Cache on a parallel branch (probe: eilev_debug_decode_prefetch) --------------------------
+// The GEMVs of a decode step are latency-bound (2.2 TB/s at 32 rows) while the attention before them is HBM-bound on the KV cache; the
+// weights do not depend on activations, so block l's out_proj / fc1 / fc2 (+ block l + 1's q|k|v) can be pulled towards the 256-MB
+// memory-side cache by a touch kernel on a second stream while block l's attention runs.  One 16-byte load per 64-byte segment.
+int g_decode_prefetch = 0;
+hipStream_t g_pf_stream = nullptr;
+hipEvent_t g_pf_fork = nullptr, g_pf_join = nullptr;
+unsigned *g_pf_sink = nullptr;
+struct TouchArgs {
+    const void *p[4];
+    size_t bytes[4];
+};
+__global__ __launch_bounds__(256) void weight_touch_kernel(const TouchArgs a, unsigned *sink) {
+    unsigned acc = 0;
+    for (int sgm = 0; sgm < 4; ++sgm) {
+        const char *base = (const char *)a.p[sgm];
+        const size_t n = a.bytes[sgm] / 64;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + i * 64);
+            acc ^= v.x;
+        }
+    }
+    if (acc == 0x5ca1ab1eu && sink) *sink = acc;  // keeps the loads alive; practically never taken
+}
+int pf_init() {
+    if (g_pf_stream) return EILEV_OK;
+    EILEV_HIP_CHECK(hipStreamCreateWithFlags(&g_pf_stream, hipStreamNonBlocking));
+    EILEV_HIP_CHECK(hipEventCreateWithFlags(&g_pf_fork, hipEventDisableTiming));
+    EILEV_HIP_CHECK(hipEventCreateWithFlags(&g_pf_join, hipEventDisableTiming));
+    EILEV_HIP_CHECK(hipMalloc(&g_pf_sink, 64));
+    return EILEV_OK;
+}
+int pf_launch(const TouchArgs &t, hipStream_t s) {  // fork from s, touch on the side stream (joined once at the end of the step)
+    EILEV_HIP_CHECK(hipEventRecord(g_pf_fork, s));
+    EILEV_HIP_CHECK(hipStreamWaitEvent(g_pf_stream, g_pf_fork, 0));
+    hipLaunchKernelGGL(weight_touch_kernel, dim3(g_decode_prefetch > 1 ? g_decode_prefetch : 128), dim3(256), 0, g_pf_stream, t, g_pf_sink);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int pf_join(hipStream_t s) {
+    EILEV_HIP_CHECK(hipEventRecord(g_pf_join, g_pf_stream));
+    EILEV_HIP_CHECK(hipStreamWaitEvent(s, g_pf_join, 0));
+    return EILEV_OK;
+}
+
 // ---- small-batch decode (M <= 8 rows): the block as 5 launches of gemv.hip + the attention split ---------------------------------------
 int g_decode_rows = 1;  // probe / test switch (eilev_debug_decode_rows): 0 = the MFMA weight-streaming kernels at every batch size
 constexpr int kDecodeKeys = 256;  // keys per flash-decoding split (misc.hip DEC_KEYS)
@@ -632,6 +677,11 @@ int opt_rows_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b
 }  // namespace
 
 extern "C" int eilev_debug_decode_rows(int on) { g_decode_rows = on; return 0; }
+// 0 off, 1 = 128 workgroups, n > 1 = n.  Creates the side stream / events here: not inside a graph capture.
+extern "C" int eilev_debug_decode_prefetch(int workgroups) {
+    g_decode_prefetch = workgroups;
+    return workgroups ? pf_init() : 0;
+}
 
 extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
                                  const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
@@ -765,6 +815,15 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         if (l == 0) RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
         RC(opt_qkv(d, w, l, b, batch, s));
+        if (g_decode_prefetch && g_pf_stream && !w->layers_w8) {  // probe: this block's remaining weights (+ the next block's q|k|v) under its attention
+            TouchArgs t = {};
+            const size_t DD = (size_t)D * D * sizeof(bf16), DF = (size_t)D * d->t_ffn * sizeof(bf16);
+            t.p[0] = L->o_w; t.bytes[0] = DD;
+            t.p[1] = L->fc1_w; t.bytes[1] = DF;
+            t.p[2] = L->fc2_w; t.bytes[2] = DF;
+            if (l + 1 < d->t_layers) { t.p[3] = w->layers[l + 1].q_w; t.bytes[3] = 3 * DD; }
+            RC(pf_launch(t, s));
+        }
         // the new token's K / V go into the cache inside the attention kernel (fuse_new): one launch less per layer
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
                               b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
@@ -772,6 +831,7 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         const bool last = l + 1 == d->t_layers;
         RC(opt_tail(d, w, l, b, batch, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b));
     }
+    if (g_decode_prefetch && g_pf_stream && !w->layers_w8) RC(pf_join(s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));

@@ -127,7 +127,8 @@ def test_rccl_entries_on_a_one_rank_communicator():
         dist.destroy_process_group()
 
 
-def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows():
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows(world):
     """`python bench.py --gpus 2` must start two ranks itself (`--gpus` was dead).  One GPU here, so the ranks share it
     over gloo (`--share-gpu`); everything else — launcher, deal, exchange rounds on the side stream, LM sharding, max-over-ranks
     timing, the one JSON line — is the path the driver's scaling run takes."""
@@ -137,14 +138,21 @@ def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
-                        "--samples", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--share-gpu", "--steps", "1", "--warmup", "0",
+                        "--samples", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["config"]["clips_per_step"] == 2 * 2 * 17 and res["scaling"] == "weak"
+    assert res["n_gpus"] == world and res["config"]["clips_per_step"] == world * 2 * 17 and res["scaling"] == "weak"
     assert res["sharded_check"]["ok"], res["sharded_check"]
+    # round 3: what the exchange did during the timed steps, and the fixed-work (strong-scaling) phase of SURVEY 8(d) in the same job
+    ex = res["exchange"]
+    assert ex["rccl_ranks"] == world and ex["transport"] == "torch" and ex["rounds_per_step"] >= 1 and ex["sent_MB_per_step"] > 0
+    assert ex["exchange_ms_per_step_side_stream"] >= 0 and ex["exposed_ms_per_step"] >= 0
+    st = res["strong_scaling"]
+    assert st["scaling"] == "strong" and st["global_samples"] == 8 and st["clips_per_step"] == 136 and st["value"] > 0
+    assert st["clips_encoded_rank0"] == len(range(0, 136, world)) and st["samples_decoded_rank0"] == -(-8 // world)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the direct-RCCL exchange between two REAL ranks")
