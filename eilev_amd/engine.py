@@ -241,6 +241,29 @@ class HipEngine:
                                                  ws.numel(), self._stream()), "eilev_qformer_forward")
         return out
 
+    def qformer_hidden_states(self, image_embeds: torch.Tensor):
+        """Debug outputs of the Q-Former [ref:eilev/model/v2.py:187-193 `output_hidden_states`]: the tuple hf returns — the embedding output
+        (LayerNorm of the query tokens) and every block's output, each (N, num_query, Dq) bf16.  Slow path: the stack is run with its first
+        i blocks for i = 1 .. L (the C ABI has no per-block export; 78 block executions instead of 12 at L = 12)."""
+        d = self.dims
+        img = image_embeds.contiguous()
+        N, kv = img.shape[:2]
+        qt = self._keep["query_tokens"].reshape(d.num_query, d.q_hidden).contiguous()
+        emb = torch.empty_like(qt)
+        abi.check(self.lib.eilev_layernorm(_ptr(qt), _ptr(self._keep["qformer.layernorm.weight"]), _ptr(self._keep["qformer.layernorm.bias"]), _ptr(emb),
+                                           d.num_query, d.q_hidden, C.c_float(d.q_eps), self._stream()), "eilev_layernorm")
+        outs = [emb.unsqueeze(0).expand(N, -1, -1).contiguous()]
+        nb = self.lib.eilev_qformer_workspace_bytes(C.byref(d), N, kv)
+        ws = self._workspace("qf", nb)
+        for i in range(1, d.q_layers + 1):
+            di = type(d).from_buffer_copy(d)
+            di.q_layers = i
+            out = torch.empty((N, d.num_query, d.q_hidden), dtype=torch.bfloat16, device=self.device)
+            abi.check(self.lib.eilev_qformer_forward(C.byref(di), C.byref(self.pack.qf), _ptr(img), N, kv, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
+                      "eilev_qformer_forward")
+            outs.append(out)
+        return tuple(outs)
+
     def project(self, query_out: torch.Tensor, out: torch.Tensor = None):
         d = self.dims
         q = query_out.reshape(-1, d.q_hidden).contiguous()

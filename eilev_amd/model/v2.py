@@ -9,7 +9,8 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
 Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling are); ``output_attentions`` / ``output_hidden_states`` of the
-Q-Former and the language model inside the full model's ``forward`` (the vision wrapper serves them from a slow path).
+language model (and ``output_attentions`` of the Q-Former) inside the full model's ``forward`` — the vision wrapper serves both from a slow path,
+the Q-Former its hidden states.
 """
 from __future__ import annotations
 
@@ -287,6 +288,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             else:
                 img, pooled = eng.vit(pixel_values, want_pooler=True)
             q = eng.qformer(img)
+            self._qformer_debug = eng.qformer_hidden_states(img) if vision_debug[0] else None
             feats = eng.project(q)
             vision, qf = (img, pooled), q
         emb = eng.embed_scatter(input_ids, video_input_mask if feats is not None else None, feats)
@@ -358,9 +360,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                       decoder_attention_mask=None, output_attentions=None, output_hidden_states=None, labels=None, return_dict=None):
         if pixel_values is not None:
             assert video_input_mask is not None
-        # output_hidden_states / output_attentions: the VISION outputs carry them (slow path of the library, what
-        # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper); the fused Q-Former / language-model kernels do not
-        # export per-block tensors, their output objects keep these fields None
+        # output_hidden_states / output_attentions: the VISION outputs carry both (slow path of the library, what
+        # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper) and the Q-Former output carries hidden_states (r3: the stack
+        # re-run with its first i blocks); attention maps of the Q-Former and per-block tensors of the language model are not exported:
+        # those fields stay None
         self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
@@ -384,7 +387,9 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype),
                                                  hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
                                                  attentions=None if va is None else tuple(a.to(dtype) for a in va))
-            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
+            qh = getattr(self, "_qformer_debug", None)
+            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype),
+                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh))
         lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
@@ -418,7 +423,9 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             vis_out = BaseModelOutputWithPooling(last_hidden_state=vision[0].to(dtype), pooler_output=vision[1].to(dtype),
                                                  hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
                                                  attentions=None if va is None else tuple(a.to(dtype) for a in va))
-            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype))
+            qh = getattr(self, "_qformer_debug", None)
+            qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype),
+                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh))
         lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype))
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)

@@ -39,6 +39,13 @@ def test_forward_and_generate_like_the_reference(golden_dir, name, dtype):
     tup = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
             video_input_mask=t(g["video_input_mask"]), return_dict=False)
     assert torch.equal(tup[0], out.logits)
+    # output_hidden_states: the Q-Former's tuple = embedding output + one tensor per block, the last one its last_hidden_state (bit for bit)
+    dbg = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+            video_input_mask=t(g["video_input_mask"]), output_hidden_states=True, return_dict=True)
+    qh = dbg.qformer_outputs.hidden_states
+    assert len(qh) == m.config.qformer_config.num_hidden_layers + 1 and all(h.shape == dbg.qformer_outputs.last_hidden_state.shape for h in qh)
+    assert torch.equal(qh[-1], dbg.qformer_outputs.last_hidden_state) and torch.equal(dbg.logits, out.logits)
+    assert not torch.equal(qh[0], qh[1]) and len(dbg.vision_outputs.hidden_states) == m.config.vision_config.num_hidden_layers + 1
     n = meta["new_tokens"]
     ids = m.generate(input_ids=t(g["input_ids"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]),
                      attention_mask=t(g["attention_mask"]), max_new_tokens=n, num_beams=1, do_sample=False,
