@@ -753,6 +753,8 @@ int launch_attn_frame(const AttnArgs &a, hipStream_t s) {
     return EILEV_OK;
 }
 
+#include "attn_frame3.h"
+
 template <int NWQ>
 int launch_attn_v2(const AttnArgs &a, hipStream_t s) {
     size_t smem = (size_t)4 * 64 * a.hd * 2 + 256 + (2 * 64 + 2) * sizeof(int);
@@ -776,7 +778,10 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
     // whole-frame ViT attention: S = 257 (17 tiles of 16), hd = 88, no mask, q / k / v rows of one fused buffer
     if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && !a.drop_thr && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
         a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll) {
-        // probe flag 16 (512: with phase stamps): the round-2 joint-tile kernel — correct, but 17 % SLOWER than the kernel above (see its header)
+        // >= 512 frames: two wave groups one phase apart (attn_frame3.h; 512: with phase stamps): 2-13 % faster at 544 / 1088 frames over
+        // six boxes (profiles/r03_attn_frame3.log), slower below ~384 frames (its slots are longer: more exposed at the start and the end
+        // of a workgroup's walk).  Probe flag 16 forces it, 32 forbids it.
+        if (a.sq == 257 && !(a.dbg & 32) && ((a.dbg & (16 | 512)) || a.batch >= 512)) return launch_attn_frame3<88, 17>(a, s);
         return launch_attn_frame<88, 17>(a, s);
     }
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "patch.hip", "gemv.hip"]
-HEADERS = ["common.h", "gemm_a4.h", "gemm_a4_loop.inc", os.path.join("..", "..", "include", "eilev.h")]
+HEADERS = ["common.h", "gemm_a4.h", "gemm_a4_loop.inc", "attn_frame3.h", os.path.join("..", "..", "include", "eilev.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 LIB = os.path.join(HERE, "libeilev_hip.so")

@@ -211,11 +211,14 @@ def test_linear_operand_over_2gib(hip):
     assert torch.equal(out[::997], ref[::997]) or (out[::997].float() - ref[::997].float()).abs().max().item() <= 2e-2
 
 
-def test_attention_frame_joint_tile_variant(hip):
-    """The round-2 experimental frame kernel (probe flag 16: two query tiles per wave share every K / V fragment, the CLS row split over
-    the keys and merged from eight partial softmaxes) against the oracle and the default kernel."""
+@pytest.mark.parametrize("batch", [1, 3, 18, 41])
+def test_attention_frame_two_group_kernel(hip, batch):
+    """`attn_frame3_kernel` (two wave groups one phase apart: two query tiles per wave share every K / V fragment, the CLS row split over
+    the keys and merged from eight partial softmaxes; the default from 256 frames, forced here by probe flag 16) against the oracle and
+    the single-tile kernel.  1 / 3 frames: workgroups with one pair (no next pair to prefetch); 18: 288 pairs > 256 CUs, the buffer
+    ring and the deferred CLS merge run over two pairs; 41: the XCD-aware walk with a ragged last round."""
     raw = C.CDLL(abi.HIP_LIB_PATH)
-    batch, heads, sq, hd = 18, 16, 257, 88  # 288 pairs > 256 CUs: the ring and the deferred merge run over two pairs
+    heads, sq, hd = 16, 257, 88
     D = heads * hd
     q, k, v = (round_bf16(det_normal(n, (batch, sq, D))) for n in ("qj", "kj", "vj"))
     ref = np.empty((batch, sq, D), np.float32)
@@ -223,15 +226,44 @@ def test_attention_frame_joint_tile_variant(hip):
     assert orc.lib().eilev_attention(pp(q), pp(k), pp(v), pp(ref), batch, heads, sq, sq, hd, D, D, D, hd ** -0.5, 0, None, None) == 0
     dq, dk, dv = dev_bf16(q), dev_bf16(k), dev_bf16(v)
     outs = []
-    for flag in (0, 16):
+    for flag in (32, 16):
         raw.eilev_debug_attn_v1(flag << 1)
         try:
-            out = torch.empty((batch, sq, D), dtype=torch.bfloat16, device="cuda")
+            out = torch.full((batch, sq, D), float("nan"), dtype=torch.bfloat16, device="cuda")
             assert hip.eilev_attention(P(dq), P(dk), P(dv), P(out), batch, heads, sq, sq, hd, D, D, D, hd ** -0.5, 0, None, stream_ptr()) == 0
             torch.cuda.synchronize()
         finally:
             raw.eilev_debug_attn_v1(0)
         outs.append(host(out))
+    assert np.isfinite(outs[1]).all()
     assert np.abs(outs[1] - ref).max() <= 1e-2 * np.abs(ref).max()
     assert np.array_equal(outs[0][:, :256], outs[1][:, :256])           # same arithmetic for the 256 patch rows
     assert np.abs(outs[0][:, 256] - outs[1][:, 256]).max() <= 2.0 ** -7 * np.abs(ref[:, 256]).max()  # CLS row: another summation order
+
+
+def test_attention_frame_default_route_from_512_frames(hip):
+    """From 512 frames `eilev_attention` takes the two-group kernel on its own: the same bits as forcing it, the patch rows the same bits
+    as the single-tile kernel, and a sample of frames against fp32 softmax attention."""
+    raw = C.CDLL(abi.HIP_LIB_PATH)
+    batch, heads, sq, hd = 520, 16, 257, 88  # 32-33 pairs per workgroup
+    D = heads * hd
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    qkv = (torch.randn((batch, sq, 3 * D), device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    outs = {}
+    for flag in (0, 16, 32):
+        raw.eilev_debug_attn_v1(flag << 1)
+        try:
+            out = torch.full((batch, sq, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert hip.eilev_attention(C.c_void_p(qkv.data_ptr()), C.c_void_p(qkv.data_ptr() + 2 * D), C.c_void_p(qkv.data_ptr() + 4 * D), P(out),
+                                       batch, heads, sq, sq, hd, 3 * D, 3 * D, 3 * D, hd ** -0.5, 0, None, stream_ptr()) == 0
+            torch.cuda.synchronize()
+        finally:
+            raw.eilev_debug_attn_v1(0)
+        outs[flag] = out
+    assert torch.equal(outs[0], outs[16])
+    assert torch.equal(outs[0][:, :256], outs[32][:, :256])
+    for b in (0, 259, 519):
+        qf, kf, vf = (t.float().view(sq, heads, hd).transpose(0, 1) for t in qkv[b].split(D, dim=-1))
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf).transpose(0, 1).reshape(sq, D)
+        assert (outs[0][b].float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
