@@ -245,7 +245,7 @@ class WeightPack:
 EXPORTS = [
     "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward", "eilev_vit_forward_debug",
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
-    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_extend", "eilev_greedy_select",
+    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_prefill_debug", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_opt_decode_step_beam", "eilev_linear", "eilev_linear_rows", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
@@ -330,6 +330,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_opt_kv_cache_bytes.argtypes = [DP, i64, i64]
     lib.eilev_opt_prefill.restype = i32
     lib.eilev_opt_prefill.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.eilev_opt_prefill_debug.restype = i32
+    lib.eilev_opt_prefill_debug.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, vp, i64, vp, vp, vp, vp, sz, vp]
     lib.eilev_opt_extend.restype = i32
     lib.eilev_opt_extend.argtypes = [DP, C.POINTER(OptWeights), vp, vp, i64, i64, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_greedy_select.restype = i32
@@ -414,7 +416,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 10:
+    if lib.eilev_abi_version() != 11:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

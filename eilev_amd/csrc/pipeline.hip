@@ -683,9 +683,10 @@ extern "C" int eilev_debug_decode_prefetch(int workgroups) {
     return workgroups ? pf_init() : 0;
 }
 
-extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
-                                 const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
-                                 float *logits_last, float *logits_all, void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+int opt_prefill_impl(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask, int64_t batch,
+                     int64_t seq_len, void *kv_cache, int64_t kv_capacity, float *logits_last, float *logits_all, bf16 *hidden,
+                     void *workspace, size_t workspace_bytes, void *stream) {
     if (!d || !w || !inputs_embeds || !attn_mask || !kv_cache || !workspace || batch <= 0 || seq_len <= 0) return EILEV_E_BADARG;
     if (seq_len > kv_capacity || seq_len > d->max_pos) return EILEV_E_BADARG;
     if (!dims_ok_opt(d)) return EILEV_E_UNSUPPORTED;
@@ -698,9 +699,11 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
     RC(launch_pos_embed((const bf16 *)inputs_embeds, (const bf16 *)w->embed_positions, attn_mask, b.pid, b.h, (int)batch,
                         (int)seq_len, D, s));
     const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    const size_t hs_elems = (size_t)M * D;  // one entry of the hidden_states tuple
     for (int l = 0; l < d->t_layers; ++l) {
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+        if (hidden) EILEV_HIP_CHECK(hipMemcpyAsync(hidden + l * hs_elems, b.h, hs_elems * sizeof(bf16), hipMemcpyDeviceToDevice, s));  // the block's input
         RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, M, D, d->t_eps, s));
         RC(opt_qkv(d, w, l, b, M, s));
         RC(launch_kv_write(b.qkv, kc, vc, (int)batch, (int)seq_len, H, hd, (int)kv_capacity, (int)seq_len, nullptr, s));
@@ -715,6 +718,7 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         RC(opt_tail(d, w, l, b, M, s));
     }
     RC(launch_layernorm(b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, b.x, D, M, D, d->t_eps, s));
+    if (hidden) EILEV_HIP_CHECK(hipMemcpyAsync(hidden + (size_t)d->t_layers * hs_elems, b.x, hs_elems * sizeof(bf16), hipMemcpyDeviceToDevice, s));
     if (logits_all) {
         GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits_all, d->vocab, M, d->vocab, D, 0);
         g.out_f32 = 1;
@@ -728,6 +732,22 @@ extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, c
         RC(launch_gemm(g, 5, s));
     }
     return EILEV_OK;
+}
+}  // namespace
+
+extern "C" int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
+                                 const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
+                                 float *logits_last, float *logits_all, void *workspace, size_t workspace_bytes, void *stream) {
+    return opt_prefill_impl(d, w, inputs_embeds, attn_mask, batch, seq_len, kv_cache, kv_capacity, logits_last, logits_all, nullptr, workspace,
+                            workspace_bytes, stream);
+}
+extern "C" int eilev_opt_prefill_debug(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
+                                       const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache, int64_t kv_capacity,
+                                       float *logits_last, float *logits_all, void *hidden_states, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    if (!hidden_states) return EILEV_E_BADARG;
+    return opt_prefill_impl(d, w, inputs_embeds, attn_mask, batch, seq_len, kv_cache, kv_capacity, logits_last, logits_all, (bf16 *)hidden_states,
+                            workspace, workspace_bytes, stream);
 }
 
 extern "C" int eilev_opt_extend(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask,

@@ -351,7 +351,9 @@ class HipEngine:
         # not zeroed (10 GB at batch 32): every slot is written (kv_write) before any kernel reads it
         return torch.empty(int(nb), dtype=torch.uint8, device=self.device)
 
-    def prefill(self, inputs_embeds, attention_mask, kv_cache=None, kv_capacity=None, all_logits=False, last_logits=True):
+    def prefill(self, inputs_embeds, attention_mask, kv_cache=None, kv_capacity=None, all_logits=False, last_logits=True, hidden_states=False):
+        """OPT prefill.  ``hidden_states=True`` appends the tuple hf returns under ``output_hidden_states`` (every block's input, then the
+        output of final_layer_norm; `eilev_opt_prefill_debug`) as a fourth result, (t_layers + 1, B, L, Dt) bf16."""
         d = self.dims
         x = inputs_embeds.contiguous()
         B, L, _ = x.shape
@@ -363,6 +365,11 @@ class HipEngine:
         alll = torch.empty((B, L, d.vocab), dtype=torch.float32, device=self.device) if all_logits else None
         nb = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, L)
         ws = self._workspace("opt", nb)
+        if hidden_states:
+            hs = torch.empty((d.t_layers + 1, B, L, d.t_hidden), dtype=torch.bfloat16, device=self.device)
+            abi.check(self.lib.eilev_opt_prefill_debug(C.byref(d), C.byref(self.pack.opt), _ptr(x), _ptr(am), B, L, _ptr(kv_cache), cap,
+                                                       _ptr(last), _ptr(alll), _ptr(hs), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_prefill_debug")
+            return last, alll, kv_cache, hs
         abi.check(self.lib.eilev_opt_prefill(C.byref(d), C.byref(self.pack.opt), _ptr(x), _ptr(am), B, L, _ptr(kv_cache), cap,
                                              _ptr(last), _ptr(alll), _ptr(ws), ws.numel(), self._stream()), "eilev_opt_prefill")
         return last, alll, kv_cache

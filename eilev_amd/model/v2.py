@@ -8,9 +8,9 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
-Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling are); ``output_attentions`` / ``output_hidden_states`` of the
-language model (and ``output_attentions`` of the Q-Former) inside the full model's ``forward`` — the vision wrapper serves both from a slow path,
-the Q-Former its hidden states.
+Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling are); ``output_attentions`` of the language
+model and of the Q-Former and ``output_hidden_states`` of the T5 stacks inside the full model's ``forward`` (those fields stay ``None``) — the
+vision wrapper serves both flags from a slow path, the Q-Former and the OPT language model their hidden states.
 """
 from __future__ import annotations
 
@@ -362,8 +362,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             assert video_input_mask is not None
         # output_hidden_states / output_attentions: the VISION outputs carry both (slow path of the library, what
         # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper) and the Q-Former output carries hidden_states (r3: the stack
-        # re-run with its first i blocks); attention maps of the Q-Former and per-block tensors of the language model are not exported:
-        # those fields stay None
+        # re-run with its first i blocks) and the OPT language model's output carries hidden_states (r3: eilev_opt_prefill_debug); the
+        # attention maps of the Q-Former and of the language model, and the T5 stacks' per-block tensors, are not exported: those stay None
         self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
@@ -373,7 +373,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             attention_mask = torch.ones_like(input_ids)
         if self._is_t5:
             return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict)
-        _, logits32, _ = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False)
+        lm_hidden = None
+        if output_hidden_states:  # hf OPTDecoder's tuple: every block's input, then the output of final_layer_norm
+            _, logits32, _, hs = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False, hidden_states=True)
+            lm_hidden = tuple(h.to(dtype) for h in hs.unbind(0))
+        else:
+            _, logits32, _ = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False)
         loss = None
         if labels is not None:
             # HF causal-LM loss: shifted CE, ignore_index -100 (hf loss_utils.ForCausalLMLoss)
@@ -390,7 +395,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             qh = getattr(self, "_qformer_debug", None)
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype),
                                                                   hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh))
-        lm_out = CausalLMOutputWithPast(loss=loss, logits=logits)
+        lm_out = CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=lm_hidden)
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
             return ((loss,) + out) if loss is not None else out

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 10  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows (round 3) */
+#define EILEV_ABI_VERSION 11  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -294,6 +294,15 @@ int eilev_opt_prefill(const EilevDims *d, const EilevOptWeights *w, const void *
                       const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache,
                       int64_t kv_capacity, float *logits_last, float *logits_all,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* eilev_opt_prefill that also exports what hf returns under `output_hidden_states=True` (ref:eilev/model/v2.py:220-227 hands the flag
+ * to the language model; hf modeling_opt.py OPTDecoder.forward collects the input of every block and, last, the output of
+ * final_layer_norm): hidden_states [t_layers + 1][B][L][t_hidden] in the activation dtype — [0] inputs_embeds + positions,
+ * [l] the residual stream after block l - 1, [t_layers] AFTER final_layer_norm (the rows the lm_head sees).  Same arithmetic and
+ * the same logits as eilev_opt_prefill; the extra cost is one device copy per block. */
+int eilev_opt_prefill_debug(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds,
+                            const int32_t *attn_mask, int64_t batch, int64_t seq_len, void *kv_cache,
+                            int64_t kv_capacity, float *logits_last, float *logits_all, void *hidden_states,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- stage 4b: continue a prefilled sequence (classify) ---------------------------------------------
  * Runs `new_len` further positions per row against a KV cache that already holds `past_len` entries.

@@ -123,7 +123,7 @@ class OracleModel:
         feats = self.project(self.qformer(img))
         return self.embed_scatter(input_ids, video_mask, feats)
 
-    def prefill(self, inputs_embeds, attn_mask, kv_capacity=None, all_logits=True):
+    def prefill(self, inputs_embeds, attn_mask, kv_capacity=None, all_logits=True, hidden_states=False):
         x = np.ascontiguousarray(inputs_embeds, dtype=np.float32)
         B, L, _ = x.shape
         d = self.dims
@@ -134,6 +134,11 @@ class OracleModel:
         alll = np.empty((B, L, d.vocab), np.float32) if all_logits else None
         nbytes = self.lib.eilev_opt_workspace_bytes(C.byref(d), B, L)
         ws = np.empty(nbytes // 4 + 1, np.float32)
+        if hidden_states:  # hf output_hidden_states: every block's input, then the output of final_layer_norm
+            hs = np.empty((d.t_layers + 1, B, L, d.t_hidden), np.float32)
+            abi.check(self.lib.eilev_opt_prefill_debug(C.byref(d), C.byref(self.pack.opt), _p(x), _p(am), B, L, _p(kv), cap, _p(last),
+                                                       _p(alll), _p(hs), _p(ws), nbytes, None), "oracle prefill_debug")
+            return last, alll, kv, hs
         abi.check(self.lib.eilev_opt_prefill(C.byref(d), C.byref(self.pack.opt), _p(x), _p(am), B, L, _p(kv), cap, _p(last),
                                              _p(alll), _p(ws), nbytes, None), "oracle prefill")
         return last, alll, kv

@@ -238,3 +238,39 @@ def test_generate_stopping_rules_and_return_sequences(golden_dir):
         m.generate(**kw, max_new_tokens=4, num_return_sequences=2)
     m.hf_device_map = {"": 0}  # accelerate's hook is a no-op on the single-device HIP engine
     assert np.array_equal(m.generate(**kw, max_new_tokens=n, eos_token_id=eos).cpu().numpy(), base)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hidden_states_of_the_language_model_and_qformer_like_the_reference(golden_dir, dtype):
+    """`forward(output_hidden_states=True)` [ref:eilev/model/v2.py:187-193, 220-227]: the language model's tuple (every block's input, then
+    the output of final_layer_norm: hf OPTDecoder.forward) and the Q-Former's, against the reference's own tuples
+    (tests/golden/mid_lmdebug.npz, made by tools/make_goldens.py from the inputs of mid_b2: left padding, two rows)."""
+    import json
+    import os
+
+    from eilev_amd.synth import synth_pixels
+
+    g = np.load(os.path.join(golden_dir, "mid_lmdebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    m = build(meta["config"], dtype)
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], m.config.vision_config.image_size)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+            video_input_mask=t(g["video_input_mask"]), output_hidden_states=True, return_dict=True)
+    hs = out.language_model_outputs.hidden_states
+    ref = g["fp32_lm_hidden_states"]
+    assert len(hs) == m.config.text_config.num_hidden_layers + 1 == ref.shape[0]
+    assert all(h.dtype == dtype and tuple(h.shape) == ref.shape[1:] for h in hs)
+    valid = g["attention_mask"] == 1  # hf leaves the rows of left-pad positions undefined
+    for i, h in enumerate(hs):
+        ref_dev = rel_rms(g["bf16_lm_hidden_states"][i][valid], ref[i][valid])  # what bf16 costs the reference itself
+        assert rel_rms(host(h)[valid], ref[i][valid]) <= max(1.5 * ref_dev, 2e-3) + 2e-3, i
+    qh, qref = out.qformer_outputs.hidden_states, g["fp32_qformer_hidden_states"]
+    assert len(qh) == qref.shape[0]
+    for i, h in enumerate(qh):
+        assert rel_rms(host(h), qref[i]) <= 1e-2, i
+    # the export changes nothing else
+    plain = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype),
+              video_input_mask=t(g["video_input_mask"]), return_dict=True)
+    assert torch.equal(plain.logits, out.logits) and plain.language_model_outputs.hidden_states is None
+    assert rel_rms(host(out.logits)[valid], g["fp32_logits"][valid]) <= 1.2e-2

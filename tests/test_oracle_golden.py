@@ -239,3 +239,24 @@ def test_vision_debug_outputs_match_reference(golden_dir):
     assert np.abs(hid - g["fp32_hidden_states"]).max() < 2e-4
     assert np.abs(att - g["fp32_attentions"]).max() < 1e-5
     assert np.allclose(att.sum(-1), 1.0, atol=1e-5)
+
+
+def test_language_model_hidden_states_match_reference(golden_dir, models):
+    """`output_hidden_states=True` through the reference's full forward (ref:eilev/model/v2.py:220-227 -> hf OPTDecoder.forward: every
+    block's input, then the output of final_layer_norm): the oracle's eilev_opt_prefill_debug against tests/golden/mid_lmdebug.npz."""
+    g = np.load(os.path.join(golden_dir, "mid_lmdebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    nclips = sum(sum(c) for c, _ in meta["rows"])
+    px = synth_pixels(nclips, meta["frames"], cfg.vision_config.image_size)
+    m = models(meta["config"])
+    emb = m.encode(px, g["input_ids"], g["video_input_mask"])
+    _, logits, _, hs = m.prefill(emb, g["attention_mask"], hidden_states=True)
+    ref = g["fp32_lm_hidden_states"]
+    assert hs.shape == ref.shape == (cfg.text_config.num_hidden_layers + 1,) + emb.shape
+    valid = g["attention_mask"] == 1  # hf leaves the rows of left-pad positions undefined
+    assert np.abs(hs - ref)[:, valid].max() < 2e-4
+    assert np.abs(logits - g["fp32_logits"])[valid].max() < 5e-4
+    # the same call without the export gives the same logits
+    _, plain, _ = m.prefill(emb, g["attention_mask"])
+    assert np.array_equal(plain, logits)

@@ -407,7 +407,37 @@ def run_vit_debug_case(name="mid_vitdebug"):
     print(name, {k: v.shape for k, v in out.items() if k != "meta"}, os.path.getsize(path))
 
 
+@torch.no_grad()
+def run_lm_debug_case(name="mid_lmdebug", base="mid_b2"):
+    """`output_hidden_states=True` through the reference's full forward (ref:eilev/model/v2.py:187-193 Q-Former, :220-227 language
+    model): the per-block tuples of the language model and of the Q-Former on the inputs of `base` (left padding, two rows)."""
+    cfg_name, frames, rows, _ = CASES[base]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, _ = build_inputs(cfg_name, frames, rows)
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask),
+              output_hidden_states=True, return_dict=True)
+        out[f"{tag}_lm_hidden_states"] = np.stack([h.float().numpy() for h in o.language_model_outputs.hidden_states])
+        out[f"{tag}_qformer_hidden_states"] = np.stack([h.float().numpy() for h in o.qformer_outputs.hidden_states])
+        out[f"{tag}_logits"] = o.logits.float().numpy()
+    meta = dict(case=name, base=base, config=cfg_name, frames=frames, rows=rows, weight_mode="fanin", torch=torch.__version__,
+                transformers=transformers.__version__, generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py")
+    out["input_ids"] = input_ids
+    out["attention_mask"] = attn
+    out["video_input_mask"] = vmask
+    out["meta"] = np.asarray(json.dumps(meta))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: v.shape for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug"]):
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug"]):
         (run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
-         else run_vit_debug_case if n == "mid_vitdebug" else run_case)(n)
+         else run_vit_debug_case if n == "mid_vitdebug" else run_lm_debug_case if n == "mid_lmdebug" else run_case)(n)
