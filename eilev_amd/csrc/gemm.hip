@@ -669,7 +669,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     const bool late = wid >= NW / 2;
     const int prow = lane >> 3, pslot = lane & 7;
 
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
+    // A through one descriptor PER TILE (base = the tile's first row, wave-uniform): the 32-bit offsets then span 256 rows, so an A
+    // operand of 2 GiB or more (the ViT fc2 input of a bench launch: 279 616 x 6144 bf16 = 3.4 GB) needs no row chunking
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
     unsigned pa[PC], pb[PC];  // per-lane byte offsets of this wave's 1-KiB pieces (8 rows x 128 B, chunk-swizzled source)
     auto set_tile = [&](int t, int &m0, int &n0) {
@@ -677,12 +679,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
         m0 = tm_i * BM;
         n0 = tn_i * BN;
+        {
+            const uint64_t base = (uint64_t)(g.A + (int64_t)m0 * g.lda);
+            const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);  // provably wave-uniform: no waterfall loop
+            ra = __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, 0x7fffffff, 0x00020000);
+        }
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
             const int row = (wid * PC + i) * 8 + prow;
             int gr = m0 + row;
             gr = gr < g.M ? gr : g.M - 1;
-            pa[i] = (unsigned)gr * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
+            pa[i] = (unsigned)(gr - m0) * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
             gr = n0 + row;
             gr = gr < g.N ? gr : g.N - 1;
             pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
@@ -2155,7 +2163,11 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     // The LDS-DMA kernels address A through a 32-bit buffer offset: an A operand of 2 GiB or more (the Q-Former k|v
     // projection of a whole step: 1.1 M rows x 1408) is processed as row chunks that fit, each with the fast kernels
     const int64_t a_bytes = (int64_t)g.M * g.lda * 2;
-    if (a_bytes >= 0x7fff0000ll && g.K % BK == 0 && g.patch_group == 0 && !g.dbg) {
+    // (the persistent ping-pong kernel addresses A per tile: shapes it takes — >= 1024 tiles of 256 x 256 — are not chunked)
+    const int64_t t256_pre = ceil_div64(g.M, 256) * ceil_div64(g.N, 256);
+    const bool pp4_takes = g.K % BK == 0 && g.patch_group == 0 && t256_pre >= 1024 && (g.N >= 2048 || ceil_div64(g.M, 256) * ceil_div64(g.N, 128) >= 512) &&
+                           (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll && !g.dbg;
+    if (a_bytes >= 0x7fff0000ll && g.K % BK == 0 && g.patch_group == 0 && !g.dbg && !pp4_takes) {
         const int64_t rows_per = (0x7fff0000ll / (g.lda * 2)) / 256 * 256;
         if (rows_per >= 256) {
             for (int64_t r0 = 0; r0 < g.M; r0 += rows_per) {
@@ -2175,7 +2187,6 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     if (ln_fold) {
-        if ((int64_t)g.M * g.lda * 2 >= 0x7fff0000ll) return EILEV_E_UNSUPPORTED;
         if (prof_kind >= 0) prof_begin(prof_kind, flops, s);
         const int rc_ln = launch_pp4(g, s);
         if (prof_kind >= 0) prof_end(s);
@@ -2207,8 +2218,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     const bool w6_pick = cfg == 1 && tiles256 < 1024;
     if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
         rc = launch_w6(g, s);
-    else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.M * g.lda * 2 < 0x7fff0000ll &&
-        (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
+    else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)
         rc = launch_pp4(g, s);  // persistent ping-pong kernel
     else if (cfg == 1) rc = launch_tiled<256, 256, 2, 4, 2, 2>(g, s);
     else if (cfg == 3) rc = launch_tiled<256, 128, 4, 2, 1, 4, 1>(g, s);
