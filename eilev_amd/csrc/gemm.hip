@@ -69,14 +69,15 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, int tiles_m, int 
         tn = t % tiles_n;
         return;
     }
-    // rows per group: 8 x 4 tiles per XCD round; narrow N with a long K (fc2: 5.5 column tiles, K = 6144) shares better with 4 rows
-    // (measured on fc2: 2 / 4 / 8 / 16 rows = 1122 / 1132 / 1093 / 1045 TFLOP/s; wide N: 8 and 16 equal, 4 and 32 worse)
+    // rows per group: 8 x 4 tiles per XCD round; narrow N (fc2, proj: 5.5 column tiles) shares better with 4 rows
+    // (measured on fc2: 2 / 4 / 8 / 16 rows = 1122 / 1132 / 1093 / 1045 TFLOP/s; r3, proj on three boxes: 4 rows +1.8 ... +2.2 %; wide N:
+    // 8 and 16 equal, 4 rows -1.5 % on fc1 and +0.1 ... +1.6 % on qkv, 32 worse)
     // The half tiles of the last column (N = 1408: 5.5 columns) stay MIXED into this order.  r2, same-box: all full tiles first and the
     // half tiles last (every XCD in step on equal work) = fc2 1090 -> 983, proj 930 -> 880, qkv 1095 -> 1084 TFLOP/s — 256 half tiles
     // at once are fabric-bound (an A panel per 128 output columns); two half tiles as one unit = fc2 1123 -> 906-1003 (a 1.5-tile unit
     // per ~11 doubles the imbalance of the static stride).
     const int gsel = (g.dbg >> 22) & 3;  // probe override: 1 -> 4 rows, 2 -> 8 rows, 3 -> 16 rows
-    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 8 : gsel == 3 ? 16 : (tiles_n <= 8 && g.K >= 4096 ? 4 : 8);
+    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 8 : gsel == 3 ? 16 : (tiles_n <= 8 ? 4 : 8);
     const int width = GROUP_M * tiles_n, group = t / width, first = group * GROUP_M;
     const int gsz = min(tiles_m - first, GROUP_M), in = t - group * width;
     tm = first + in % gsz;
