@@ -4,7 +4,7 @@
 #include <cstdio>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-enum { NONE = 0, MFMA = 1, VALU = 2, TRANS = 3, MIX = 4 };
+enum { NONE = 0, MFMA = 1, VALU = 2, TRANS = 3, MIX = 4, PKFMA = 5, PKMUL = 6 };
 template <int KIND>
 __device__ __forceinline__ float stream(int iters, float seed) {
     f32x4 acc[4] = {{seed, 0, 0, 0}, {0, seed, 0, 0}, {0, 0, seed, 0}, {0, 0, 0, seed}};
@@ -22,6 +22,19 @@ __device__ __forceinline__ float stream(int iters, float seed) {
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[k]) : "v"(seed));
+        }
+        if constexpr (KIND == PKFMA || KIND == PKMUL) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 sv = {seed, seed};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    f2 x = {v[k], v[k + 1]};
+                    if constexpr (KIND == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(sv));
+                    else asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(sv));
+                    v[k] = x.x; v[k + 1] = x.y;
+                }
         }
         if constexpr (KIND == TRANS) {
 #pragma unroll
@@ -72,6 +85,9 @@ int main() {
     run<MFMA, VALU>("A: mfma        B: valu", d, it);
     run<MFMA, TRANS>("A: mfma        B: trans", d, it);
     run<VALU, TRANS>("A: valu        B: trans", d, it);
+    run<PKFMA, PKFMA>("A: pk_fma_f32  B: pk_fma_f32 (16 per iteration = 32 elements)", d, it);
+    run<PKMUL, PKMUL>("A: pk_mul_f32  B: pk_mul_f32", d, it);
+    run<PKFMA, NONE>("A: pk_fma_f32  B: -", d, it);
     run<MIX, NONE>("A: mfma+valu (one wave) B: -", d, it);
     run<MIX, MIX>("A: mfma+valu   B: mfma+valu", d, it);
     return 0;
