@@ -24,6 +24,7 @@ from eilev_amd import abi
 lib = abi.load_hip()
 raw = C.CDLL(abi.HIP_LIB_PATH)
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+NOBIAS = bool(os.environ.get("PROBE_NOBIAS"))
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True), "qkv": (34952, 4224, 1408, 0, False),
        "proj": (34952, 1408, 1408, 0, True), "opt_fc1": (7680, 10240, 2560, 2, False), "opt_qkv": (7680, 7680, 2560, 0, False),
