@@ -289,11 +289,14 @@ def strong_scaling_phase(eng, cfg, world, rank, dev, exch_weak, is_t5, global_sa
         am = torch.ones_like(ids, dtype=torch.int32)
     exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport=exch_weak.transport if world > 1 else "local", comm=exch_weak.comm)
 
+    seen = []  # the same (ids, vm) batch every step: its contract checks (two host syncs) run on the first submission only
+
     def step():
         feats = eng.encode_and_exchange(px, exch)
         if not mine:
             return None
-        emb = eng.embed_scatter(ids, vm, feats)
+        emb = eng.embed_scatter(ids, vm, feats, validated=bool(seen))
+        seen.append(1)
         if is_t5:
             return eng.t5_greedy(emb, am, NEW_TOKENS, eos_id=-1, pad_id=0)[:, 1:]
         return eng.greedy_decode(emb, am, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)
@@ -434,10 +437,13 @@ def main():
             ev.record()
             eng.timing.append((name, ev))
 
+    seen = []  # the same (ids, vm) batch every step: its contract checks (two host syncs) run on the first (warm-up) submission only
+
     def step():
         stamp("step_begin")
         mine_f = last["feats"] = eng.encode_and_exchange(px, exch)  # chunks of 136 clips; each chunk's RCCL exchange runs under the next ViT
-        emb = eng.embed_scatter(ids, vm, mine_f)
+        emb = eng.embed_scatter(ids, vm, mine_f, validated=bool(seen))
+        seen.append(1)
         stamp("encode_done")
         if is_t5:  # encoder-decoder LM: encoder + cross K/V take the place of the prefill
             out_ids = eng.t5_greedy(emb, am, NEW_TOKENS, eos_id=-1, pad_id=0)[:, 1:]

@@ -28,13 +28,40 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
+def _generate_a4_loop() -> None:
+    """gemm_a4_loop.inc = the hand-scheduled K loop of gemm_a4_kernel as inline-asm text, written by gen_a4_loop.py.  The committed copy
+    is used as is unless its CONTENT differs from what the generator prints now (mtimes mean nothing after a checkout); the new text
+    goes to a temporary file first, so a failing generator or a read-only tree leaves the committed file alone."""
     gen, inc = os.path.join(HERE, "gen_a4_loop.py"), os.path.join(HERE, "gemm_a4_loop.inc")
-    if _stale(inc, [gen]):  # the hand-scheduled K loop of gemm_a4_kernel as inline-asm text
-        with open(inc, "w") as f:
-            subprocess.check_call([sys.executable, gen], stdout=f)
+    try:
+        text = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
+    except (OSError, subprocess.CalledProcessError) as e:
+        if os.path.exists(inc):
+            print(f"warning: gen_a4_loop.py failed ({e}); keeping the committed gemm_a4_loop.inc", file=sys.stderr)
+            return
+        raise
+    try:
+        with open(inc) as f:
+            if f.read() == text:
+                return
+    except OSError:
+        pass
+    tmp = inc + f".tmp{os.getpid()}"
+    try:
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, inc)
+    except OSError as e:  # read-only install: the committed file stays
+        print(f"warning: cannot refresh gemm_a4_loop.inc ({e})", file=sys.stderr)
+
+
+def build_hip(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """``variant`` / ``extra_flags``: an A/B build of the same sources with extra -D flags into build/<variant>/ and
+    libeilev_hip_<variant>.so (tools/gemm_ab.py compares two libraries in one process on one box)."""
+    _generate_a4_loop()
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", variant) if variant else os.path.join(HERE, "build")
+    lib = os.path.join(HERE, f"libeilev_hip_{variant}.so") if variant else LIB
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
@@ -47,7 +74,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(objdir, obj)
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, *extra, "-c", s, "-o", o])
+            jobs.append([_hipcc(), *FLAGS, *extra, *extra_flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -61,10 +88,17 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn, file=sys.stderr)
-    if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv, verbose=True))
+    # python build.py [--force] [--variant NAME -DX=1 ...]
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    name = ""
+    if "--variant" in args:
+        i = args.index("--variant")
+        name = args[i + 1]
+        del args[i:i + 2]
+    print(build_hip(force="--force" in sys.argv, verbose=True, variant=name, extra_flags=tuple(args)))

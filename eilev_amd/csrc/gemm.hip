@@ -753,6 +753,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    // EILEV_PP4_DEEP == 2: the late group's LDS-DMA of step st + 2 is issued INSIDE its second MFMA phase of step st (one piece per two
+    // MFMAs), i.e. after the barrier that follows every wave's last read of that buffer — see kstep below.
+    auto mma_half_staging = [&](int st, bool w_too) {
+        char *sa = smem + (st & 1) * STEP + (wid * PC) * 1024;
+        char *sb = sa + BM * 128;
+        __builtin_amdgcn_s_setprio(1);
+        static_for<2 * TM * TN>([&](auto x_c) {
+            constexpr int X = decltype(x_c)::value, k2 = X / (TM * TN), i = (X / TN) % TM, j = X % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+            if constexpr (X % 2 == 1 && X / 2 < 2 * PC) {
+                constexpr int pc = X / 4;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((X / 2) % 2 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + pc * 1024), 16, pa[pc], st * 128, 0, 0);
+                else if (w_too) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + pc * 1024), 16, pb[pc], st * 128, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        __builtin_amdgcn_s_setprio(0);
+    };
     // Half-empty last column tile (N % 256 <= 128, e.g. N = 1408 = 5.5 x 256): only columns [0, 128) of the tile exist.
     // The 8 waves re-split the valid 256 x 128 region as 4 x 2 blocks of 64 x 64 (half the fragment reads and MFMAs per
     // wave, same ping-pong schedule); waves 4..7 own W rows 128..255 of the tile and skip their W pieces.
@@ -1043,7 +1062,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();
             if constexpr (HT) read_half_ht(st, 1); else read_half(st, 1);
-#if EILEV_PP4_DEEP
+#if EILEV_PP4_DEEP == 2
+            // with the issue at the end of the late group's read phase (DEEP == 1) only the DMA's latency keeps a piece from
+            // landing in a buffer another late wave is still reading; here every wave has passed the barrier behind its last read
+            if (late) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            if constexpr (HT) {
+                if (late && st + 2 < ns) stage_step(st + 2, w_mine);
+                mma_half_ht();
+            } else if constexpr (F8) {
+                if (late && st + 2 < ns) stage_step(st + 2, w_mine);
+                mma_half();
+            } else {
+                if (late && st + 2 < ns) mma_half_staging(st + 2, w_mine);
+                else mma_half();
+            }
+#elif EILEV_PP4_DEEP
             if (late) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
                 if (st + 2 < ns) stage_step(st + 2, w_mine);

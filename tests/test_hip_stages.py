@@ -91,6 +91,34 @@ def test_scatter_count_mismatch_raises(golden_dir):
         eng.embed_scatter(torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["video_input_mask"]).cuda(), feats)
 
 
+def test_scatter_checks_run_on_every_batch(golden_dir):
+    """A loop's SECOND batch lands in the storage the allocator just freed (same address, same shape, version 0): its mask / id
+    checks must still run — boolean index_put and nn.Embedding raise in the reference on every call (ref:eilev/model/v2.py:308-316)."""
+    g, meta, px = load_case(golden_dir, "mid_b1")
+    cfg, oracle, eng = models("mid")
+    nrows = int(g["video_input_mask"].sum())
+    feats = torch.zeros(nrows, eng.dims.t_hidden, device="cuda", dtype=torch.bfloat16)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    vm = torch.from_numpy(g["video_input_mask"]).cuda()
+    ptrs = (ids.data_ptr(), vm.data_ptr())
+    eng.embed_scatter(ids, vm, feats)
+    bad_vm = g["video_input_mask"].copy()
+    bad_vm.reshape(-1)[np.flatnonzero(bad_vm.reshape(-1))[0]] = 0
+    bad_ids = g["input_ids"].copy()
+    bad_ids.reshape(-1)[0] = eng.dims.vocab
+    del ids, vm
+    ids2 = torch.from_numpy(g["input_ids"]).cuda()
+    vm2 = torch.from_numpy(bad_vm).cuda()
+    # (normally (ids2.data_ptr(), vm2.data_ptr()) == ptrs here: the situation the check must survive)
+    with pytest.raises(RuntimeError):
+        eng.embed_scatter(ids2, vm2, feats)
+    del ids2, vm2
+    with pytest.raises(IndexError):
+        eng.embed_scatter(torch.from_numpy(bad_ids).cuda(), torch.from_numpy(g["video_input_mask"]).cuda(), feats)
+    # the explicit opt-out is the caller's statement, and only that
+    eng.embed_scatter(torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["video_input_mask"]).cuda(), feats, validated=True)
+
+
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_greedy_ids_exact(golden_dir, name, use_graph):
