@@ -658,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
     constexpr int STEP = (BM + BN) * 128;
-    constexpr int PC = 4;
+    constexpr int PC = 8;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) per wave and K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
@@ -670,11 +670,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     const bool late = wid >= NW / 2;
     const int prow = lane >> 3, pslot = lane & 7;
 
+    // Who stages what (round 4; ADVICE r3: the round-3 schedule let a late wave's DMA land in rows another late wave might still be
+    // reading, with only the DMA's latency in between).  The early group (waves 0-3) stages ALL of A: wave w the tile rows 64 w .. 64 w + 63.
+    // The late group (waves 4-7) stages ALL of W: wave 4 + j the tile rows 64 j .. 64 j + 63 — exactly the W rows that wave reads itself
+    // (wn = j) and that, besides it, only the early wave j reads, one barrier interval EARLIER.  So when a late wave issues step st + 2
+    // at the end of its own reads of (st, half 1), nobody else can still be reading the rows it overwrites: no timing argument left.
+    // (Half tiles re-split the reads 4 x 2, so there the late group issues after the barrier instead: kstep below.)
     // A through one descriptor PER TILE (base = the tile's first row, wave-uniform): the 32-bit offsets then span 256 rows, so an A
     // operand of 2 GiB or more (the ViT fc2 input of a bench launch: 279 616 x 6144 bf16 = 3.4 GB) needs no row chunking
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
-    unsigned pa[PC], pb[PC];  // per-lane byte offsets of this wave's 1-KiB pieces (8 rows x 128 B, chunk-swizzled source)
+    unsigned po[PC];  // per-lane byte offsets of this wave's pieces (chunk-swizzled source): into A for waves 0-3, into W for waves 4-7
+    const int pw = late ? wid - NW / 2 : wid;  // which 64-row slab of its operand the wave stages
     auto set_tile = [&](int t, int &m0, int &n0) {
         int tm_i, tn_i;
         tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
@@ -688,22 +695,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
-            const int row = (wid * PC + i) * 8 + prow;
-            int gr = m0 + row;
-            gr = gr < g.M ? gr : g.M - 1;
-            pa[i] = (unsigned)(gr - m0) * (unsigned)(g.lda * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
-            gr = n0 + row;
-            gr = gr < g.N ? gr : g.N - 1;
-            pb[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + ((pslot ^ ((row >> 1) & 7)) << 4);
+            const int row = (pw * PC + i) * 8 + prow;
+            const unsigned sw = (unsigned)((pslot ^ ((row >> 1) & 7)) << 4);
+            if (!late) {
+                int gr = m0 + row;
+                gr = gr < g.M ? gr : g.M - 1;
+                po[i] = (unsigned)(gr - m0) * (unsigned)(g.lda * 2) + sw;
+            } else {
+                int gr = n0 + row;
+                gr = gr < g.N ? gr : g.N - 1;
+                po[i] = (unsigned)gr * (unsigned)(g.ldw * 2) + sw;
+            }
         }
     };
-    auto stage_step = [&](int st, bool w_too = true) {
-        char *sa = smem + (st & 1) * STEP + (wid * PC) * 1024;
-        char *sb = sa + BM * 128;
+    auto stage_step = [&](int st, bool mine = true) {  // mine == false: a late wave whose W rows do not exist in a half tile
+        char *sd = smem + (st & 1) * STEP + (late ? BM * 128 : 0) + (pw * PC) * 1024;
+        if (!mine) return;
+        if (late) {
 #pragma unroll
-        for (int i = 0; i < PC; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + i * 1024), 16, pa[i], st * 128, 0, 0);
-            if (w_too) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + i * 1024), 16, pb[i], st * 128, 0, 0);
+            for (int i = 0; i < PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
         }
     };
     f32x16 acc[TM][TN];
@@ -751,25 +764,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // EILEV_PP4_DEEP == 2: the late group's LDS-DMA of step st + 2 is issued INSIDE its second MFMA phase of step st (one piece per two
-    // MFMAs), i.e. after the barrier that follows every wave's last read of that buffer — see kstep below.
-    auto mma_half_staging = [&](int st, bool w_too) {
-        char *sa = smem + (st & 1) * STEP + (wid * PC) * 1024;
-        char *sb = sa + BM * 128;
-        __builtin_amdgcn_s_setprio(1);
-        static_for<2 * TM * TN>([&](auto x_c) {
-            constexpr int X = decltype(x_c)::value, k2 = X / (TM * TN), i = (X / TN) % TM, j = X % TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
-            if constexpr (X % 2 == 1 && X / 2 < 2 * PC) {
-                constexpr int pc = X / 4;
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr ((X / 2) % 2 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sa + pc * 1024), 16, pa[pc], st * 128, 0, 0);
-                else if (w_too) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sb + pc * 1024), 16, pb[pc], st * 128, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
         __builtin_amdgcn_s_setprio(0);
     };
     // Half-empty last column tile (N % 256 <= 128, e.g. N = 1408 = 5.5 x 256): only columns [0, 128) of the tile exist.
@@ -954,7 +948,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     int t = blockIdx.x, m0, n0;
     if (t >= ntiles) return;
     set_tile(t, m0, n0);
-    auto w_piece_mine = [&](int n0_) { return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2; };
+    // half tile: only W rows 0..127 of the tile exist; the late waves 6 and 7 (rows 128..255) have nothing to stage
+    auto w_piece_mine = [&](int n0_) { return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2 + 2; };
     stage_step(0, w_piece_mine(n0));
     bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
@@ -1046,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         auto kstep = [&](int st, auto first_c, auto ht_c) {
             constexpr bool FIRST = decltype(first_c)::value;
             constexpr bool HT = decltype(ht_c)::value;
-            const bool w_mine = !HT || wid < NW / 2;
+            const bool w_mine = !HT || wid < NW / 2 + 2;
             if constexpr (HT) read_half_ht(st, 0); else read_half(st, 0);
 #if EILEV_PP4_DEEP
             if (!late) {
@@ -1062,29 +1057,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();
             if constexpr (HT) read_half_ht(st, 1); else read_half(st, 1);
-#if EILEV_PP4_DEEP == 2
-            // with the issue at the end of the late group's read phase (DEEP == 1) only the DMA's latency keeps a piece from
-            // landing in a buffer another late wave is still reading; here every wave has passed the barrier behind its last read
-            if (late) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if EILEV_PP4_DEEP
+            if (late) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                // full tile: the W rows this wave stages are read by itself (done: lgkmcnt(0) above) and by its early twin (done one
+                // barrier ago) only.  Half tile: the reads are re-split 4 x 2, two late waves share W rows -> issue after the barrier.
+                if constexpr (!HT) if (st + 2 < ns) stage_step(st + 2, w_mine);
+            } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BARRIER();
             if constexpr (HT) {
                 if (late && st + 2 < ns) stage_step(st + 2, w_mine);
                 mma_half_ht();
-            } else if constexpr (F8) {
-                if (late && st + 2 < ns) stage_step(st + 2, w_mine);
-                mma_half();
-            } else {
-                if (late && st + 2 < ns) mma_half_staging(st + 2, w_mine);
-                else mma_half();
-            }
-#elif EILEV_PP4_DEEP
-            if (late) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-                if (st + 2 < ns) stage_step(st + 2, w_mine);
-            } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BARRIER();
-            if constexpr (HT) mma_half_ht(); else mma_half();
+            } else mma_half();
             __builtin_amdgcn_sched_barrier(0);
             if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PP_BARRIER();

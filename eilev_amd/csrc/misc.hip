@@ -290,12 +290,17 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     auto key_row = [&](const bf16 *base, const bf16 *gen, int j) -> const bf16 * {
         if (!anc || j < seq_len) return base + (int64_t)j * hd;
         const int gi = j - seq_len;
-        return gen + (((int64_t)anc[(int64_t)gi * rows + b] * heads + h) * cap_g + gi) * hd;
+        int a = anc[(int64_t)gi * rows + b];  // a table entry outside [0, rows) must not become an address (the host fills it: ADVICE r3)
+        a = a < 0 ? 0 : (a >= rows ? rows - 1 : a);
+        return gen + (((int64_t)a * heads + h) * cap_g + gi) * hd;
     };
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
     // fuse_new: the newest key / value (slot kv_total - 1) is still only in the q|k|v row of this step.  The split that owns the
     // slot reads it from there and stores it into the cache (what a separate kv_write launch did before the attention).
-    const int slot_new = fuse_new ? kv_total - 1 : -1;
+    // beam form: state[0] counts the generated tokens INCLUDING this step's, so it is >= 1 here; a caller that passes 0 (or more than the
+    // generation cache holds: kv_total is clamped above) must not make this row write outside its own generation slots
+    const int slot_raw = fuse_new ? kv_total - 1 : -1;
+    const int slot_new = (anc && (slot_raw < seq_len || state[0] > cap_g)) ? -1 : slot_raw;
     const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
     if (slot_new >= k0 && slot_new < k1 && tid < 2 * nch) {
         const int which = tid / nch, cc = tid - which * nch;

@@ -520,8 +520,9 @@ class HipEngine:
 
 
     def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
-                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, use_graph=True):
+                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, use_graph=True, trace=None):
         """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
+        ``trace``: a list that receives (tokens fed, parent rows, fp32 logits) of every step (tests replay the hypotheses teacher-forced).
 
         The prompt is prefilled ONCE per sample; no cache row is ever copied (see below); one HIP decode step on all rows per
         generated token, captured into a hipGraph and replayed."""
@@ -536,6 +537,8 @@ class HipEngine:
             # at most 32 decode rows per call: beam search of a large batch runs sample group by sample group (groups are
             # independent in beam search); shorter results are padded with pad_id like HF pads finished hypotheses
             per = max(1, 32 // num_beams)
+            if trace is not None:
+                raise ValueError("trace: at most 32 decode rows")
             parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
                                       pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens, use_graph) for i in range(0, B, per)]
             n = max(p.shape[1] for p in parts)
@@ -591,6 +594,8 @@ class HipEngine:
                 graph[0].replay()
             else:
                 launch()
+            if trace is not None:
+                trace.append((next_tokens.clone(), beam_src.clone(), logits.clone()))
             return logits
 
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step

@@ -75,6 +75,10 @@ def synth_param(name: str, shape, mode: str = "fanin", seed: int = 0) -> np.ndar
     HF ``initializer_range`` (what the benchmark uses).  LayerNorm weights are
     1 + 0.1 n, LayerNorm biases 0.05 n, linear biases 0.02 n; every value is
     representable in bf16 so fp32 and bf16 models hold identical weights.
+    ``mode='varied'``: 'fanin' with a SMALL token embedding (std 0.06) and the usual 0.5 for position embeddings.  With the tied
+    lm_head of OPT, 'fanin' makes a random model repeat one token for ever (the residual stream is dominated by the last token's own
+    embedding, whose logit is its squared norm); with the token embedding small the stream is dominated by position and block outputs,
+    greedy / beam outputs change from step to step, and a decode step that used a wrong position or a stale KV slot shows up in the ids.
     """
     shape = tuple(int(s) for s in shape)
     n = det_normal(name, shape, seed)
@@ -85,15 +89,15 @@ def synth_param(name: str, shape, mode: str = "fanin", seed: int = 0) -> np.ndar
         out = 0.02 * n
     elif len(shape) >= 2 and name.endswith("weight") and "embed" not in low:
         fan_in = int(np.prod(shape[1:]))
-        std = (1.0 / np.sqrt(fan_in)) if mode == "fanin" else 0.02
-        if mode == "fanin" and low.endswith("attention.q.weight"):
+        std = (1.0 / np.sqrt(fan_in)) if mode in ("fanin", "varied") else 0.02
+        if mode in ("fanin", "varied") and low.endswith("attention.q.weight"):
             # T5 attention has no 1/sqrt(d_kv) factor (trained checkpoints carry it in q): without it the synthetic softmax
             # saturates and the model amplifies bf16 noise chaotically
             std *= 0.125
         out = std * n
     else:
         # embeddings, query_tokens, class/position embeddings
-        std = 0.5 if mode == "fanin" else 0.02
+        std = 0.02 if mode == "hf" else (0.06 if mode == "varied" and "embed_tokens" in low else 0.5)
         out = std * n
     return round_bf16(out.astype(np.float32))
 

@@ -19,7 +19,10 @@
  * Conventions: the caller owns every buffer (weights, activations, workspace, KV cache); the
  * library never allocates device memory and never synchronises the stream.  Returns 0 on
  * success, a negative EILEV_E_* for bad arguments / unsupported dimensions, a positive value
- * = passthrough hipError_t.  No global mutable state besides the optional kernel profiler.
+ * = passthrough hipError_t.  Global mutable state: none on the product path.  The library also exports a handful of
+ * process-global PROBE switches (`eilev_debug_*`, listed at the end of this header): they all default to "off", nothing in
+ * eilev_amd/ sets them outside tests / tools/, and a caller that never touches them gets a stateless library.  They are not
+ * thread-safe (plain ints read at launch time) and not part of the drop-in contract.
  * Linear weights are in the checkpoint's layout: [out_features, in_features] row-major.
  */
 #ifndef EILEV_H
@@ -251,6 +254,15 @@ int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, cons
                         int64_t n, int64_t k, int epilogue, void *stream);
 /* probe / test knob: minimum token rows of a launch for the folded ViT path (default 65 536; 0 = always when layers_fold is set) */
 void eilev_debug_ln_fold_min_rows(int64_t rows);
+/* The other process-global probe switches (all default 0 = the product path; tools/ and tests/ only; see the header comment):
+ *   eilev_debug_gemm_flags(int)        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
+ *   eilev_debug_gemm_trace(ptr, tiles) per-tile time stamps of the persistent GEMM (tools/gemm_trace.py)
+ *   eilev_debug_patch_trace(ptr)       phase stamps of the fused patch kernel (tools/patch_trace.py)
+ *   eilev_debug_attn_v1(int)           route attention to the round-1 kernels (A/B in tests/test_hip_kernels.py)
+ *   eilev_debug_attn_ts(ptr)           phase stamps of the frame attention kernel (tools/attn_ts.py)
+ *   eilev_debug_fused_patch(int) / eilev_debug_no_fused_patch(int)   select the fused patch-embed + LayerNorm kernel (opt-in since r3)
+ *   eilev_debug_decode_rows(int)       force the row-dot (1) / MFMA (2) decode block regardless of the batch
+ *   eilev_debug_decode_prefetch(int)   the rejected Infinity-Cache touch kernel of DESIGN 3b (off) */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.

@@ -14,14 +14,14 @@ from oracle.runner import OracleModel, synth_state_dict
 _cache = {}
 
 
-def models(cfg_name, mode="fanin", emu=False):
+def models(cfg_name, mode="fanin", emu=False, seed=0):
     """(config, oracle model, HIP engine) sharing one deterministic bf16-exact state dict."""
     from eilev_amd.engine import HipEngine
 
-    key = (cfg_name, mode)
+    key = (cfg_name, mode, seed)
     if key not in _cache:
         cfg = blip2_config(cfg_name)
-        sd = synth_state_dict(cfg, mode)
+        sd = synth_state_dict(cfg, mode, seed)
         eng = HipEngine(cfg, {k: torch.from_numpy(v).cuda() for k, v in sd.items()}, device="cuda")
         _cache[key] = (cfg, sd, eng, {})
     cfg, sd, eng, oracles = _cache[key]
@@ -62,10 +62,10 @@ def P(t):
 
 
 def record_parity(section: str, **numbers):
-    """Append measured parity distances to gpurun_out/parity_r03.json (merged back from the GPU box; the copy under
+    """Append measured parity distances to gpurun_out/parity_r04.json (merged back from the GPU box; the copy under
     profiles/ is the tracked one).  Numbers only: what HIP-vs-reference distances actually are, next to the tolerance."""
     root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "parity_r03.json")
+    path = os.path.join(root, "gpurun_out", "parity_r04.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     try:
         with open(path) as fh:

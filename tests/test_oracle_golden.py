@@ -31,11 +31,11 @@ def load_case(golden_dir, name):
 def models():
     cache = {}
 
-    def get(cfg_name, emu=False):
-        key = (cfg_name, emu)
+    def get(cfg_name, emu=False, mode="fanin", seed=0):
+        key = (cfg_name, emu, mode, seed)
         if key not in cache:
             cfg = blip2_config(cfg_name)
-            cache[key] = OracleModel(cfg, synth_state_dict(cfg), emulate_bf16=emu)
+            cache[key] = OracleModel(cfg, synth_state_dict(cfg, mode, seed), emulate_bf16=emu)
         return cache[key]
 
     return get
@@ -260,3 +260,69 @@ def test_language_model_hidden_states_match_reference(golden_dir, models):
     # the same call without the export gives the same logits
     _, plain, _ = m.prefill(emb, g["attention_mask"])
     assert np.array_equal(plain, logits)
+
+
+# ---- fixtures whose reference outputs CHANGE from step to step (weight mode 'varied', tools/make_goldens.py::run_varied_case) ----------
+# Every 'fanin' OPT fixture above makes the reference repeat one id (tied lm_head: the last token's own embedding dominates), which a
+# decode step with a wrong position or a stale KV slot would reproduce; these do not.
+VARIED = ["mid_v1", "mid_v2"]
+
+
+def varied_model(models, meta, emu=False):
+    return models(meta["config"], emu, meta["weight_mode"], meta["weight_seed"])
+
+
+@pytest.mark.parametrize("name", VARIED)
+def test_varied_fixture_is_not_degenerate(golden_dir, name):
+    g, meta, cfg, px = load_case(golden_dir, name)
+    ids = g["fp32_greedy_free"]
+    assert ids.shape[1] >= 12 and all(len(set(r.tolist())) >= 4 for r in ids)
+    assert np.array_equal(ids, g["bf16_greedy_free"])  # the reference's own two precisions agree: "ids exact" is well posed
+    eos = g["fp32_greedy_eos"]
+    stop = np.argmax(eos == int(g["fp32_eos_id"]), axis=1)  # a row stops in the MIDDLE (and is padded if another row runs on)
+    assert (eos == int(g["fp32_eos_id"])).any() and 0 < stop.max() < ids.shape[1] - 3
+    assert eos.shape[1] < ids.shape[1] or (eos == 1).any()
+
+
+@pytest.mark.parametrize("name", VARIED)
+def test_varied_logits_loss_and_greedy_match_reference(golden_dir, models, name):
+    g, meta, cfg, px = load_case(golden_dir, name)
+    m = varied_model(models, meta)
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"])
+    logits = m.forward_logits(*args)
+    valid = g["attention_mask"] == 1
+    assert np.abs(logits - g["fp32_logits"])[valid].max() < 5e-4
+    lg = np.where(valid[..., None], logits, g["fp32_logits"])
+    assert abs(shifted_ce_loss(lg, g["labels"]) - float(g["fp32_loss"])) < 1e-4
+    n = meta["new_tokens"]
+    ids, steps = m.generate(*args, n, eos_id=-1, return_logits=True)
+    assert np.array_equal(ids, g["fp32_greedy_free"]), (ids, g["fp32_greedy_free"])
+    # every decode step's logits, not only its argmax: position ids, KV slots and the left-padding mask all enter here
+    ref_steps = g["fp32_step_logits"]
+    assert len(steps) == n  # the prefill row, then one per decode step that a selection follows
+    for k in range(n):
+        assert np.abs(steps[k] - ref_steps[k]).max() < 5e-4, k
+    eos = m.generate(*args, n, eos_id=int(g["fp32_eos_id"]))
+    assert np.array_equal(eos, g["fp32_greedy_eos"]), (eos, g["fp32_greedy_eos"])
+
+
+@pytest.mark.parametrize("name", VARIED)
+@pytest.mark.parametrize("tag,nb,lp", BEAMS)
+@pytest.mark.parametrize("no_move", [False, True])
+def test_varied_beam_search_matches_reference(golden_dir, models, name, tag, nb, lp, no_move):
+    g, meta, cfg, px = load_case(golden_dir, name)
+    m = varied_model(models, meta)
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta.get("beam_new_tokens", meta["new_tokens"]), nb, lp)
+    ids = m.generate_beam(*args, eos_id=int(g["fp32_eos_id"]), no_move=no_move)
+    assert np.array_equal(ids, g[f"fp32_{tag}"]), (ids, g[f"fp32_{tag}"])
+    free = m.generate_beam(*args, eos_id=-1, no_move=no_move)
+    assert np.array_equal(free, g[f"fp32_{tag}_free"]), (free, g[f"fp32_{tag}_free"])
+    assert len(set(free.reshape(-1).tolist())) >= 4
+
+
+@pytest.mark.parametrize("name", VARIED)
+def test_varied_bf16_emulation_picks_the_reference_ids(golden_dir, models, name):
+    g, meta, cfg, px = load_case(golden_dir, name)
+    m = varied_model(models, meta, emu=True)
+    ids = m.generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
+    assert np.array_equal(ids, g["bf16_greedy_free"])

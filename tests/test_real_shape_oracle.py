@@ -58,3 +58,27 @@ def test_real_width_t5_matches_reference(golden_dir):
     assert np.array_equal(logits.argmax(-1), g["fp32_logits_argmax"])
     ids = m.t5_generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
     assert np.array_equal(ids, g["fp32_greedy_free"])
+
+
+def test_real_width_varied_ids_match_reference(golden_dir):
+    """tests/golden/real_v1.npz: the same real-width single-block model with weight mode 'varied' (small token embedding), whose
+    reference greedy / beam outputs change from step to step and include a row stopped by EOS in the middle (12 tokens)."""
+    g = np.load(os.path.join(golden_dir, "real_v1.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)
+    m = OracleModel(cfg, synth_state_dict(cfg, meta["weight_mode"], meta["weight_seed"]))
+    args = (px, g["input_ids"], g["attention_mask"], g["video_input_mask"])
+    n = meta["new_tokens"]
+    ids, steps = m.generate(*args, n, eos_id=-1, return_logits=True)
+    assert len(set(g["fp32_greedy_free"][0].tolist())) >= 4 and np.array_equal(g["fp32_greedy_free"], g["bf16_greedy_free"])
+    assert np.array_equal(ids, g["fp32_greedy_free"]), (ids, g["fp32_greedy_free"])
+    assert np.abs(steps[0] - g["fp32_logits_last"]).max() < 5e-4
+    for k in range(n):  # the eight leading logits of every step: ids and values
+        top = np.argsort(-steps[k], axis=-1)[:, :8]
+        assert np.array_equal(top[:, :2], g["fp32_step_logits_top8_ids"][k][:, :2]), k
+        assert np.abs(np.take_along_axis(steps[k], g["fp32_step_logits_top8_ids"][k], -1) - g["fp32_step_logits_top8"][k]).max() < 5e-4, k
+    eos = m.generate(*args, n, eos_id=int(g["fp32_eos_id"]))
+    assert np.array_equal(eos, g["fp32_greedy_eos"]) and eos.shape[1] < n
+    beam = m.generate_beam(*args, n, 3, 1.0, eos_id=-1, no_move=True)
+    assert np.array_equal(beam, g["fp32_beam3_lp1_free"]), (beam, g["fp32_beam3_lp1_free"])

@@ -79,7 +79,7 @@ T5_CASES = {
 }
 
 
-def load_det_weights(model, mode="fanin"):
+def load_det_weights(model, mode="fanin", seed=0):
     sd = model.state_dict()
     new = {}
     tied = {"language_model.lm_head.weight": None, "language_model.encoder.embed_tokens.weight": "language_model.shared.weight",
@@ -87,7 +87,7 @@ def load_det_weights(model, mode="fanin"):
     for k, v in sd.items():
         if k in tied:
             continue
-        new[k] = torch.from_numpy(synth_param(k, tuple(v.shape), mode)).to(v.dtype)
+        new[k] = torch.from_numpy(synth_param(k, tuple(v.shape), mode, seed)).to(v.dtype)
     if "language_model.shared.weight" in new:  # T5: encoder/decoder embeddings and (installed transformers) lm_head = shared
         for k in tied:
             if k in sd:
@@ -273,6 +273,146 @@ def run_case(name):
           os.path.getsize(path))
 
 
+VARIED_CASES = {
+    # name: (config, frames T, rows, new_tokens) — weight mode 'varied' (eilev_amd.synth.synth_param): the reference's greedy and beam
+    # outputs change from step to step (every 'fanin' OPT fixture repeats ONE id, which a decode step with a wrong
+    # position or a stale KV slot would reproduce).  The weight SEED is searched (run_varied_case) and stored in the fixture's meta.
+    "mid_v1": ("mid", 2, [([1, 1, 1], [5, 5, 4])], 14),
+    "mid_v2": ("mid", 2, [([1, 1], [6, 7]), ([1, 1], [3, 3])], 14),
+    "real_v1": ("real_1l", 8, [([1, 1], [10, 8])], 12),
+}
+FULL_CASES = {
+    # the C1 workload at FULL DEPTH (39 ViT / 12 Q-Former / 32 OPT blocks, real widths): 1 clip x 8 frames, 0 in-context examples
+    "full_c1": ("opt27", 8, [([1], [14])], 32),
+}
+
+
+def _greedy_with_scores(m, kw, new_tokens, eos):
+    o = m.generate(**kw, max_new_tokens=new_tokens, num_beams=1, do_sample=False, eos_token_id=eos, output_scores=True,
+                   return_dict_in_generate=True)
+    return o.sequences, torch.stack([sc.float() for sc in o.scores])  # (B, n), (n, B, vocab): the processed scores = raw logits here
+
+
+BEAM_CONFIGS = ((5, -1.0, "beam5_lpm1"), (3, 1.0, "beam3_lp1"))
+
+
+def _beams_are_stable(m, kw, new_tokens, eos_ids, sigma=0.012, trials=6):
+    """Beam search prunes: two hypotheses tied to within rounding noise can flip and change everything after.  A fixture whose
+    beam outputs are to be matched EXACTLY by another bf16 implementation must not sit on such a tie: the reference's fp32 beam
+    results have to survive Gaussian noise of the size of a bf16 path's logit deviation (sigma = 0.012 on logits of std 0.8:
+    what the HIP path measures against these fixtures) on every step's scores, for both beam configurations, with and without EOS."""
+    from transformers import LogitsProcessorList
+
+    class Noise:
+        def __init__(self, seed):
+            self.g = torch.Generator().manual_seed(seed)
+
+        def __call__(self, input_ids, scores):
+            return scores + sigma * torch.randn(scores.shape, generator=self.g, dtype=scores.dtype)
+
+    for nbm, lp, _ in BEAM_CONFIGS:
+        for e_id in eos_ids:
+            base = m.generate(**kw, max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=e_id)
+            for trial in range(trials):
+                g = m.generate(**kw, max_new_tokens=new_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=e_id,
+                               logits_processor=LogitsProcessorList([Noise(100 + trial)]))
+                if g.shape != base.shape or not torch.equal(g, base):
+                    return False
+    return True
+
+
+@torch.no_grad()
+def run_varied_case(name, max_seeds=2000):
+    full = name in FULL_CASES
+    cfg_name, frames, rows, new_tokens = (FULL_CASES if full else VARIED_CASES)[name]
+    cfg = blip2_config(cfg_name)
+    vocab = cfg.text_config.vocab_size
+    pixels, input_ids, attn, vmask, labels = build_inputs(cfg_name, frames, rows)
+    B = len(rows)
+    t = lambda a: torch.from_numpy(a)
+    never = vocab - 1
+    beam_tokens = new_tokens if B == 1 else 8  # two rows x four beam runs x 14 steps never all survive the noise test below
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    chosen = None
+    for seed in range(max_seeds):
+        model = model.to(torch.float32)
+        load_det_weights(model, "varied", seed)
+        res = {}
+        for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            m = model.to(dtype)
+            kw = dict(input_ids=t(input_ids), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask), attention_mask=t(attn))
+            res[tag] = _greedy_with_scores(m, kw, new_tokens, never)
+        ids32, sc32 = res["fp32"]
+        ids16, sc16 = res["bf16"]
+        if sc32.shape != sc16.shape or ids32.shape != (B, new_tokens):  # a run emitted the "never" id and stopped: not this seed
+            print(f"{name}: weight seed {seed}: early stop", flush=True)
+            continue
+        tk = sc32.topk(2, dim=-1)
+        top2 = tk.values
+        margin = float((top2[..., 0] - top2[..., 1]).min())
+        dev = float((sc16.gather(-1, tk.indices) - top2).abs().max())  # the reference's own bf16 deviation on the two leading logits
+        distinct = min(len(set(r.tolist())) for r in ids32)
+        same = bool(torch.equal(ids32, ids16)) and ids32.shape == (B, new_tokens) and not bool((ids32 == never).any())
+        print(f"{name}: weight seed {seed}: fp32==bf16 ids {same}, distinct ids per row >= {distinct}, min top-2 margin {margin:.4f}, "
+              f"max |bf16 - fp32| of the top-2 step logits {dev:.4f}, logit std {float(sc32.std()):.3f}", flush=True)
+        r0 = ids32[0].tolist()
+        has_eos_step = same and any(r0[k] not in r0[:k] for k in range(4, new_tokens - 3))
+        print("   ", ids32.tolist(), flush=True)
+        if same and distinct >= 5 and margin >= 2.5 * dev and has_eos_step:
+            if name.startswith("mid") and not _beams_are_stable(model.to(torch.float32), dict(
+                    input_ids=t(input_ids), pixel_values=t(pixels), video_input_mask=t(vmask), attention_mask=t(attn)), beam_tokens,
+                    (r0[next(k for k in range(4, new_tokens - 3) if r0[k] not in r0[:k])], never)):
+                print("    beam search not stable under logit noise of bf16 size: next seed", flush=True)
+                continue
+            chosen = seed
+            break
+    assert chosen is not None, "no weight seed gives a well-separated, varied greedy sequence"
+    out = {}
+    model = model.to(torch.float32)
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        px = t(pixels).to(dtype)
+        kw = dict(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn))
+        ids, sc = _greedy_with_scores(m, kw, new_tokens, never)
+        out[f"{tag}_greedy_free"] = ids.numpy().astype(np.int64)
+        out[f"{tag}_step_logits_top8_ids"] = sc.topk(8, dim=-1).indices.numpy().astype(np.int64)      # (n, B, 8)
+        out[f"{tag}_step_logits_top8"] = sc.topk(8, dim=-1).values.numpy()
+        if full:
+            out[f"{tag}_logits_last"] = sc[0].numpy()                                                   # prefill last row, full vocabulary
+        else:
+            o = m(**kw, labels=t(labels), return_dict=True)
+            lg = o.logits.float().numpy()
+            out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
+            if lg.size <= (1 << 20):
+                out[f"{tag}_logits"] = lg
+            else:
+                out[f"{tag}_logits_last"] = lg[:, -1]
+            if name.startswith("mid"):
+                out[f"{tag}_step_logits"] = sc.numpy()                                                  # (n, B, vocab): every decode step
+        if tag == "fp32":  # a row that stops in the MIDDLE: eos = what row 0 emits at step 5, if it is new there
+            r0 = ids[0].tolist()
+            k_eos = next(k for k in range(4, new_tokens - 3) if r0[k] not in r0[:k])
+            eos = r0[k_eos]
+        g = m.generate(**kw, max_new_tokens=new_tokens, num_beams=1, do_sample=False, eos_token_id=eos)
+        out[f"{tag}_greedy_eos"] = g.numpy().astype(np.int64)
+        out[f"{tag}_eos_id"] = np.asarray(eos, dtype=np.int64)
+        if not full:
+            for nbm, lp, nm in ((5, -1.0, "beam5_lpm1"), (3, 1.0, "beam3_lp1")):
+                for e_id, suffix in ((eos, ""), (never, "_free")):
+                    g = m.generate(**kw, max_new_tokens=beam_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=e_id)
+                    out[f"{tag}_{nm}{suffix}"] = g.numpy().astype(np.int64)
+    assert np.array_equal(out["fp32_greedy_eos"], out["bf16_greedy_eos"])
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="varied", weight_seed=chosen,
+                never_id=never, beam_new_tokens=beam_tokens, torch=torch.__version__, transformers=transformers.__version__, generator="tools/make_goldens.py",
+                reference="/root/reference/eilev/model/v2.py")
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, labels=labels, meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+    print(name, "greedy fp32", out["fp32_greedy_free"].tolist(), "eos", out["fp32_greedy_eos"].tolist())
+
+
 REAL_CASES = {
     # name: (config, frames T, rows, new_tokens) — real widths, one block per stack (SURVEY 8c golden plan (2)).  The clip has
     # the real 8 frames so the Q-Former's cross-attention sees the real 2056 keys; L = 1 + 2 * 33 + 18 = 85 tokens.
@@ -438,6 +578,7 @@ def run_lm_debug_case(name="mid_lmdebug", base="mid_b2"):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug"]):
-        (run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug"] +
+              list(VARIED_CASES)):  # full_c1 (15 GB of fp32 weights, minutes): by name only
+        (run_varied_case if n in VARIED_CASES or n in FULL_CASES else run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
          else run_vit_debug_case if n == "mid_vitdebug" else run_lm_debug_case if n == "mid_lmdebug" else run_case)(n)

@@ -32,15 +32,14 @@ out = {"_comment": "HBM/fabric traffic and MFMA-busy counters of the ViT GEMM ke
                    "bench launch shape, random bf16 operands; tools/prof_round3.sh; raw: profiles/r03_gemm_pmc.txt.  bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream).  These are "
                    "L2 <-> fabric bytes: re-reads of an A / W panel by another XCD or a later tile batch that the 256-MB Infinity Cache serves "
-                   "are counted, so the figure is an UPPER bound of the HBM bytes (DESIGN 3c).  fc2's A operand exceeds the 32-bit DMA offset "
-                   "range and runs as two row-chunk launches: its numbers are per chunk launch.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                   "are counted, so the figure is an UPPER bound of the HBM bytes (DESIGN 3c).  fc2 is one launch of all rows (per-tile A descriptors, round 3).  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                    "1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); eff_clock_ghz = GRBM_GUI_ACTIVE / 8 / duration."}
 for name, v in vals.items():
     base = name.split("_")[0]
     n, k = SHAPES[base]
-    rows = M // 2 + (M % 2) if base == "fc2" else M
-    e = {"kernel": kern.get(name, ("?", 0))[0] + (" (2 chunk launches per call)" if base == "fc2" else ""),
-         "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE"), "algorithmic_bytes": 2 * (rows * k + (n * k // 2 if base == "fc2" else n * k) + rows * n * (2 if base in ("fc2", "proj") else 1)),
+    rows = M
+    e = {"kernel": kern.get(name, ("?", 0))[0],
+         "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE"), "algorithmic_bytes": 2 * (rows * k + n * k + rows * n * (2 if base in ("fc2", "proj") else 1)),
          "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES"),
          "grbm_gui_active": v.get("GRBM_GUI_ACTIVE"), "dur_us": v.get("_dur_us")}
     if e["mfma_busy_cycles"] and e["grbm_gui_active"]:
