@@ -321,7 +321,40 @@ def strong_scaling_phase(eng, cfg, world, rank, dev, exch_weak, is_t5, global_sa
         dt = float(t.item())
     assert out is None or out.shape == (len(mine), NEW_TOKENS)
     clips = global_samples * cps
-    return {"what": f"SURVEY 8(d): {global_samples} samples per GLOBAL step x {cps} clips = {clips} clips dealt over {world} rank(s), language model "
+    projection = None
+    if world == 1 and not is_t5:
+        # What ONE rank of an N-rank strong-scaling job would run, measured on this GPU: its dealt clips through ViT + Q-Former +
+        # projection, then prefill + decode of its global_samples / N samples (N = 8: 17 clips, ONE sample, batch-1 decode).  The
+        # exchange itself (2.8 MB per rank at N = 8, on a side stream under the next chunk's ViT) is not in it.  speedup = this job's
+        # measured N = 1 step / that share: the strong-scaling curve the design predicts BEFORE multi-GPU hardware runs it.
+        t1 = 1e3 * dt / steps
+        projection = {"what": "one rank's share of the fixed global step, timed alone on this GPU (encode of its dealt clips + prefill and "
+                              "decode of its samples; exchange excluded): projected speed-up = measured N=1 step / share", "n1_ms_per_step": round(t1, 3)}
+        for n_ranks in (2, 4, 8):
+            if global_samples % n_ranks:
+                continue
+            ns_, nc_ = global_samples // n_ranks, clips // n_ranks
+            ids_n, vm_n, am_n, px_n = ids[:ns_], vm[:ns_], am[:ns_], px[:nc_]
+
+            def share(first):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                feats = torch.cat([eng.encode_clips(px_n[i:i + 136]) for i in range(0, nc_, 136)])
+                e1.record()
+                emb = eng.embed_scatter(ids_n, vm_n, feats, validated=not first)
+                eng.greedy_decode(emb, am_n, NEW_TOKENS, eos_id=-1, pad_id=1, use_graph=True)
+                e2.record()
+                torch.cuda.synchronize(dev)
+                return e0.elapsed_time(e1), e1.elapsed_time(e2)
+
+            share(True)
+            runs = [share(False) for _ in range(3)]
+            enc_ms, lm_ms = min(r[0] for r in runs), min(r[1] for r in runs)
+            projection[f"N={n_ranks}"] = {"clips": nc_, "samples": ns_, "encode_ms": round(enc_ms, 2), "prefill_decode_ms": round(lm_ms, 2),
+                                          "share_ms": round(enc_ms + lm_ms, 2), "projected_speedup": round(t1 / (enc_ms + lm_ms), 2)}
+        if "N=8" in projection:
+            projection["projected_speedup_at_8"] = projection["N=8"]["projected_speedup"]
+    return {"projection": projection, "what": f"SURVEY 8(d): {global_samples} samples per GLOBAL step x {cps} clips = {clips} clips dealt over {world} rank(s), language model "
                     f"data-parallel over samples; fixed total work, same timing bracket as the headline number",
             "scaling": "strong", "global_samples": global_samples, "clips_per_step": clips, "steps": steps, "warmup": warmup,
             "value": round(clips * steps / dt, 3), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3),

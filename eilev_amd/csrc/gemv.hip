@@ -19,6 +19,7 @@
 // HBM-bound: the weight bytes are read exactly once; the activations (M x K x 2 B) come from L2 once per workgroup.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -55,6 +56,15 @@ __device__ __forceinline__ float dot8(const u32x4_t &w, const u32x4_t &x, float 
         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, we), __builtin_bit_cast(bf16x2_t, xe), acc, false);
     }
     return acc;
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_i_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for_i(F &&f) {
+    static_for_i_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // MR: the number of rows M, compile-time (1..8: a run-time bound made hipcc branch around every row's dot products).  The rows [M][K] are staged ONCE in LDS as bf16 (host: M * K * 2 <= 150 KB), the
@@ -227,6 +237,167 @@ int launch_rows_p(const GemvArgs &a, int grid, size_t smem, hipStream_t s) {
     }
 }
 
+
+// ---- M = 1 (round 4): activations in REGISTERS, no LDS, no barrier, a register ring of weight sub-blocks ----------------------------------
+// Per-kernel durations of the batch-1 step (profiles/r04_decode_b1_kernel_stats.md): q|k|v 13 us for 39 MB, out_proj 11.3 us for 13 MB,
+// fc1 15.4 / fc2 13.3 us for 52 MB each — 3-4 TB/s inside a kernel, ~2.2 TB/s over the block — where a launch-per-op batch-1 layer of
+// this size streams at ~4 TB/s end to end on this part (MI355X_MICROARCH.md, launches-baseline: 121.6 MB in 30.7 us).  What the kernel
+// above spends around its stream: the rows staged through LDS behind a __syncthreads with ONE sub-block of weights (5 KB per wave) in
+// flight, a grid that covers the CUs unevenly (480 / 320 / 640 workgroups over 256 CUs), the merge of the attention partials repeated by
+// every workgroup of out_proj.  Here, for one row:
+//   * grid = one 320-thread workgroup per CU (5 waves: 1280 waves divide N = 2560 / 7680 / 10240 evenly), wave w owns contiguous output
+//     rows: every CU streams the same number of bytes and the launch ends everywhere at once;
+//   * lane l keeps ITS 8 elements of every 512-element chunk of x in registers (K = 10240: 80 VGPRs), loaded straight from L2 (PRO_X) or
+//     produced by a per-wave LayerNorm (PRO_LN: the row is 5 KB; every wave recomputes mean / variance from registers) — no LDS, no barrier;
+//   * RB sub-blocks of SB chunks (K = 2560: 8 x 5 KB = every byte of a wave's q|k|v or fc1 rows) are requested before anything else;
+//     waves with more items than ring slots (the lm_head: 40 rows) run a branch-free steady loop — consume slot, refill slot — so that
+//     hipcc's wait-count pass sees straight-line code and emits counted vmcnt waits (with a branch around a refill it joins the paths
+//     with vmcnt(0): one sub-block in flight; inline-asm loads with hand-counted waits were tried first and are not safe: the compiler
+//     may COPY an asm output register before the hand-written wait);
+//   * bias / residual of the wave's rows come through the SCALAR cache (wave-uniform addresses): a vector load behind the prefetched
+//     weights would return after them (returns are in order) and stall the ring once per row;
+//   * results stay in lane (row - first row) until the end: one store per wave.
+template <int NCH, int PRO, int SB, int RB>
+__global__ __launch_bounds__(320) void gemv1_kernel(const GemvArgs a) {
+    constexpr int IPR = NCH / SB;  // items (sub-blocks) per output row
+    static_assert(NCH % SB == 0 && RB % IPR == 0, "ring / row geometry");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 5 + (threadIdx.x >> 6)));
+    // rows [r0, r1) of this wave: N / W each, the first N % W waves one more (quotient and remainder from the host: a 64-bit division
+    // here costs some two hundred scalar instructions before the first load)
+    const int r0 = wave * a.rows_per_wave + (wave < a.KB ? wave : a.KB), r1 = r0 + a.rows_per_wave + (wave < a.KB ? 1 : 0);
+    const int total = (r1 - r0) * IPR;
+    constexpr int K = NCH * 512;
+    u32x4_t wv[RB][SB];
+    const bf16 *wbase = a.W + (int64_t)r0 * K + lane * 8;
+    auto load_item = [&](int it, auto buf_c) {  // item it = (row it / IPR, sub-block it % IPR): SB * 512 consecutive weights
+        constexpr int B = decltype(buf_c)::value;
+        const bf16 *wrow = wbase + (int64_t)it * (SB * 512);
+#pragma unroll
+        for (int c = 0; c < SB; ++c) wv[B][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wrow + c * 512));
+    };
+    u32x4_t xr[NCH];
+    auto load_x = [&]() {  // the row of activations: lane l holds elements [c * 512 + l * 8, + 8) of every chunk c
+        if constexpr (PRO == PRO_LN) {
+            // the row stays bf16 in registers (NCH x 4 VGPRs) and is unpacked in each of the three passes: an fp32 copy (8 NCH registers)
+            // beside the ring made hipcc spill
+            bf16x8 xb[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) xb[c] = *reinterpret_cast<const bf16x8 *>(a.x + c * 512 + lane * 8);
+            float s1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float f[8];
+                unpack8(xb[c], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1 += f[e];
+            }
+            const float mean = wave_sum(s1) / (float)K;
+            float s2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float f[8];
+                unpack8(xb[c], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s2 = fmaf(f[e] - mean, f[e] - mean, s2);
+            }
+            const float rstd = rsqrtf(wave_sum(s2) / (float)K + a.eps);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float f[8], gm[8], bt[8];
+                unpack8(xb[c], f);
+                unpack8(*reinterpret_cast<const bf16x8 *>(a.gamma + c * 512 + lane * 8), gm);
+                unpack8(*reinterpret_cast<const bf16x8 *>(a.beta + c * 512 + lane * 8), bt);
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((f[e] - mean) * rstd * gm[e] + bt[e]);
+                xr[c] = __builtin_bit_cast(u32x4_t, v);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const u32x4_t *>(a.x + c * 512 + lane * 8);
+        }
+    };
+    float acc = 0.0f, mine = 0.0f;  // mine: the finished value of row r0 + lane (mod 64)
+    const unsigned *bias32 = reinterpret_cast<const unsigned *>(a.bias), *res32 = reinterpret_cast<const unsigned *>(a.resid);
+    auto finish_row = [&](int r) {  // r wave-uniform
+        const int n = r0 + r;
+        float v = wave_sum(acc);
+        acc = 0.0f;
+        if (bias32) {  // wave-uniform address: one scalar load, no entry in the vector-memory queue
+            const unsigned w2 = bias32[n >> 1];
+            v += __builtin_bit_cast(float, (n & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+        }
+        if (n < a.scale_cols) v *= a.scale;
+        if (a.epi == 2) v = fmaxf(v, 0.0f);
+        if (res32) {
+            const unsigned w2 = res32[n >> 1];
+            v += __builtin_bit_cast(float, (n & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+        }
+        if (lane == (r & 63)) mine = v;
+        if ((r & 63) == 63 || r + 1 == r1 - r0) {  // 64 rows collected or the wave's last row: one store
+            const int rr = (r & ~63) + lane;
+            if (rr <= r) {
+                if (a.out_f32) reinterpret_cast<float *>(a.out)[r0 + rr] = mine;
+                else reinterpret_cast<bf16 *>(a.out)[r0 + rr] = (bf16)mine;
+            }
+        }
+    };
+    auto consume = [&](int it, auto j_c) {  // slot J holds item it; it % IPR == J % IPR (every base is a multiple of RB, RB % IPR == 0)
+        constexpr int J = decltype(j_c)::value, SBI = J % IPR;
+#pragma unroll
+        for (int c = 0; c < SB; ++c) acc = dot8(wv[J][c], xr[SBI * SB + c], acc);
+        if constexpr (SBI == IPR - 1) finish_row(it / IPR);
+    };
+    if (total >= 2 * RB) {
+        // long waves (the lm_head): RB items in flight, branch-free steady loop
+        static_for_i<RB>([&](auto j_c) { load_item(decltype(j_c)::value, j_c); });
+        load_x();
+        int base = 0;
+        for (; base + 2 * RB <= total; base += RB)
+            static_for_i<RB>([&](auto j_c) {
+                consume(base + decltype(j_c)::value, j_c);
+                load_item(base + decltype(j_c)::value + RB, j_c);
+            });
+        static_for_i<RB>([&](auto j_c) {
+            consume(base + decltype(j_c)::value, j_c);
+            if (base + decltype(j_c)::value + RB < total) load_item(base + decltype(j_c)::value + RB, j_c);
+        });
+        base += RB;
+        static_for_i<RB>([&](auto j_c) {
+            if (base + decltype(j_c)::value < total) consume(base + decltype(j_c)::value, j_c);
+        });
+    } else {
+        // short waves (every block matrix at K = 2560: 6 / 2 / 8 items): all of the wave's weights are requested up front
+        static_for_i<RB>([&](auto j_c) {
+            if (decltype(j_c)::value < total) load_item(decltype(j_c)::value, j_c);
+        });
+        load_x();
+        static_for_i<RB>([&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            if (J < total) {
+                consume(J, j_c);
+                if (J + RB < total) load_item(J + RB, j_c);
+            }
+        });
+        static_for_i<RB>([&](auto j_c) {
+            if (decltype(j_c)::value + RB < total) consume(decltype(j_c)::value + RB, j_c);
+        });
+    }
+}
+
+template <int NCH, int PRO>
+int launch_gemv1_c(const GemvArgs &a, int grid, hipStream_t s) {
+    constexpr int SB = NCH % 5 == 0 ? 5 : 8;
+    constexpr int IPR = NCH / SB;
+    // registers: ring RB * SB * 4 + x NCH * 4 (K = 2560: 160 + 20; K = 10240: 80 + 80); the LayerNorm prologue holds the row as 8 NCH floats
+    // beside the ring (RB = 8 spilled 204 VGPRs there)
+    constexpr int RB = IPR == 1 ? (SB == 5 ? (PRO == PRO_LN ? 4 : 8) : (PRO == PRO_LN ? 2 : 4)) : 4;
+    hipLaunchKernelGGL((gemv1_kernel<NCH, PRO, SB, RB>), dim3(grid), dim3(320), 0, s, a);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 }  // namespace
 
 // M rows of K bf16 must fit the LDS staging (150 KB): M = 8 with K = 10240 (160 KB) does not — those shapes keep the MFMA kernels
@@ -261,4 +432,40 @@ int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, con
         return EILEV_E_UNSUPPORTED;
     }
     return launch_rows_p<PRO_X>(a, grid, smem, s);
+}
+
+
+// M = 1 fast path (gemv1_kernel): x (K), K / 512 in {5, 8, 20}; pro 0 = x as given, 1 = LayerNorm(x).  n_cu workgroups of 5 waves.
+bool gemv1_ok(int N, int K, int pro) {
+    const int nch = K >> 9;
+    if (K % 512 || N < 1) return false;
+    if (pro == PRO_LN) return nch == 5;  // (K = 4096 with the LayerNorm prologue spills 60 VGPRs: the LDS kernel above)
+    return pro == PRO_X && (nch == 5 || nch == 8 || nch == 20);  // (K = 16384: 128 registers of x alone — the LDS kernel above)
+}
+int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid, void *out,
+                 int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s) {
+    if (!gemv1_ok(N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
+    if ((bias && ((uintptr_t)bias & 3)) || (resid && ((uintptr_t)resid & 3)) || (pro == PRO_LN && (!gamma || !beta))) return EILEV_E_BADARG;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    GemvArgs a = {};
+    a.x = x; a.ldx = K; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.out = out; a.ldo = N;
+    a.out_f32 = out_f32; a.M = 1; a.N = N; a.K = K; a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;
+    int grid = n_cu;
+    if ((int64_t)grid * 5 > N) grid = (N + 4) / 5;
+    a.rows_per_wave = N / (grid * 5);
+    a.KB = N % (grid * 5);  // (field reused: the first KB waves own one row more)
+    const int nch = K >> 9;
+    if (pro == PRO_LN) return launch_gemv1_c<5, PRO_LN>(a, grid, s);
+    switch (nch) {
+        case 5: return launch_gemv1_c<5, PRO_X>(a, grid, s);
+        case 8: return launch_gemv1_c<8, PRO_X>(a, grid, s);
+        default: return launch_gemv1_c<20, PRO_X>(a, grid, s);
+    }
 }

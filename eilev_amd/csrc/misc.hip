@@ -375,6 +375,98 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16 *__re
     }
 }
 
+// ---- small-batch form (round 4): ONE workgroup per (row, head), every key in one pass, no partials, no merge -------------------------------
+// At batch 1 the split kernel above costs 13.9 us per block for 9.8 MB of keys and values (profiles/r04_decode_b1_kernel_stats.md): 128
+// workgroups each walk three dependent load rounds, and the merge of their partials was repeated by every workgroup of out_proj.  Here a
+// 1024-thread workgroup owns a head: thread j requests key j's whole row (NCH 16-byte loads) AND its share of V (thread (kg, c): chunk c of
+// keys kg, kg + G, ... — VK loads) before anything is computed, so the head's K and V (307 KB at 960 keys x 80) arrive in one round trip;
+// scores, a block-wide softmax (P rounded to bf16 for the product like every attention kernel here, the row sum from the unrounded
+// values), p . V through LDS partials, the normalised row straight to `out`.  The new token's K / V come from the q|k|v row and are
+// stored to the cache here (fuse_new of the split kernel).  Needs cap <= 1024 and cap <= VK * (1024 / NCH).
+template <int NCH, int VK>
+__global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
+                                                            bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
+                                                            const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
+    constexpr int hd = NCH * 8, G = 1024 / NCH;
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ float ps[1024];
+    __shared__ float wred[32];
+    __shared__ float part[G * hd];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, d = heads * hd;
+    const int kv_total = min(cap, seq_len + state[0]);
+    const int slot_new = kv_total - 1;
+    bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
+    // every load of the workgroup is requested here
+    const int jk = tid < kv_total ? tid : slot_new;
+    const bf16 *kp = jk == slot_new ? knew : kbase + (int64_t)jk * hd;
+    bf16x8 kr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) kr[c] = *reinterpret_cast<const bf16x8 *>(kp + c * 8);
+    const int vc_ = tid % NCH, kg = tid / NCH;
+    bf16x8 vr[VK];
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        int key = kg + i * G;
+        key = key < kv_total ? key : slot_new;
+        const bf16 *vp = key == slot_new ? vnew : vbase + (int64_t)key * hd;
+        vr[i] = *reinterpret_cast<const bf16x8 *>(vp + vc_ * 8);
+    }
+    const bool vis = tid < kv_total && (tid >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + tid] != 0);
+    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
+    if (tid >= 1024 - 2 * NCH) {  // the new token's K / V -> the cache (what a separate kv_write launch did)
+        const int t2 = tid - (1024 - 2 * NCH), which = t2 / NCH, cc = t2 - which * NCH;
+        *reinterpret_cast<bf16x8 *>((which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
+    }
+    __syncthreads();
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float kv[8];
+        unpack8(kr[c], kv);
+        const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]), q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+        s += kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
+    }
+    s = vis ? s : -1e30f;
+    const float mxw = wave_max(s);
+    if (lane == 0) wred[wid] = mxw;
+    __syncthreads();
+    float mx = wred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, wred[w]);
+    const float p = s > -1e29f ? __expf(s - mx) : 0.0f;
+    ps[tid] = (float)(bf16)p;
+    const float sw = wave_sum(p);
+    if (lane == 0) wred[16 + wid] = sw;
+    __syncthreads();
+    float lsum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) lsum += wred[16 + w];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        const int key = kg + i * G;
+        const float pj = key < kv_total ? ps[key < 1024 ? key : 1023] : 0.0f;
+        float vv[8];
+        unpack8(vr[i], vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
+    }
+    if (kg < G) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[kg * hd + vc_ * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float v = 0.0f;
+        for (int k2 = 0; k2 < G; ++k2) v += part[k2 * hd + tid];
+        out[((int64_t)b * heads + h) * hd + tid] = (bf16)(lsum > 0.0f ? v / lsum : 0.0f);
+    }
+}
+
 __global__ __launch_bounds__(128) void attn_decode_merge_kernel(const float *__restrict__ part, bf16 *__restrict__ out,
                                                                 int heads, int hd, int nsplit) {
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
@@ -638,6 +730,24 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
     EILEV_LAUNCH_CHECK();
     if (!out) return EILEV_OK;  // the caller merges the partials itself (gemv.hip: in the prologue of out_proj)
     hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, nsplit);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+// plain decode step at small batch (no beams, no relative bias): true if the one-pass kernel took it
+bool attn_decode1_ok(int batch, int cap, int hd) {
+    if (batch > 8 || cap > 1024) return false;
+    if (hd == 80) return cap <= 12 * (1024 / 10);
+    if (hd == 64) return cap <= 8 * (1024 / 8);
+    if (hd == 128) return cap <= 8 * (1024 / 16);
+    return false;
+}
+int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state, int batch, int seq_len,
+                        int cap, int heads, int hd, hipStream_t s) {
+    if (!attn_decode1_ok(batch, cap, hd) || !state || !out) return EILEV_E_UNSUPPORTED;
+    const int64_t ldq = 3 * (int64_t)heads * hd;
+    if (hd == 80) hipLaunchKernelGGL((attn_decode1_kernel<10, 12>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
+    else if (hd == 64) hipLaunchKernelGGL((attn_decode1_kernel<8, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
+    else hipLaunchKernelGGL((attn_decode1_kernel<16, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -646,6 +646,13 @@ bool opt_rows_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M) {
     }
     return true;
 }
+// batch 1 (latency mode; one sample per GPU of a strong-scaled step): gemv1_kernel + attn_decode1_kernel.  eilev_debug_decode_rows(3) = off
+bool opt_rows1_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M, int64_t cap) {
+    if (M != 1 || g_decode_rows == 3 || !opt_rows_usable(d, w, M)) return false;
+    const int D = d->t_hidden;
+    return gemv1_ok(3 * D, D, 1) && gemv1_ok(D, D, 0) && gemv1_ok(d->t_ffn, D, 1) && gemv1_ok(D, d->t_ffn, 0) && gemv1_ok(d->vocab, D, 1) &&
+           attn_decode1_ok(1, (int)cap, D / d->t_heads);
+}
 // self_attn_layer_norm + q|k|v of block l from b.h into b.qkv (q pre-scaled)
 int opt_rows_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
     const EilevOptLayer *L = &w->layers[l];
@@ -816,6 +823,23 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
     RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab,
                            d->max_pos + 1, b.h, (int)batch, D, s));
     const size_t per_layer = (size_t)2 * batch * H * kv_capacity * hd;
+    if (opt_rows1_usable(d, w, batch, kv_capacity)) {  // ONE row (round 4): register-resident activations, one-pass attention: 5 launches per block
+        for (int l = 0; l < d->t_layers; ++l) {
+            const EilevOptLayer *L = &w->layers[l];
+            bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+            const int Ft = d->t_ffn;
+            RC(launch_gemv1(1, b.h, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, d->t_eps, (const bf16 *)L->q_w, (const bf16 *)L->q_b, nullptr, b.qkv, 0, 3 * D, D, 0,
+                            1.0f / sqrtf((float)hd), D, s));
+            RC(launch_attn_decode1(b.qkv, kc, vc, b.att, attn_mask, state, 1, (int)seq_len, (int)kv_capacity, H, hd, s));
+            RC(launch_gemv1(0, b.att, nullptr, nullptr, 0.f, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, b.h, 0, D, D, 0, 1.0f, 0, s));
+            RC(launch_gemv1(1, b.h, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, d->t_eps, (const bf16 *)L->fc1_w, (const bf16 *)L->fc1_b, nullptr, b.ffn, 0, Ft, D, 2,
+                            1.0f, 0, s));
+            RC(launch_gemv1(0, b.ffn, nullptr, nullptr, 0.f, (const bf16 *)L->fc2_w, (const bf16 *)L->fc2_b, b.h, b.h, 0, D, Ft, 0, 1.0f, 0, s));
+        }
+        RC(launch_gemv1(1, b.h, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, d->t_eps, (const bf16 *)w->embed_tokens, nullptr, nullptr, logits, 1, d->vocab,
+                        D, 0, 1.0f, 0, s));
+        return launch_select(logits, 1, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
+    }
     if (opt_rows_usable(d, w, batch)) {  // M <= 8: row-dot kernels with LayerNorm / merge in their prologues (gemv.hip): 5 launches + attention per block
         float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
         const int nsplit = (int)((kv_capacity + kDecodeKeys - 1) / kDecodeKeys);
@@ -1006,6 +1030,9 @@ extern "C" int eilev_linear_rows(const void *x, const void *ln_gamma, const void
                                  const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
     if (!x || !w || !c || m <= 0 || n <= 0 || k <= 0 || n > 0x7fffffff || k > 0x7fffffff || (ln_gamma != nullptr) != (ln_beta != nullptr)) return EILEV_E_BADARG;
     if (m > 8 || !gemv_rows_ok((int)m, (int)n, (int)k) || (epilogue != 0 && epilogue != 2)) return EILEV_E_UNSUPPORTED;
+    if (m == 1 && g_decode_rows != 3 && gemv1_ok((int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3))  // round 4: one row
+        return launch_gemv1(ln_gamma ? 1 : 0, (const bf16 *)x, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, (const bf16 *)w, (const bf16 *)bias,
+                            (const bf16 *)residual, c, out_f32, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
     return launch_gemv_rows(ln_gamma ? 1 : 0, (const bf16 *)x, k, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, nullptr, 0, 0, 0, (const bf16 *)w,
                             (const bf16 *)bias, (const bf16 *)residual, n, c, n, out_f32, (int)m, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
 }

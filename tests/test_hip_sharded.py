@@ -127,11 +127,12 @@ def test_rccl_entries_on_a_one_rank_communicator():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows(world):
+@pytest.mark.parametrize("world,samples", [(2, 2), (3, 2), (8, 1)])
+def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows(world, samples):
     """`python bench.py --gpus 2` must start two ranks itself (`--gpus` was dead).  One GPU here, so the ranks share it
     over gloo (`--share-gpu`); everything else — launcher, deal, exchange rounds on the side stream, LM sharding, max-over-ranks
-    timing, the one JSON line — is the path the driver's scaling run takes."""
+    timing, the one JSON line — is the path the driver's scaling run takes.  world = 8 (round 4) is the driver's largest launch: eight
+    processes, eight exchange plans, ONE sample per rank in the strong-scaling phase (batch-1 prefill and decode)."""
     import json
     import subprocess
     import sys
@@ -139,12 +140,12 @@ def test_bench_launches_n_ranks_and_the_exchanged_rows_are_the_local_rows(world)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--share-gpu", "--steps", "1", "--warmup", "0",
-                        "--samples", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+                        "--samples", str(samples)], capture_output=True, text=True, timeout=900 if world < 8 else 1800, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res["n_gpus"] == world and res["config"]["clips_per_step"] == world * 2 * 17 and res["scaling"] == "weak"
+    assert res["n_gpus"] == world and res["config"]["clips_per_step"] == world * samples * 17 and res["scaling"] == "weak"
     assert res["sharded_check"]["ok"], res["sharded_check"]
     # round 3: what the exchange did during the timed steps, and the fixed-work (strong-scaling) phase of SURVEY 8(d) in the same job
     ex = res["exchange"]

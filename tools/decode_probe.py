@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GPU probe: ms per decode step (hipGraph) at batch 32 / L = 960 with the bench's OPT-2.7B, several rounds."""
+"""GPU probe: ms per decode step (hipGraph) at batch PROBE_B (default 32) / L = 960 with the bench's OPT-2.7B, several rounds."""
 import os
 import sys
 
@@ -14,7 +14,7 @@ cfg = blip2_config("opt27")
 dev = torch.device("cuda")
 w = bench.random_weights(cfg, dev)
 eng = HipEngine(cfg, w, device=dev, parts=("opt",))
-B, L, NEW = 32, 960, 32
+B, L, NEW = int(os.environ.get("PROBE_B", "32")), 960, 32
 emb = (torch.randn(B, L, cfg.text_config.hidden_size, device=dev) * 0.02).to(torch.bfloat16)
 am = torch.ones(B, L, dtype=torch.int32, device=dev)
 import ctypes as C

@@ -359,6 +359,12 @@ def run_varied_case(name, max_seeds=2000):
         r0 = ids32[0].tolist()
         has_eos_step = same and any(r0[k] not in r0[:k] for k in range(4, new_tokens - 3))
         print("   ", ids32.tolist(), flush=True)
+        if full and same and margin >= 2.0 * dev:
+            # 39 + 12 + 32 blocks take ~10 minutes per pass on this host: no search for variety here (a deep random stack settles on a
+            # fixed point whatever the embedding scale; varied ids are what mid_v* / real_v1 are for).  What this fixture adds is DEPTH:
+            # the full-vocabulary prefill row, the 32 greedy ids, and a FORCED continuation (below) whose tokens do change.
+            chosen = seed
+            break
         if same and distinct >= 5 and margin >= 2.5 * dev and has_eos_step:
             if name.startswith("mid") and not _beams_are_stable(model.to(torch.float32), dict(
                     input_ids=t(input_ids), pixel_values=t(pixels), video_input_mask=t(vmask), attention_mask=t(attn)), beam_tokens,
@@ -390,6 +396,23 @@ def run_varied_case(name, max_seeds=2000):
                 out[f"{tag}_logits_last"] = lg[:, -1]
             if name.startswith("mid"):
                 out[f"{tag}_step_logits"] = sc.numpy()                                                  # (n, B, vocab): every decode step
+        if full:
+            # teacher-forced continuation: 24 pseudo-random tokens appended to the prompt, ONE forward of the reference over prompt +
+            # tokens; logits of position L - 1 + j = what a decode step returns after j forced tokens (positions, KV slots and 32 blocks
+            # of weight-streaming kernels, on inputs that differ at every step)
+            from eilev_amd.synth import det_uniform_int
+
+            forced = det_uniform_int("full_c1_forced", (B, 24), 4, 50000)
+            ids_f = np.concatenate([input_ids, forced], 1)
+            am_f = np.concatenate([attn, np.ones_like(forced)], 1)
+            vm_f = np.concatenate([vmask, np.zeros_like(forced)], 1)
+            o = m(input_ids=t(ids_f), pixel_values=px, video_input_mask=t(vm_f), attention_mask=t(am_f), return_dict=True)
+            lg = o.logits.float()[:, input_ids.shape[1] - 1:]                                           # (B, 25, vocab)
+            out["forced_tokens"] = forced
+            out[f"{tag}_forced_top8_ids"] = lg.topk(8, dim=-1).indices.numpy().astype(np.int64)
+            out[f"{tag}_forced_top8"] = lg.topk(8, dim=-1).values.numpy()
+            out[f"{tag}_forced_logits_row12"] = lg[:, 12].numpy()                                       # one full row in the middle
+            continue
         if tag == "fp32":  # a row that stops in the MIDDLE: eos = what row 0 emits at step 5, if it is new there
             r0 = ids[0].tolist()
             k_eos = next(k for k in range(4, new_tokens - 3) if r0[k] not in r0[:k])
@@ -402,7 +425,7 @@ def run_varied_case(name, max_seeds=2000):
                 for e_id, suffix in ((eos, ""), (never, "_free")):
                     g = m.generate(**kw, max_new_tokens=beam_tokens, num_beams=nbm, do_sample=False, length_penalty=lp, eos_token_id=e_id)
                     out[f"{tag}_{nm}{suffix}"] = g.numpy().astype(np.int64)
-    assert np.array_equal(out["fp32_greedy_eos"], out["bf16_greedy_eos"])
+    assert full or np.array_equal(out["fp32_greedy_eos"], out["bf16_greedy_eos"])
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="varied", weight_seed=chosen,
                 never_id=never, beam_new_tokens=beam_tokens, torch=torch.__version__, transformers=transformers.__version__, generator="tools/make_goldens.py",
                 reference="/root/reference/eilev/model/v2.py")
@@ -410,7 +433,7 @@ def run_varied_case(name, max_seeds=2000):
     path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **out)
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
-    print(name, "greedy fp32", out["fp32_greedy_free"].tolist(), "eos", out["fp32_greedy_eos"].tolist())
+    print(name, "greedy fp32", out["fp32_greedy_free"].tolist(), "eos", out["fp32_greedy_eos"].tolist() if "fp32_greedy_eos" in out else None)
 
 
 REAL_CASES = {
