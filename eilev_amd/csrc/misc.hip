@@ -387,31 +387,32 @@ template <int NCH, int VK>
 __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                             bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
                                                             const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
-    constexpr int hd = NCH * 8, G = 1024 / NCH;
+    constexpr int hd = NCH * 8, G = 1024 / NCH, RS = NCH + 1;  // RS: row stride of the per-key chunk partials (odd: conflict-free column sums)
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float ps[1024];
     __shared__ float wred[32];
-    __shared__ float part[G * hd];
+    __shared__ float red[1024 * RS];  // scores: [key][chunk] partial dot products; afterwards the p . V partials [key group][hd] (G * hd <= 1024 * 8)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, d = heads * hd;
     const int kv_total = min(cap, seq_len + state[0]);
     const int slot_new = kv_total - 1;
     bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
     const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
-    // every load of the workgroup is requested here
-    const int jk = tid < kv_total ? tid : slot_new;
-    const bf16 *kp = jk == slot_new ? knew : kbase + (int64_t)jk * hd;
-    bf16x8 kr[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) kr[c] = *reinterpret_cast<const bf16x8 *>(kp + c * 8);
-    const int vc_ = tid % NCH, kg = tid / NCH;
-    bf16x8 vr[VK];
+    // every load of the workgroup is requested here.  Thread (kg, c) owns 16-byte chunk c of keys kg, kg + G, ...: consecutive lanes read
+    // consecutive bytes (one key row per thread touches 64 cache lines per instruction and re-fetches each of them NCH times: 15 us)
+    const int c = tid % NCH, kg = tid / NCH;
+    bf16x8 kr[VK], vr[VK];
 #pragma unroll
     for (int i = 0; i < VK; ++i) {
         int key = kg + i * G;
         key = key < kv_total ? key : slot_new;
-        const bf16 *vp = key == slot_new ? vnew : vbase + (int64_t)key * hd;
-        vr[i] = *reinterpret_cast<const bf16x8 *>(vp + vc_ * 8);
+        kr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? knew : kbase + (int64_t)key * hd) + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        int key = kg + i * G;
+        key = key < kv_total ? key : slot_new;
+        vr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? vnew : vbase + (int64_t)key * hd) + c * 8);
     }
     const bool vis = tid < kv_total && (tid >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + tid] != 0);
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
@@ -420,14 +421,21 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
         *reinterpret_cast<bf16x8 *>((which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
     }
     __syncthreads();
+    if (kg < G) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]), q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+#pragma unroll
+        for (int i = 0; i < VK; ++i) {
+            const int key = kg + i * G;
+            float kv[8];
+            unpack8(kr[i], kv);
+            if (key < 1024)
+                red[key * RS + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
+        }
+    }
+    __syncthreads();
     float s = 0.0f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        float kv[8];
-        unpack8(kr[c], kv);
-        const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]), q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
-        s += kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
-    }
+    for (int cc = 0; cc < NCH; ++cc) s += red[tid * RS + cc];
     s = vis ? s : -1e30f;
     const float mxw = wave_max(s);
     if (lane == 0) wred[wid] = mxw;
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
     ps[tid] = (float)(bf16)p;
     const float sw = wave_sum(p);
     if (lane == 0) wred[16 + wid] = sw;
-    __syncthreads();
+    __syncthreads();  // (also: every thread has read its red[] column sums)
     float lsum = 0.0f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) lsum += wred[16 + w];
@@ -457,12 +465,23 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
     }
     if (kg < G) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[kg * hd + vc_ * 8 + e] = acc[e];
+        for (int e = 0; e < 8; ++e) red[kg * hd + c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    // G partial rows -> one: two levels (a single thread per output element walking all G partials is a chain of G dependent LDS reads:
+    // ~5 us of the 12 this kernel took)
+    constexpr int P2 = 1024 / hd;  // threads per output element in the first level
+    const int dd = tid % hd, j = tid / hd;
+    if (j < P2) {
+        float v = 0.0f;
+        for (int k2 = j; k2 < G; k2 += P2) v += red[k2 * hd + dd];
+        ps[j * hd + dd] = v;  // (ps is free: every p was consumed before the barrier above; P2 * hd <= 1024)
     }
     __syncthreads();
     if (tid < hd) {
         float v = 0.0f;
-        for (int k2 = 0; k2 < G; ++k2) v += part[k2 * hd + tid];
+#pragma unroll
+        for (int jj = 0; jj < P2; ++jj) v += ps[jj * hd + tid];
         out[((int64_t)b * heads + h) * hd + tid] = (bf16)(lsum > 0.0f ? v / lsum : 0.0f);
     }
 }
@@ -738,16 +757,14 @@ bool attn_decode1_ok(int batch, int cap, int hd) {
     if (batch > 8 || cap > 1024) return false;
     if (hd == 80) return cap <= 12 * (1024 / 10);
     if (hd == 64) return cap <= 8 * (1024 / 8);
-    if (hd == 128) return cap <= 8 * (1024 / 16);
-    return false;
+    return false;  // (head size 128: 74 KB of static LDS for the partials — the split kernel)
 }
 int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state, int batch, int seq_len,
                         int cap, int heads, int hd, hipStream_t s) {
     if (!attn_decode1_ok(batch, cap, hd) || !state || !out) return EILEV_E_UNSUPPORTED;
     const int64_t ldq = 3 * (int64_t)heads * hd;
     if (hd == 80) hipLaunchKernelGGL((attn_decode1_kernel<10, 12>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
-    else if (hd == 64) hipLaunchKernelGGL((attn_decode1_kernel<8, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
-    else hipLaunchKernelGGL((attn_decode1_kernel<16, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
+    else hipLaunchKernelGGL((attn_decode1_kernel<8, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -134,3 +134,63 @@ def synth_interleaved_ids(
         ids += toks
         mask += [0] * len(toks)
     return np.asarray(ids, dtype=np.int64), np.asarray(mask, dtype=np.int64)
+
+
+# ---- the same generator on a torch device (bit-identical; tests/test_synth_torch.py) ---------------------------------------------------
+# The full-depth fixture (tests/golden/full_c1.npz) needs the 3.8 G parameters of eilev-blip2-opt-2.7b by recipe on the GPU box: numpy
+# takes ~6 minutes for them (page faults on GB-sized temporaries), the device a few seconds.  Integer arithmetic wraps identically in
+# int64; the float steps are single correctly-rounded IEEE operations in the same order and types as the numpy code above.
+def _to_i64(v: int) -> int:
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def det_normal_torch(name: str, shape, seed: int = 0, device="cpu"):
+    import torch
+
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    lsr = lambda z, k: (z >> k) & ((1 << (64 - k)) - 1)
+    base = (fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    z = torch.arange(n, dtype=torch.int64, device=device) + _to_i64(base) + _to_i64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * _to_i64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _to_i64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    s = (z & 0xFFFF) + (lsr(z, 16) & 0xFFFF) + (lsr(z, 32) & 0xFFFF) + (lsr(z, 48) & 0xFFFF)
+    x = (s - 2 * 65535).to(torch.float64) / float(np.sqrt(4.0 * (65536.0**2 - 1.0) / 12.0))
+    return x.to(torch.float32).reshape(tuple(int(s_) for s_ in shape))
+
+
+def round_bf16_torch(x):
+    import torch
+
+    u = x.contiguous().view(torch.int32)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) & -65536
+    return r.view(torch.float32)
+
+
+def synth_param_torch(name: str, shape, mode: str = "fanin", seed: int = 0, device="cpu"):
+    """`synth_param` evaluated on a torch device: float32 tensor holding bf16-exact values, bit-identical to the numpy version."""
+    import torch
+
+    shape = tuple(int(s_) for s_ in shape)
+    n = det_normal_torch(name, shape, seed, device)
+    low = name.lower()
+    if "layernorm" in low or "layer_norm" in low:
+        out = 1.0 + 0.1 * n if name.endswith("weight") else 0.05 * n
+    elif name.endswith(".bias"):
+        out = 0.02 * n
+    elif len(shape) >= 2 and name.endswith("weight") and "embed" not in low:
+        fan_in = int(np.prod(shape[1:]))
+        if mode in ("fanin", "varied"):
+            std = 1.0 / np.sqrt(fan_in)            # np.float64: the numpy product is evaluated in float64 ...
+            if low.endswith("attention.q.weight"):
+                std = std * 0.125
+            out = (n.to(torch.float64) * float(std)).to(torch.float32)   # ... and cast back: same here
+        else:
+            out = 0.02 * n                          # python float: float32 arithmetic in both
+    else:
+        std = 0.02 if mode == "hf" else (0.06 if mode == "varied" and "embed_tokens" in low else 0.5)
+        out = std * n
+    return round_bf16_torch(out.to(torch.float32))
