@@ -1822,6 +1822,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
     }
 }
 
+// (round 4, measured and removed: gemm_skinny5_kernel — one 16-row weight block x 5 waves x 2 K tiles per workgroup, every weight tile and
+// activation fragment requested up front, no ring: 24.2 us per q|k|v / fc1 / fc2 launch against 19.8 us for the kernel above, 5.53 vs 5.40
+// ms/token at batch 32 (profiles/r04_skinny5_rejected_*).  The ring depth was not the limit: each workgroup re-reads the 160 KB of
+// activations from L2, and with one block per workgroup that is 2-3x the weight bytes entering every CU.)
 template <int MB, bool PRE>
 __global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;

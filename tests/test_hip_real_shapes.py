@@ -181,3 +181,45 @@ def test_real_width_t5_path(golden_dir):
     assert rel_rms(lg, g["fp32_logits_cols"]) <= 1.2 * rel_rms(g["bf16_logits_cols"], g["fp32_logits_cols"]) + 2e-3
     ids = eng.t5_greedy(emb, t("attention_mask"), meta["new_tokens"], eos_id=-1).cpu().numpy()
     assert any(np.array_equal(ids, g[k]) for k in ("fp32_greedy_free", "bf16_greedy_free")), (ids, g["fp32_greedy_free"], g["bf16_greedy_free"])
+
+
+@pytest.mark.parametrize("B", [20, 32])
+def test_batch_decode_step_at_real_widths_vs_oracle(B):
+    """The batch-17..32 decode block at OPT-2.7B widths (round 4: gemm_skinny5_kernel — q|k|v and fc1 without a K split, out_proj and fc2
+    with 2 / 4 K splits through the partial buffer and reduce_ln_kernel; K = 2560 / 10240) against the fp32 ORACLE: after a prefill of L
+    positions, one decode step on token t must give the logits a prefill over the L + 1 positions gives for its last row (left padding in
+    two rows; ragged M = 20 exercises the row guards)."""
+    import ctypes as C
+
+    cfg, oracle, eng = models("real_1l")
+    d = eng.dims
+    rng = np.random.default_rng(5)
+    L = 24
+    ids = rng.integers(4, 50000, size=(B, L + 1)).astype(np.int64)
+    am = np.ones((B, L + 1), np.int64)
+    am[1, :5] = 0
+    am[B - 1, :9] = 0
+    emb_o = oracle.embed_scatter(ids, None, None)
+    ref, _, _ = oracle.prefill(emb_o, am, all_logits=False)
+    t = lambda a: torch.from_numpy(a).cuda()
+    emb = eng.embed_scatter(t(ids), None, None)
+    cap = L + 4
+    am_l = t(am[:, :L]).to(torch.int32).contiguous()
+    kv = eng.new_kv_cache(B, cap)
+    eng.prefill(emb[:, :L].contiguous(), am_l, kv_cache=kv, kv_capacity=cap)
+    state = torch.tensor([1, B], dtype=torch.int32, device="cuda")
+    tokens = t(ids[:, L]).contiguous()
+    finished = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    n_valid = am_l.sum(dim=1).to(torch.int32).contiguous()
+    out = torch.zeros((B, 4), dtype=torch.int64, device="cuda")
+    logits = torch.empty((B, d.vocab), dtype=torch.float32, device="cuda")
+    ws = torch.empty(int(eng.lib.eilev_opt_workspace_bytes(C.byref(d), B, 1)), dtype=torch.uint8, device="cuda")
+    P = lambda x: C.c_void_p(x.data_ptr())
+    rc = eng.lib.eilev_opt_decode_step(C.byref(d), C.byref(eng.pack.opt), P(tokens), P(state), P(am_l), P(n_valid), B, L, P(kv), cap, P(logits), P(finished),
+                                       -1, 1, P(out), 4, P(ws), ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = host(logits)
+    for b in range(B):
+        assert rel_rms(got[b], ref[b]) <= 1e-2, (b, rel_rms(got[b], ref[b]))
+    assert np.array_equal(out[:, 1].cpu().numpy(), got.argmax(-1))
