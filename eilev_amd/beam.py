@@ -26,12 +26,16 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
                 eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None,
-                min_new_tokens: int = 0) -> torch.Tensor:
+                min_new_tokens: int = 0, processors=None, stopping=None, prefix: torch.Tensor | None = None) -> torch.Tensor:
     """``first_logits``: (batch, vocab) fp32 from the prefill.  Returns int64 (batch * num_return_sequences, n_generated).
 
     ``sampler`` (``generate(num_beams > 1, do_sample=True)``, hf `_get_top_k_continuations`): the 2K continuations of a step are DRAWN
     without replacement from softmax(warped log-probabilities + beam scores) over all beams x vocabulary instead of being the top 2K,
-    and keep their draw order (HF lets only the first K drawn finish); everything else is the same bookkeeping."""
+    and keep their draw order (HF lets only the first K drawn finish); everything else is the same bookkeeping.
+
+    ``processors`` (`LogitsProcessorList` / callable): applied to every step's LOG-PROBABILITIES with each beam's own ids, as hf `_beam_search`
+    does (`repetition_penalty`, `no_repeat_ngram_size`, user processors); ``stopping``: the search ends when it flags every row;
+    ``prefix`` (batch, P): ids in front of the generated ones (see sampling.sample_loop)."""
     dev = first_logits.device
     B, nb, T = batch, num_beams, max_new_tokens
     V = first_logits.shape[-1]
@@ -57,6 +61,16 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     cur = 0
     while True:
         logp = torch.log_softmax(logits, dim=-1)
+        if processors is not None or stopping is not None:
+            seen = run_seq[:, :, :cur].reshape(B * nb, cur)
+            if prefix is not None:
+                seen = torch.cat((prefix.to(dev, torch.int64).repeat_interleave(nb, dim=0), seen), dim=1)
+            if stopping is not None and cur > 0:
+                done_all = stopping(seen, logp)
+                if bool(done_all.all() if torch.is_tensor(done_all) else done_all):
+                    break
+            if processors is not None:
+                logp = processors(seen, logp)
         if eos_t is not None and cur < int(min_new_tokens):  # MinNewTokensLengthLogitsProcessor acts on the log-probabilities here
             logp = logp.index_fill(-1, eos_t, float("-inf"))
         if sampler is not None:

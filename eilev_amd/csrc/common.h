@@ -212,6 +212,9 @@ int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, con
 bool gemv1_ok(int N, int K, int pro);
 int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid, void *out,
                  int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s);
+bool gemvm_ok(int M, int N, int K, int pro);  // 2 <= M <= 8 rows with the same geometry, rows staged in LDS (round 4)
+int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid,
+                 int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N, int K, int epi, float scale, int scale_cols, hipStream_t s);
 // misc.hip: single-query attention at small batch, one workgroup per (row, head), merged output (round 4)
 bool attn_decode1_ok(int batch, int cap, int hd);
 int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state, int batch, int seq_len,

@@ -238,6 +238,19 @@ int launch_rows_p(const GemvArgs &a, int grid, size_t smem, hipStream_t s) {
 }
 
 
+// lane reduction as DPP adds (VALU) instead of ds_bpermute round trips; the same tree in gemv1_kernel and gemvm_kernel, so a row's bits do
+// not depend on how many rows share the launch
+__device__ __forceinline__ float dpp_wave_sum(float v) {  // total of the 64 lanes, returned wave-uniform
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror: 16-lane sums
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+
 // ---- M = 1 (round 4): activations in REGISTERS, no LDS, no barrier, a register ring of weight sub-blocks ----------------------------------
 // Per-kernel durations of the batch-1 step (profiles/r04_decode_b1_kernel_stats.md): q|k|v 13 us for 39 MB, out_proj 11.3 us for 13 MB,
 // fc1 15.4 / fc2 13.3 us for 52 MB each — 3-4 TB/s inside a kernel, ~2.2 TB/s over the block — where a launch-per-op batch-1 layer of
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(320) void gemv1_kernel(const GemvArgs a) {
     const unsigned *bias32 = reinterpret_cast<const unsigned *>(a.bias), *res32 = reinterpret_cast<const unsigned *>(a.resid);
     auto finish_row = [&](int r) {  // r wave-uniform
         const int n = r0 + r;
-        float v = wave_sum(acc);
+        float v = dpp_wave_sum(acc);
         acc = 0.0f;
         if (bias32) {  // wave-uniform address: one scalar load, no entry in the vector-memory queue
             const unsigned w2 = bias32[n >> 1];
@@ -398,6 +411,188 @@ int launch_gemv1_c(const GemvArgs &a, int grid, hipStream_t s) {
     return EILEV_OK;
 }
 
+
+// ---- 2 <= M <= 8 rows with the geometry of gemv1_kernel (round 4) -----------------------------------------------------------------------
+// Beam search (5 beams of one sample: the sample script's default), two / four samples per GPU of a strong-scaled step.  The rows cannot
+// live in registers (M x K / 64 values per lane), so they are staged ONCE per workgroup in LDS as bf16 — behind the weight ring's first
+// RB sub-blocks, which are requested before the staging starts — and read back per dot product (M ds_read_b128 per 1 KiB of weights: LDS
+// bandwidth is not the limit at these M).  Everything else is gemv1_kernel: one 320-thread workgroup per CU, contiguous equal row ranges
+// per wave, all of a short wave's weights requested up front, branch-free steady loop for long waves (the lm_head), bias / residual
+// through the scalar cache, one store per row of x at the end.  The lane reduction is DPP adds (VALU) instead of ds_bpermute round trips:
+// with M accumulators per output row the shuffles were the longest chain in the kernel.
+template <int MR, int NCH, int PRO, int SB, int RB, bool LONG>
+__global__ __launch_bounds__(320) void gemvm_kernel(const GemvArgs a) {
+    constexpr int IPR = NCH / SB, K = NCH * 512;
+    static_assert(NCH % SB == 0 && RB % IPR == 0, "ring / row geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    bf16 *xs = reinterpret_cast<bf16 *>(smem_m);  // [MR][K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = blockIdx.x * 5 + wid;
+    const int r0 = wave * a.rows_per_wave + (wave < a.KB ? wave : a.KB), r1 = r0 + a.rows_per_wave + (wave < a.KB ? 1 : 0);
+    const int total = (r1 - r0) * IPR;
+    u32x4_t wv[RB][SB];
+    const bf16 *wbase = a.W + (int64_t)r0 * K + lane * 8;
+    auto load_item = [&](int it, auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+        const bf16 *wrow = wbase + (int64_t)it * (SB * 512);
+#pragma unroll
+        for (int c = 0; c < SB; ++c) wv[B][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wrow + c * 512));
+    };
+    auto stage_x = [&]() {
+        if constexpr (PRO == PRO_LN) {
+            for (int m = wid; m < MR; m += 5) {  // one wave per row, the row in registers (bf16), mean then centred second moment
+                const bf16 *row = a.x + (int64_t)m * a.ldx;
+                bf16x8 xb[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) xb[c] = *reinterpret_cast<const bf16x8 *>(row + c * 512 + lane * 8);
+                float s1 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    float f[8];
+                    unpack8(xb[c], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1 += f[e];
+                }
+                const float mean = wave_sum(s1) / (float)K;
+                float s2 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    float f[8];
+                    unpack8(xb[c], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s2 = fmaf(f[e] - mean, f[e] - mean, s2);
+                }
+                const float rstd = rsqrtf(wave_sum(s2) / (float)K + a.eps);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    float f[8], gm[8], bt[8];
+                    unpack8(xb[c], f);
+                    unpack8(*reinterpret_cast<const bf16x8 *>(a.gamma + c * 512 + lane * 8), gm);
+                    unpack8(*reinterpret_cast<const bf16x8 *>(a.beta + c * 512 + lane * 8), bt);
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)((f[e] - mean) * rstd * gm[e] + bt[e]);
+                    *reinterpret_cast<bf16x8 *>(xs + m * K + c * 512 + lane * 8) = v;
+                }
+            }
+        } else {
+            for (int idx = tid * 8; idx < MR * K; idx += 320 * 8) {
+                const int m = idx / K, k = idx - m * K;
+                *reinterpret_cast<bf16x8 *>(xs + idx) = *reinterpret_cast<const bf16x8 *>(a.x + (int64_t)m * a.ldx + k);
+            }
+        }
+        __syncthreads();
+    };
+    float acc[MR], mine[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = mine[m] = 0.0f;
+    const unsigned *bias32 = reinterpret_cast<const unsigned *>(a.bias);
+    auto bf_at = [](const unsigned *p32, int64_t i) {  // element i of a bf16 array through a (wave-uniform) 4-byte scalar load
+        const unsigned w2 = p32[i >> 1];
+        return __builtin_bit_cast(float, (i & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+    };
+    auto finish_row = [&](int r) {
+        const int n = r0 + r;
+        const float bv = bias32 ? bf_at(bias32, n) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float v = dpp_wave_sum(acc[m]) + bv;
+            acc[m] = 0.0f;
+            if (n < a.scale_cols) v *= a.scale;
+            if (a.epi == 2) v = fmaxf(v, 0.0f);
+            if (a.resid) v += bf_at(reinterpret_cast<const unsigned *>(a.resid), (int64_t)m * a.ldr + n);
+            if (lane == (r & 63)) mine[m] = v;
+        }
+        if ((r & 63) == 63 || r + 1 == r1 - r0) {
+            const int rr = (r & ~63) + lane;
+            if (rr <= r) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (a.out_f32) reinterpret_cast<float *>(a.out)[(int64_t)m * a.ldo + r0 + rr] = mine[m];
+                    else reinterpret_cast<bf16 *>(a.out)[(int64_t)m * a.ldo + r0 + rr] = (bf16)mine[m];
+                }
+            }
+        }
+    };
+    auto consume = [&](int it, auto j_c) {
+        constexpr int J = decltype(j_c)::value, SBI = J % IPR;
+        const bf16 *xb = xs + SBI * (SB * 512) + lane * 8;
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            __builtin_amdgcn_sched_barrier(0);  // one chunk's LDS reads at a time: left alone, hipcc hoists the reads of every slot and spills
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[m] = dot8(wv[J][c], *reinterpret_cast<const u32x4_t *>(xb + m * K + c * 512), acc[m]);
+        }
+        if constexpr (SBI == IPR - 1) finish_row(it / IPR);
+    };
+    if constexpr (LONG) {  // (host: every wave has at least 2 RB items)
+        static_for_i<RB>([&](auto j_c) { load_item(decltype(j_c)::value, j_c); });
+        stage_x();
+        int base = 0;
+        for (; base + 2 * RB <= total; base += RB)
+            static_for_i<RB>([&](auto j_c) {
+                consume(base + decltype(j_c)::value, j_c);
+                load_item(base + decltype(j_c)::value + RB, j_c);
+            });
+        static_for_i<RB>([&](auto j_c) {
+            consume(base + decltype(j_c)::value, j_c);
+            if (base + decltype(j_c)::value + RB < total) load_item(base + decltype(j_c)::value + RB, j_c);
+        });
+        base += RB;
+        static_for_i<RB>([&](auto j_c) {
+            if (base + decltype(j_c)::value < total) consume(base + decltype(j_c)::value, j_c);
+        });
+    } else {
+        static_for_i<RB>([&](auto j_c) {
+            if (decltype(j_c)::value < total) load_item(decltype(j_c)::value, j_c);
+        });
+        stage_x();
+        static_for_i<RB>([&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            if (J < total) {
+                consume(J, j_c);
+                if (J + RB < total) load_item(J + RB, j_c);
+            }
+        });
+        static_for_i<RB>([&](auto j_c) {
+            if (decltype(j_c)::value + RB < total) consume(decltype(j_c)::value + RB, j_c);
+        });
+    }
+}
+
+template <int MR, int NCH, int PRO>
+int launch_gemvm_c(const GemvArgs &a, int grid, hipStream_t s) {
+    constexpr int SB = 5, IPR = NCH / SB;
+    // ring slots: 8 (K = 2560: every byte of a wave's block rows up front) where the registers allow; with 3+ rows hipcc hoists the LDS reads
+    // of all slots and spills (MR = 5, 8 slots: 862 VGPRs spilled), so 4 there
+    constexpr int RB = (PRO == PRO_LN || MR >= 3) ? 4 : 8;
+    const size_t smem = (size_t)MR * NCH * 512 * sizeof(bf16);
+    static bool attr = false;
+    if (!attr) {
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemvm_kernel<MR, NCH, PRO, SB, RB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemvm_kernel<MR, NCH, PRO, SB, RB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    // one code path per instance (both in one kernel doubled the register pressure): long waves only when EVERY wave has 2 RB items
+    if (a.rows_per_wave * IPR >= 2 * RB) hipLaunchKernelGGL((gemvm_kernel<MR, NCH, PRO, SB, RB, true>), dim3(grid), dim3(320), smem, s, a);
+    else hipLaunchKernelGGL((gemvm_kernel<MR, NCH, PRO, SB, RB, false>), dim3(grid), dim3(320), smem, s, a);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+template <int NCH, int PRO>
+int launch_gemvm_m(const GemvArgs &a, int grid, hipStream_t s) {
+    switch (a.M) {
+        case 2: return launch_gemvm_c<2, NCH, PRO>(a, grid, s);
+        case 3: return launch_gemvm_c<3, NCH, PRO>(a, grid, s);
+        case 4: return launch_gemvm_c<4, NCH, PRO>(a, grid, s);
+        case 5: return launch_gemvm_c<5, NCH, PRO>(a, grid, s);
+        case 6: return launch_gemvm_c<6, NCH, PRO>(a, grid, s);
+        case 7: return launch_gemvm_c<7, NCH, PRO>(a, grid, s);
+        default: return launch_gemvm_c<8, NCH, PRO>(a, grid, s);
+    }
+}
+
 }  // namespace
 
 // M rows of K bf16 must fit the LDS staging (150 KB): M = 8 with K = 10240 (160 KB) does not — those shapes keep the MFMA kernels
@@ -468,4 +663,34 @@ int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, fl
         case 8: return launch_gemv1_c<8, PRO_X>(a, grid, s);
         default: return launch_gemv1_c<20, PRO_X>(a, grid, s);
     }
+}
+
+
+// 2 <= M <= 8 rows, K = 2560 (plain or LayerNorm): gemvm_kernel
+bool gemvm_ok(int M, int N, int K, int pro) {
+    const int nch = K >> 9;
+    if (M < 2 || M > 8 || K % 512 || N < 1 || (int64_t)M * K * 2 > 150 * 1024) return false;
+    return nch == 5 && (pro == PRO_X || pro == PRO_LN);  // (K = 10240: every variant tried spills hundreds of VGPRs — fc2 keeps gemv_rows_kernel)
+}
+int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid,
+                 int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N, int K, int epi, float scale, int scale_cols, hipStream_t s) {
+    if (!gemvm_ok(M, N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || (ldx & 7) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
+    if ((bias && ((uintptr_t)bias & 3)) || (resid && (((uintptr_t)resid & 3) || (ldr & 1))) || (pro == PRO_LN && (!gamma || !beta))) return EILEV_E_BADARG;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        EILEV_HIP_CHECK(hipGetDevice(&dev));
+        EILEV_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    GemvArgs a = {};
+    a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K; a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;
+    int grid = n_cu;
+    if ((int64_t)grid * 5 > N) grid = (N + 4) / 5;
+    a.rows_per_wave = N / (grid * 5);
+    a.KB = N % (grid * 5);
+    if (pro == PRO_LN) return launch_gemvm_m<5, PRO_LN>(a, grid, s);
+    return launch_gemvm_m<5, PRO_X>(a, grid, s);
 }

@@ -653,6 +653,47 @@ bool opt_rows1_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M, i
     return gemv1_ok(3 * D, D, 1) && gemv1_ok(D, D, 0) && gemv1_ok(d->t_ffn, D, 1) && gemv1_ok(D, d->t_ffn, 0) && gemv1_ok(d->vocab, D, 1) &&
            attn_decode1_ok(1, (int)cap, D / d->t_heads);
 }
+// 2..8 rows (beam search, a few samples per GPU): gemvm_kernel for every K = t_hidden linear, the one-pass attention where it applies
+bool opt_rowsm_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M) {
+    // measured (OPT-2.7B, L = 960, ms per token): 2 rows 2.06 (row-dot kernels of round 3: 2.67), 4 rows 2.51, 5 rows 3.20 against 2.87 for the MFMA
+    // weight-streaming kernels, whose cost is flat up to 16 rows: every extra row costs this kernel a pass of LDS reads + dot products
+    if (M < 2 || M > 4 || g_decode_rows == 3 || !g_decode_rows || w->layers_w8) return false;
+    const int D = d->t_hidden;
+    if (!gemvm_ok((int)M, 3 * D, D, 1) || !gemvm_ok((int)M, D, D, 0) || (D / d->t_heads) % 8 || (d->vocab & 1)) return false;
+    for (int l = 0; l < d->t_layers; ++l) {  // q | k | v must be ONE [3 D, D] matrix with one bias vector (the engine packs them so)
+        const EilevOptLayer *L = &w->layers[l];
+        const bf16 *qw = (const bf16 *)L->q_w, *qb = (const bf16 *)L->q_b;
+        if ((const bf16 *)L->k_w != qw + (size_t)D * D || (const bf16 *)L->v_w != qw + 2 * (size_t)D * D || !qb || (const bf16 *)L->k_b != qb + D ||
+            (const bf16 *)L->v_b != qb + 2 * D)
+            return false;
+    }
+    return true;
+}
+// block l without its attention: LayerNorm + q|k|v (before), out_proj + residual, LayerNorm + fc1 + ReLU, fc2 + residual (after)
+int opt_rowsm_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
+    const int D = d->t_hidden;
+    return launch_gemvm(1, b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, d->t_eps, (const bf16 *)L->q_w, (const bf16 *)L->q_b, nullptr, 0, b.qkv, 3 * D, 0, (int)M,
+                        3 * D, D, 0, 1.0f / sqrtf((float)(D / d->t_heads)), D, s);
+}
+int opt_rowsm_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+    const EilevOptLayer *L = &w->layers[l];
+    const int D = d->t_hidden, Ft = d->t_ffn;
+    RC(launch_gemvm(0, b.att, D, nullptr, nullptr, 0.f, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, D, b.h, D, 0, (int)M, D, D, 0, 1.0f, 0, s));
+    RC(launch_gemvm(1, b.h, D, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, d->t_eps, (const bf16 *)L->fc1_w, (const bf16 *)L->fc1_b, nullptr, 0, b.ffn, Ft, 0, (int)M, Ft, D,
+                    2, 1.0f, 0, s));
+    if (gemv_rows_ok((int)M, D, Ft))  // K = t_ffn: the LDS-staged row-dot kernel (gemvm_kernel spills at K = 10240)
+        return launch_gemv_rows(0, b.ffn, Ft, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, (const bf16 *)L->fc2_w, (const bf16 *)L->fc2_b, b.h, D, b.h, D, 0, (int)M, D, Ft, 0, 1.0f,
+                                0, s);
+    GemmArgs g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    return launch_gemm(g, 5, s);
+}
+int opt_rowsm_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b, int64_t M, float *logits, hipStream_t s) {
+    const int D = d->t_hidden;
+    return launch_gemvm(1, b.h, D, (const bf16 *)w->final_ln_w, (const bf16 *)w->final_ln_b, d->t_eps, (const bf16 *)w->embed_tokens, nullptr, nullptr, 0, logits, d->vocab, 1,
+                        (int)M, d->vocab, D, 0, 1.0f, 0, s);
+}
 // self_attn_layer_norm + q|k|v of block l from b.h into b.qkv (q pre-scaled)
 int opt_rows_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
     const EilevOptLayer *L = &w->layers[l];
@@ -840,6 +881,19 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
                         D, 0, 1.0f, 0, s));
         return launch_select(logits, 1, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
     }
+    if (opt_rowsm_usable(d, w, batch)) {  // 2..8 rows (round 4)
+        const bool one_pass = attn_decode1_ok((int)batch, (int)kv_capacity, hd);
+        for (int l = 0; l < d->t_layers; ++l) {
+            bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
+            RC(opt_rowsm_qkv(d, w, l, b, batch, s));
+            if (one_pass) RC(launch_attn_decode1(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd, s));
+            else RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
+                                       b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
+            RC(opt_rowsm_tail(d, w, l, b, batch, s));
+        }
+        RC(opt_rowsm_head(d, w, b, batch, logits, s));
+        return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
+    }
     if (opt_rows_usable(d, w, batch)) {  // M <= 8: row-dot kernels with LayerNorm / merge in their prologues (gemv.hip): 5 launches + attention per block
         float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
         const int nsplit = (int)((kv_capacity + kDecodeKeys - 1) / kDecodeKeys);
@@ -908,6 +962,21 @@ extern "C" int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeig
     RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab, d->max_pos + 1, b.h,
                            (int)rows, D, s));
     const size_t per_p = (size_t)2 * samples * H * seq_len * hd, per_g = (size_t)2 * rows * H * gen_capacity * hd;
+    if (opt_rowsm_usable(d, w, rows)) {  // 2..8 rows (the sample script: 5 beams of one sample), round 4: gemvm_kernel around the beam attention
+        for (int l = 0; l < d->t_layers; ++l) {
+            const bf16 *kc = (const bf16 *)kv_prompt + l * per_p, *vc = kc + per_p / 2;
+            bf16 *kg = (bf16 *)kv_gen + l * per_g, *vg = kg + per_g / 2;
+            RC(opt_rowsm_qkv(d, w, l, b, rows, s));
+            RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)rows, (int)seq_len, (int)seq_len, H, hd,
+                                  b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1, kg, vg, ancestors, (int)beams,
+                                  (int)gen_capacity));
+            RC(opt_rowsm_tail(d, w, l, b, rows, s));
+        }
+        RC(opt_rowsm_head(d, w, b, rows, logits, s));
+        bump_step_kernel<<<1, 64, 0, s>>>(state);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     if (opt_rows_usable(d, w, rows)) {  // <= 8 rows (the sample script: 5 beams of one sample): the small-batch block of gemv.hip
         float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
         const int nsplit = (int)((seq_len + gen_capacity + kDecodeKeys - 1) / kDecodeKeys);
@@ -1033,6 +1102,9 @@ extern "C" int eilev_linear_rows(const void *x, const void *ln_gamma, const void
     if (m == 1 && g_decode_rows != 3 && gemv1_ok((int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3))  // round 4: one row
         return launch_gemv1(ln_gamma ? 1 : 0, (const bf16 *)x, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, (const bf16 *)w, (const bf16 *)bias,
                             (const bf16 *)residual, c, out_f32, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
+    if (m >= 2 && g_decode_rows != 3 && gemvm_ok((int)m, (int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3) && !(n & 1))
+        return launch_gemvm(ln_gamma ? 1 : 0, (const bf16 *)x, k, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, (const bf16 *)w, (const bf16 *)bias,
+                            (const bf16 *)residual, n, c, n, out_f32, (int)m, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
     return launch_gemv_rows(ln_gamma ? 1 : 0, (const bf16 *)x, k, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, nullptr, 0, 0, 0, (const bf16 *)w,
                             (const bf16 *)bias, (const bf16 *)residual, n, c, n, out_f32, (int)m, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
 }

@@ -520,9 +520,10 @@ class HipEngine:
 
 
     def beam_decode(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=-1, pad_id=1,
-                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, use_graph=True, trace=None):
+                    early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, use_graph=True, trace=None, rules=None):
         """Beam search on the HIP path [sample default: num_beams=5, length_penalty=-1; hf generation/utils.py:3208+].
         ``trace``: a list that receives (tokens fed, parent rows, fp32 logits) of every step (tests replay the hypotheses teacher-forced).
+        ``rules``: dict(processors=, stopping=, prefix=) for the host loops (eilev_amd/sampling.py, beam.py): hf logits processors / stopping criteria.
 
         The prompt is prefilled ONCE per sample; no cache row is ever copied (see below); one HIP decode step on all rows per
         generated token, captured into a hipGraph and replayed."""
@@ -539,8 +540,10 @@ class HipEngine:
             per = max(1, 32 // num_beams)
             if trace is not None:
                 raise ValueError("trace: at most 32 decode rows")
+            if rules and rules.get("prefix") is not None:
+                raise NotImplementedError("prefix ids with more than 32 decode rows")
             parts = [self.beam_decode(inputs_embeds[i:i + per], attention_mask[i:i + per], max_new_tokens, num_beams, length_penalty, eos_id,
-                                      pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens, use_graph) for i in range(0, B, per)]
+                                      pad_id, early_stopping, num_return_sequences, sampler, min_new_tokens, use_graph, None, rules) for i in range(0, B, per)]
             n = max(p.shape[1] for p in parts)
             return torch.cat([torch.nn.functional.pad(p, (0, n - p.shape[1]), value=int(pad_id)) for p in parts], dim=0)
         am = attention_mask.to(self.device, torch.int32).contiguous()
@@ -601,9 +604,9 @@ class HipEngine:
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step
             from .sampling import sample_loop
 
-            return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler)
+            return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler, **(rules or {}))
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
-                           num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens)
+                           num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens, **(rules or {}))
 
     def sample_decode(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=-1, pad_id=1, temperature=1.0, top_k=50, top_p=1.0,
                       generator=None):
@@ -717,7 +720,7 @@ class HipEngine:
         return torch.cat((start, ids), dim=1)
 
     def t5_beam(self, inputs_embeds, attention_mask, max_new_tokens, num_beams, length_penalty=1.0, eos_id=1, pad_id=0, start_id=0,
-                early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0):
+                early_stopping=False, num_return_sequences=1, sampler=None, min_new_tokens=0, rules=None):
         """Beam search for the encoder-decoder LM [sample default num_beams=5, length_penalty=-1; hf generation/utils.py:3208+]:
         the encoder runs once per sample, its cross K/V are replicated to the beams, every step reorders the self-attention
         cache rows by the surviving beams' parents and runs one decoder step on all rows."""
@@ -752,10 +755,10 @@ class HipEngine:
         if sampler is not None and num_beams == 1:
             from .sampling import sample_loop
 
-            ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler)
+            ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler, **(rules or {}))
         else:
             ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
-                              early_stopping, num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens)
+                              early_stopping, num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens, **(rules or {}))
         head = torch.full((ids.shape[0], 1), int(start_id), dtype=torch.int64, device=self.device)
         return torch.cat((head, ids), dim=1)
 

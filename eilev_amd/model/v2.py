@@ -492,6 +492,28 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             min_new = 0
         for k in ("use_cache", "return_dict_in_generate", "output_scores"):
             kw.pop(k, None)
+        # hf hands every other kwarg to GenerationMixin (ref:eilev/model/v2.py:318-322).  Logits processors and stopping criteria run in the
+        # host loops over the same HIP decode step, with transformers' own processor classes (exactly hf's arithmetic and order).
+        from transformers import (LogitsProcessorList, MaxTimeCriteria, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
+                                  StoppingCriteriaList)
+
+        procs = LogitsProcessorList()
+        rp = kw.pop("repetition_penalty", None)
+        if rp is not None and float(rp) != 1.0:
+            procs.append(RepetitionPenaltyLogitsProcessor(penalty=float(rp)))
+        ngram = kw.pop("no_repeat_ngram_size", None)
+        if ngram:
+            procs.append(NoRepeatNGramLogitsProcessor(int(ngram)))
+        user_procs = kw.pop("logits_processor", None)
+        if user_procs:
+            procs.extend(user_procs)
+        crit = StoppingCriteriaList(kw.pop("stopping_criteria", None) or [])
+        max_time = kw.pop("max_time", None)
+        if max_time is not None:
+            crit.append(MaxTimeCriteria(max_time=float(max_time)))
+        rules = None
+        if len(procs) or len(crit):
+            rules = dict(processors=procs if len(procs) else None, stopping=crit if len(crit) else None)
         if kw:
             raise NotImplementedError(f"unsupported generate() arguments on the HIP path: {sorted(kw)}")
         if num_beams == 1 and not do_sample and int(num_return) != 1:
@@ -508,28 +530,30 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         # the captured device step knows ONE eos id and no minimum length; several ids or 0 < min_new_tokens < max_new_tokens run the
         # same HIP decode step with the stopping rule applied by the host loop (eilev_amd/sampling.py, beam.py)
         eos1 = eos_ids[0] if eos_ids else -1
-        host_rules = len(eos_ids) > 1 or min_new > 0
+        host_rules = len(eos_ids) > 1 or min_new > 0 or rules is not None
         eng = self.engine()
         if self._is_t5:
             t = self.config.text_config
             start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id
+            if rules is not None:  # hf's processors see the decoder ids, which begin with the start token
+                rules["prefix"] = torch.full((emb.shape[0], 1), int(start), dtype=torch.int64, device=emb.device)
             if num_beams > 1:
                 return eng.t5_beam(emb, attention_mask, int(max_new), num_beams, float(length_penalty), eos_id=eos_ids if host_rules else eos1,
                                    pad_id=int(pad), start_id=int(start), early_stopping=early_stopping,
-                                   num_return_sequences=int(num_return), sampler=sampler, min_new_tokens=min_new)
+                                   num_return_sequences=int(num_return), sampler=sampler, min_new_tokens=min_new, rules=rules)
             if sampler is not None or host_rules:
                 rule = dict(sampler) if sampler is not None else dict(greedy=True)
                 return eng.t5_beam(emb, attention_mask, int(max_new), 1, eos_id=eos_ids if host_rules else eos1, pad_id=int(pad),
-                                   start_id=int(start), sampler=dict(rule, min_new_tokens=min_new))
+                                   start_id=int(start), sampler=dict(rule, min_new_tokens=min_new), rules=rules)
             return eng.t5_greedy(emb, attention_mask, int(max_new), eos_id=int(eos1), pad_id=int(pad), start_id=int(start))
         if num_beams > 1:
             return eng.beam_decode(emb, attention_mask, int(max_new), num_beams, float(length_penalty), eos_id=eos_ids if host_rules else eos1,
                                    pad_id=int(pad), early_stopping=early_stopping, num_return_sequences=int(num_return), sampler=sampler,
-                                   min_new_tokens=min_new)
+                                   min_new_tokens=min_new, rules=rules)
         if sampler is not None or host_rules:
             rule = dict(sampler) if sampler is not None else dict(greedy=True)
             return eng.beam_decode(emb, attention_mask, int(max_new), 1, eos_id=eos_ids if host_rules else eos1, pad_id=int(pad),
-                                   sampler=dict(rule, min_new_tokens=min_new))
+                                   sampler=dict(rule, min_new_tokens=min_new), rules=rules)
         return eng.greedy_decode(emb, attention_mask, int(max_new), eos_id=int(eos1), pad_id=int(pad))
 
     @torch.no_grad()

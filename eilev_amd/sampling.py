@@ -45,13 +45,19 @@ def eos_list(eos_id) -> list:
 
 def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id=-1, pad_id: int = 0, temperature: float = 1.0,
                 top_k: int = 50, top_p: float = 1.0, generator: torch.Generator | None = None, min_new_tokens: int = 0,
-                greedy: bool = False) -> torch.Tensor:
+                greedy: bool = False, processors=None, stopping=None, prefix: torch.Tensor | None = None) -> torch.Tensor:
     """`step(next_tokens (R,), row_src (R,)) -> logits (R, vocab)` is the decode step of engine.beam_decode / t5_beam (row_src is the
     identity here).  Returns (R, n) new tokens, n <= max_new_tokens (the loop stops once every row has produced EOS, as HF does).
 
     ``eos_id`` may be a list (any of the ids finishes a row); ``min_new_tokens`` is HF's MinNewTokensLengthLogitsProcessor (the EOS
     logits are -inf while fewer tokens than that have been generated; applied before the warpers); ``greedy=True`` takes the argmax
-    instead of drawing (the host-side form of greedy search used for the stopping rules the captured device step does not cover)."""
+    instead of drawing (the host-side form of greedy search used for the stopping rules the captured device step does not cover).
+
+    ``processors``: a `transformers.LogitsProcessorList` (or any callable ``(input_ids, scores) -> scores``) applied to every step's scores
+    before the warpers, as hf `_sample` does — `repetition_penalty`, `no_repeat_ngram_size` and user `logits_processor`s arrive here;
+    ``stopping``: a `StoppingCriteriaList` / callable ``(input_ids, scores) -> bool per row`` (`stopping_criteria`, `max_time`), a row it
+    flags is finished like one that produced EOS.  ``prefix`` (R, P): the ids the processors see in front of the generated ones — none for
+    the OPT path (the reference drives the LM with inputs_embeds: hf then starts from an empty id tensor), the start token for T5."""
     R = first_logits.shape[0]
     dev = first_logits.device
     ident = torch.arange(R, device=dev)
@@ -60,7 +66,10 @@ def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id=-1
     eos_t = torch.tensor(eos, dtype=torch.int64, device=dev) if eos else None
     out = []
     logits = first_logits
+    prev = prefix.to(dev, torch.int64) if prefix is not None else torch.zeros((R, 0), dtype=torch.int64, device=dev)
     for t in range(max_new_tokens):
+        if processors is not None:
+            logits = processors(prev, logits.float())
         if eos_t is not None and t < int(min_new_tokens):
             logits = logits.float().index_fill(-1, eos_t, float("-inf"))
         if greedy:
@@ -70,10 +79,14 @@ def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id=-1
             nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, int(pad_id)))
         out.append(nxt)
+        prev = torch.cat((prev, nxt.view(R, 1)), dim=1)
         if eos_t is not None:
             unfinished = unfinished & ~torch.isin(nxt, eos_t)
-            if not bool(unfinished.any()):
-                break
+        if stopping is not None:
+            done = stopping(prev, logits)
+            unfinished = unfinished & ~(done.to(dev) if torch.is_tensor(done) else torch.full((R,), bool(done), device=dev))
+        if (eos_t is not None or stopping is not None) and not bool(unfinished.any()):
+            break
         if t + 1 < max_new_tokens:
             logits = step(nxt, ident)
     return torch.stack(out, dim=1)

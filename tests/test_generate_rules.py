@@ -75,3 +75,76 @@ def test_beam_host_rules_equal_transformers(tiny_opt, eos, min_new, nb, lp):
     hf = _hf(tiny_opt, prompt, max_new_tokens=9, do_sample=False, num_beams=nb, length_penalty=lp, eos_token_id=eos,
              min_new_tokens=min_new or None, early_stopping=False)
     _eq(ours, hf)
+
+
+# ---- round 4: logits processors and stopping criteria through the same host loops (generate(repetition_penalty=, no_repeat_ngram_size=,
+# logits_processor=, stopping_criteria=, max_time=) on the HIP path; hf's own processor classes, hf's order) ------------------------------
+class _BanEven:
+    """a user LogitsProcessor: even token ids above 9 are forbidden"""
+
+    def __call__(self, input_ids, scores):
+        scores = scores.clone()
+        scores[:, 10::2] = float("-inf")
+        return scores
+
+
+class _StopOnLength:
+    """a user StoppingCriteria: rows are done once they hold `n` ids"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __call__(self, input_ids, scores, **kw):
+        return torch.full((input_ids.shape[0],), input_ids.shape[1] >= self.n, dtype=torch.bool, device=input_ids.device)
+
+
+def _procs(rp=None, ngram=None, user=False):
+    from transformers import LogitsProcessorList, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor
+
+    lst = LogitsProcessorList()
+    if rp:
+        lst.append(RepetitionPenaltyLogitsProcessor(penalty=rp))
+    if ngram:
+        lst.append(NoRepeatNGramLogitsProcessor(ngram))
+    if user:
+        lst.append(_BanEven())
+    return lst
+
+
+@pytest.mark.parametrize("rp,ngram,user", [(1.3, None, False), (None, 2, False), (1.2, 3, True), (None, None, True)])
+def test_greedy_with_logits_processors_equals_transformers(tiny_opt, rp, ngram, user):
+    from transformers import LogitsProcessorList
+
+    torch.manual_seed(3)
+    prompt = torch.randint(4, 40, (3, 6))
+    step, first = _stepper(tiny_opt, prompt, 3)
+    ours = sample_loop(step, first, 12, eos_id=3, pad_id=1, greedy=True, processors=_procs(rp, ngram, user), prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=12, do_sample=False, num_beams=1, eos_token_id=3, repetition_penalty=rp, no_repeat_ngram_size=ngram,
+             logits_processor=LogitsProcessorList([_BanEven()]) if user else None)
+    _eq(ours, hf)
+    if user:
+        assert not ((ours >= 10) & (ours % 2 == 0)).any()
+
+
+@pytest.mark.parametrize("rp,ngram,nb,lp", [(1.3, None, 3, 1.0), (None, 2, 4, -1.0), (1.15, 3, 3, 1.0)])
+def test_beam_with_logits_processors_equals_transformers(tiny_opt, rp, ngram, nb, lp):
+    torch.manual_seed(4)
+    prompt = torch.randint(4, 40, (2, 6))
+    step, first = _stepper(tiny_opt, prompt, 2 * nb)
+    ours = beam_search(step, first, 2, nb, 9, lp, 3, 1, False, 1, processors=_procs(rp, ngram), prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=9, do_sample=False, num_beams=nb, length_penalty=lp, eos_token_id=3, repetition_penalty=rp,
+             no_repeat_ngram_size=ngram, early_stopping=False)
+    _eq(ours, hf)
+
+
+def test_greedy_with_stopping_criteria_equals_transformers(tiny_opt):
+    from transformers import StoppingCriteriaList
+
+    torch.manual_seed(5)
+    prompt = torch.randint(4, 40, (2, 5))
+    step, first = _stepper(tiny_opt, prompt, 2)
+    crit = StoppingCriteriaList([_StopOnLength(5 + 4)])
+    ours = sample_loop(step, first, 12, eos_id=-1, pad_id=1, greedy=True, stopping=crit, prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=12, do_sample=False, num_beams=1, eos_token_id=None, stopping_criteria=StoppingCriteriaList([_StopOnLength(5 + 4)]))
+    assert ours.shape[1] == 4
+    _eq(ours, hf)

@@ -274,3 +274,42 @@ def test_hidden_states_of_the_language_model_and_qformer_like_the_reference(gold
               video_input_mask=t(g["video_input_mask"]), return_dict=True)
     assert torch.equal(plain.logits, out.logits) and plain.language_model_outputs.hidden_states is None
     assert rel_rms(host(out.logits)[valid], g["fp32_logits"][valid]) <= 1.2e-2
+
+
+def test_generate_passes_logits_processors_and_stopping_criteria(golden_dir):
+    """hf hands every generate kwarg on (ref:eilev/model/v2.py:318-322): repetition_penalty / no_repeat_ngram_size / logits_processor /
+    stopping_criteria / max_time run in the host loops over the HIP decode step (tests/test_generate_rules.py pins those loops to
+    transformers token for token on the CPU)."""
+    from transformers import LogitsProcessorList, StoppingCriteriaList
+
+    g, meta, px = load_case(golden_dir, "mid_b2")
+    m = build(meta["config"], torch.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    kw = dict(input_ids=t(g["input_ids"]), pixel_values=t(px), video_input_mask=t(g["video_input_mask"]), attention_mask=t(g["attention_mask"]),
+              max_new_tokens=10, do_sample=False, eos_token_id=511)
+    plain = m.generate(**kw, num_beams=1)
+    assert (plain[:, 1:] == plain[:, :-1]).any()  # the 'fanin' model repeats itself ...
+    ng = m.generate(**kw, num_beams=1, no_repeat_ngram_size=1)
+    assert ng.shape == plain.shape and all(len(set(r.tolist())) == r.numel() for r in ng)  # ... and may not with the 1-gram ban
+    rp = m.generate(**kw, num_beams=1, repetition_penalty=50.0)
+    assert not torch.equal(rp, plain)
+    bm = m.generate(**kw, num_beams=3, no_repeat_ngram_size=2)
+    for r in bm.tolist():
+        grams = list(zip(r, r[1:]))
+        assert len(set(grams)) == len(grams)
+
+    class Ban:
+        def __call__(self, input_ids, scores):
+            scores = scores.clone()
+            scores[:, int(plain[0, 0])] = float("-inf")
+            return scores
+
+    class Stop3:
+        def __call__(self, input_ids, scores, **kw):
+            return torch.full((input_ids.shape[0],), input_ids.shape[1] >= 3, dtype=torch.bool, device=input_ids.device)
+
+    banned = m.generate(**kw, num_beams=1, logits_processor=LogitsProcessorList([Ban()]))
+    assert not (banned == plain[0, 0]).any()
+    short = m.generate(**kw, num_beams=1, stopping_criteria=StoppingCriteriaList([Stop3()]))
+    assert short.shape[1] == 3 and torch.equal(short, plain[:, :3])
+    assert m.generate(**kw, num_beams=1, max_time=1e-9).shape[1] == 1  # the time budget is checked after the first token, as in hf
