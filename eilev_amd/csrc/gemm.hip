@@ -1826,6 +1826,167 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
 // activation fragment requested up front, no ring: 24.2 us per q|k|v / fc1 / fc2 launch against 19.8 us for the kernel above, 5.53 vs 5.40
 // ms/token at batch 32 (profiles/r04_skinny5_rejected_*).  The ring depth was not the limit: each workgroup re-reads the 160 KB of
 // activations from L2, and with one block per workgroup that is 2-3x the weight bytes entering every CU.)
+// ---- round 4: 17..32 rows, ONE workgroup per CU, the activations loaded once per CU -----------------------------------------------------
+// What bounds the kernels above at batch 32 is not the weight stream but the activations: every workgroup re-reads the 32 x K rows from
+// L2 (160 KB at K = 2560) for 16-32 weight rows (80-160 KB) — 2-3x the weight bytes enter each CU (measured twice: 2 / 4 / 8 blocks per
+// workgroup in round 2, and round 4's one-block-per-workgroup variant with every load up front, which was SLOWER: 24 vs 20 us).  Here the
+// grid is the CUs.  A 512-thread workgroup splits K over its 8 waves (wave w: K / (8 ks) columns = KS k-steps of 32): its slice of the
+// 32 rows is 80 VGPRs of MFMA A fragments, loaded ONCE; the CU then walks its share of the 16-row weight blocks, every wave streaming
+// its K slice of a block straight into registers as B fragments (16 rows x 64 B per instruction, non-temporal) through a ring of RB
+// blocks (30 KB per wave, 240 KB per CU in flight), 2 KS MFMAs per block, the 8 K-slice partials summed through LDS in a fixed order
+// (ping-pong buffers, one barrier per block).  blockIdx.y = K split across CUs where the 8-wave slice would not fit the registers (fc2:
+// K = 10240 -> 4) or the matrix has fewer blocks than CUs (out_proj): partials + reduce_ln_kernel as before.
+template <int MB, int KS, int RB>
+__global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
+    const GemmArgs &g = a.g;
+    __shared__ float red[2][8][MB][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = (g.N + 15) / 16;
+    const int G = gridDim.x;
+    // this CU's blocks of K split blockIdx.y: [b0, b1)
+    const int per = nb / G, rem = nb % G;
+    const int b0 = blockIdx.x * per + min((int)blockIdx.x, rem), b1 = b0 + per + ((int)blockIdx.x < rem ? 1 : 0);
+    const int nblk = b1 - b0;
+    if (nblk <= 0) return;  // (uniform per workgroup)
+    const int k0 = (blockIdx.y * 8 + wid) * (KS * 32);
+    bf16x8 wv[RB][KS];
+    float bv[RB];  // bias of the lane's output column, requested WITH the block's weights: a load in the epilogue put one global round trip
+                   // (~1.5 us) on the critical path of every block (measured without any operand loads: 7.5 us per q|k|v launch, 20.7 for the lm_head)
+    const bool plain_epi = a.ks == 1 && !g.wscale && !g.resid;
+    auto load_block = [&](int j, auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+        int gr = (b0 + j) * 16 + l15;
+        gr = gr < g.N ? gr : g.N - 1;
+        bv[B] = (plain_epi && g.bias) ? (float)g.bias[gr] : 0.0f;
+        const bf16 *wp = g.W + (int64_t)gr * g.ldw + k0 + lg * 8;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+#ifdef ROWS32_NOW
+            wv[B][u] = zero8();
+#else
+            wv[B][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wp + u * 32));
+#endif
+        }
+    };
+    bf16x8 av[MB][KS];
+    auto load_x = [&]() {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int r = mb * 16 + l15;
+            const bf16 *ap = g.A + (int64_t)(r < g.M ? r : 0) * g.lda + k0 + lg * 8;
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+#ifdef ROWS32_NOX
+                av[mb][u] = zero8();
+#else
+                av[mb][u] = r < g.M ? *reinterpret_cast<const bf16x8 *>(ap + u * 32) : zero8();
+#endif
+            }
+        }
+    };
+    auto consume = [&](int j, auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+        f32x4 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mb][u], wv[B][u], acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[j & 1][wid][mb][lane][r] = acc[mb][r];
+        __syncthreads();  // the partials of block j are complete; region (j + 1) & 1 is free again (its readers passed the previous barrier's successor)
+        if (wid < MB) {
+            const int mb = wid, col = (b0 + j) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[j & 1][w][mb][lane][r];
+                const int row = mb * 16 + lg * 4 + r;
+                if (row < g.M && col < g.N) {
+                    if (plain_epi) {  // bias (prefetched) + activation + store: no load here
+                        v += bv[B];
+                        if (col < g.scale_cols) v *= g.scale;
+                        if (g.epi == 1) v = gelu_erf(v);
+                        else if (g.epi == 2) v = fmaxf(v, 0.0f);
+                        if (g.out_f32) reinterpret_cast<float *>(g.C)[(int64_t)row * g.ldc + col] = v;
+                        else reinterpret_cast<bf16 *>(g.C)[(int64_t)row * g.ldc + col] = (bf16)v;
+                    } else if (a.ks == 1) skinny_epilogue(g, row, col, v);
+                    else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
+                }
+            }
+        }
+    };
+    if (nblk >= 2 * RB) {  // long: the lm_head (12 blocks per CU) — ring with a branch-free steady loop
+        static_for<RB>([&](auto j_c) { load_block(decltype(j_c)::value, j_c); });
+        load_x();
+        int base = 0;
+        for (; base + 2 * RB <= nblk; base += RB)
+            static_for<RB>([&](auto j_c) {
+                consume(base + decltype(j_c)::value, j_c);
+                load_block(base + decltype(j_c)::value + RB, j_c);
+            });
+        static_for<RB>([&](auto j_c) {
+            consume(base + decltype(j_c)::value, j_c);
+            if (base + decltype(j_c)::value + RB < nblk) load_block(base + decltype(j_c)::value + RB, j_c);
+        });
+        base += RB;
+        static_for<RB>([&](auto j_c) {
+            if (base + decltype(j_c)::value < nblk) consume(base + decltype(j_c)::value, j_c);
+        });
+    } else {  // short: the block matrices (1-3 blocks per CU): everything requested up front
+        static_for<RB>([&](auto j_c) {
+            if (decltype(j_c)::value < nblk) load_block(decltype(j_c)::value, j_c);
+        });
+        load_x();
+        static_for<RB>([&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            if (J < nblk) {
+                consume(J, j_c);
+                if (J + RB < nblk) load_block(J + RB, j_c);
+            }
+        });
+        static_for<RB>([&](auto j_c) {
+            if (decltype(j_c)::value + RB < nblk) consume(decltype(j_c)::value + RB, j_c);
+        });
+    }
+}
+
+static int skinny_n_cu() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        else n = 256;
+    }
+    return n;
+}
+
+// K split of gemm_rows32_kernel: the 8-wave K slice must be 5 or 10 k-steps of 32; more splits when the matrix has fewer blocks than CUs
+static bool rows32_plan(const GemmArgs &g, int nb, int n_cu, SkinnyArgs &a, int &ks, int &ksteps) {
+    if (g.K % 256) return false;
+    const int per_wave = g.K / 256;  // k-steps of 32 per wave without a split
+    int k5 = 0;
+    for (int c = 1; c <= 8; c *= 2)
+        if (per_wave % c == 0 && (per_wave / c == 10 || per_wave / c == 5)) {
+            k5 = c;
+            if (nb * c >= n_cu || per_wave / c == 5 || !(g.dbg & 134217728)) break;
+        }
+    if (!k5) return false;
+    if (k5 > 1 && !(g.dbg & 134217728)) return false;  // measured: the split-K forms (out_proj, fc2) lose to the round-3 kernels in the step; probe flag 1 << 27 enables them
+    if (k5 > 1 && (!g.scratch || (size_t)k5 * a.mr * g.N * sizeof(float) > g.scratch_bytes)) return false;
+    ks = k5;
+    a.ks = k5;
+    ksteps = per_wave / k5;
+    return true;
+}
+
 template <int MB, bool PRE>
 __global__ __launch_bounds__(256) void gemm_skinny_w8_kernel(const SkinnyArgs a) {
     const GemmArgs &g = a.g;
@@ -2100,6 +2261,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         const int per_w = ((g.K / 256 + ks - 1) / ks + 3) / 4;
         const bool pre = per_w <= 3 && !(g.dbg & 128);
         // weight blocks per workgroup (activation fragments reused): probe override (dbg >> 26) & 7 = 1 / 2 / 4; default by shape below
+        int ks32 = 0;
         int nbsel = (g.dbg >> 26) & 7;
         // measured at M = 32 (tools/skinny_sweep.py, 2 LDS stages so that two workgroups share a CU): lm_head (3142 blocks) 2.82 -> 3.45 /
         // 3.76 / 4.20 TB/s with 2 / 4 / 8 blocks per workgroup, qkv (480) 2.25 -> 2.46 with 2 (1.71 with 4: 120 workgroups leave CUs idle),
@@ -2120,6 +2282,11 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         } else if (g.W8) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
+        } else if (g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32)) {
+            // round 4 (gemm_rows32_kernel): one workgroup per CU, the 32 rows loaded once per CU.  probe flag 1 << 28: the kernels below
+            const int grid_x = nb < skinny_n_cu() ? nb : skinny_n_cu();
+            if (ks32 == 10) hipLaunchKernelGGL((gemm_rows32_kernel<2, 10, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gemm_rows32_kernel<2, 5, 4>), dim3(grid_x, ks), dim3(512), 0, s, a);
         } else if (dma_ok && pre && nbsel > 1) {
             // activations held across NB weight blocks per workgroup (see gemm_skinny_nb_kernel): 2 LDS-DMA stages + ping-pong partials =
             // 64 KB + 2 x MB x 4 KB, so two workgroups share a CU
