@@ -691,7 +691,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             traffic = tr = None
             try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
-                with open(os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")) as fh:
                     tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
                 if tr:  # measured on the bench's launch shape (1088 frames x 257 tokens per launch)
                     traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
@@ -700,7 +700,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "launches": int(n), "avg_launch_ms": round(ms / n, 4), "traffic_measured_in_run": False,
-                               "traffic_source": "profiles/r03_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run)",
+                               "traffic_source": "profiles/r04_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run)",
                                "mfma_busy_frac_pmc": (tr or {}).get("mfma_busy_frac"), "effective_clock_ghz_pmc": (tr or {}).get("eff_clock_ghz"),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}

@@ -246,7 +246,7 @@ EXPORTS = [
     "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward", "eilev_vit_forward_debug",
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_prefill_debug", "eilev_opt_extend", "eilev_greedy_select",
-    "eilev_opt_decode_step", "eilev_opt_decode_step_beam", "eilev_linear", "eilev_linear_rows", "eilev_layernorm", "eilev_attention", "eilev_prof_enable",
+    "eilev_opt_decode_step", "eilev_opt_decode_step_beam", "eilev_linear", "eilev_linear_rows", "eilev_layernorm", "eilev_attention", "eilev_attention_probs", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_quant_rows_e4m3", "eilev_linear_a8w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
@@ -349,6 +349,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_layernorm.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.eilev_attention.restype = i32
     lib.eilev_attention.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
+    lib.eilev_attention_probs.restype = i32
+    lib.eilev_attention_probs.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
     lib.eilev_attention_bwd.restype = i32
     lib.eilev_attention_bwd.argtypes = [vp] * 9 + [i64] * 11 + [f32, i32, vp, vp]
     lib.eilev_layernorm_bwd.restype = i32
@@ -416,7 +418,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 11:
+    if lib.eilev_abi_version() != 12:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

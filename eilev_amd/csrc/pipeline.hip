@@ -1017,6 +1017,74 @@ extern "C" int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeig
 // =====================================================================================================
 // Building blocks (unit parity tests, roofline probe)
 // =====================================================================================================
+namespace {
+// eilev_attention_probs: one wave per (batch, head, query row); a lane owns keys lane, lane + 64, ... (up to 64 per lane = 4096 keys)
+__global__ void __launch_bounds__(256) attn_probs_masked_kernel(const bf16 *__restrict__ q, const bf16 *__restrict__ k, bf16 *__restrict__ probs, int heads,
+                                                                int sq, int skv, int hd, int64_t ldq, int64_t ldk, float scale, int causal,
+                                                                const int32_t *__restrict__ key_mask) {
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= sq) return;
+    const bf16 *qr = q + ((int64_t)b * sq + i) * ldq + h * hd;
+    bf16 *out = probs + (((int64_t)b * heads + h) * sq + i) * skv;
+    const int nt = (skv + 63) / 64;
+    float mx = -INFINITY;
+    // two passes over the keys (scores recomputed): no per-lane array of 64 scores
+    for (int pass = 0; pass < 2; ++pass) {
+        float sum = 0.0f;
+        float keep_mx = mx;
+        for (int t = 0; t < nt; ++t) {
+            const int j = lane + 64 * t;
+            float s = -INFINITY;
+            if (j < skv && (!causal || j <= i + (skv - sq)) && (!key_mask || key_mask[(int64_t)b * skv + j] != 0)) {
+                const bf16 *kr = k + ((int64_t)b * skv + j) * ldk + h * hd;
+                s = 0.0f;
+                for (int e = 0; e < hd; e += 8) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qr + e), ka = *reinterpret_cast<const bf16x8 *>(kr + e);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fmaf((float)qa[u], (float)ka[u], s);
+                }
+                s *= scale;
+            }
+            if (pass == 0) mx = fmaxf(mx, s);
+            else sum += s == -INFINITY ? 0.0f : __expf(s - keep_mx);
+        }
+        if (pass == 0) {
+            mx = wave_max(mx);
+            continue;
+        }
+        sum = wave_sum(sum);
+        for (int t = 0; t < nt; ++t) {  // third walk: write (scores recomputed once more: this is the debug path)
+            const int j = lane + 64 * t;
+            if (j >= skv) continue;
+            float p = 0.0f;
+            if ((!causal || j <= i + (skv - sq)) && (!key_mask || key_mask[(int64_t)b * skv + j] != 0)) {
+                const bf16 *kr = k + ((int64_t)b * skv + j) * ldk + h * hd;
+                float s = 0.0f;
+                for (int e = 0; e < hd; e += 8) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qr + e), ka = *reinterpret_cast<const bf16x8 *>(kr + e);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fmaf((float)qa[u], (float)ka[u], s);
+                }
+                p = sum > 0.0f ? __expf(s * scale - keep_mx) / sum : 0.0f;
+            }
+            out[j] = (bf16)p;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int eilev_attention_probs(const void *q, const void *k, void *probs, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim,
+                                     int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, void *stream) {
+    if (!q || !k || !probs || batch < 0 || heads <= 0 || sq < 0 || skv <= 0 || skv > 4096) return EILEV_E_BADARG;
+    if ((head_dim & 7) || (ldq & 7) || (ldk & 7) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15)) return EILEV_E_UNSUPPORTED;
+    if (batch == 0 || sq == 0) return EILEV_OK;
+    attn_probs_masked_kernel<<<dim3((unsigned)(batch * heads), (unsigned)((sq + 3) / 4)), 256, 0, (hipStream_t)stream>>>(
+        (const bf16 *)q, (const bf16 *)k, (bf16 *)probs, (int)heads, (int)sq, (int)skv, (int)head_dim, ldq, ldk, scale, causal, key_mask);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 extern "C" int eilev_linear(const void *a, const void *w, const void *bias, const void *residual, void *c, int64_t m,
                             int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
     if (!a || !w || !c || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffff || n > 0x7fffffff) return EILEV_E_BADARG;

@@ -240,6 +240,74 @@ class HipEngine:
                                                  ws.numel(), self._stream()), "eilev_qformer_forward")
         return out
 
+    # ---- attention WEIGHTS of the Q-Former and the language model (slow path: `output_attentions=True` inside the full forward) ------------
+    def _lin(self, x2d, wname, bname=None, resid=None):
+        w = self._keep[wname]
+        b = self._keep[bname] if bname else None
+        m, k = x2d.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
+        abi.check(self.lib.eilev_linear(_ptr(x2d.contiguous()), _ptr(w), _ptr(b), _ptr(resid), _ptr(out), m, n, k, 0, 0, self._stream()), "eilev_linear")
+        return out
+
+    def _ln(self, x2d, wname, bname, eps):
+        out = torch.empty_like(x2d)
+        abi.check(self.lib.eilev_layernorm(_ptr(x2d.contiguous()), _ptr(self._keep[wname]), _ptr(self._keep[bname]), _ptr(out), x2d.shape[0], x2d.shape[1],
+                                           C.c_float(eps), self._stream()), "eilev_layernorm")
+        return out
+
+    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None):
+        out = torch.empty((B, H, sq, skv), dtype=torch.bfloat16, device=self.device)
+        km = None if key_mask is None else key_mask.to(self.device, torch.int32).contiguous()
+        abi.check(self.lib.eilev_attention_probs(_ptr(q), _ptr(k), _ptr(out), B, H, sq, skv, hd, q.shape[-1], k.shape[-1], C.c_float(scale), int(causal),
+                                                 _ptr(km), self._stream()), "eilev_attention_probs")
+        return out
+
+    def lm_attentions(self, hidden_states: torch.Tensor, attention_mask: torch.Tensor):
+        """`output_attentions` of the OPT language model [ref:eilev/model/v2.py:220-227 -> hf modeling_opt.py eager_attention_forward]:
+        per block softmax(causal + padding mask over scale * q . k), (t_layers, B, heads, L, L) bf16.  hidden_states = the tuple of
+        `prefill(..., hidden_states=True)` (every block's input); q and k are recomputed from it (LayerNorm + the two projections)."""
+        d = self.dims
+        Lyr, B, L, D = hidden_states.shape[0] - 1, *hidden_states.shape[1:]
+        H, hd = d.t_heads, d.t_hidden // d.t_heads
+        out = []
+        for l in range(Lyr):
+            p = abi.OPT_PREFIX.format(l)
+            x = self._ln(hidden_states[l].reshape(B * L, D), p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", d.t_eps)
+            q = self._lin(x, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias")
+            k = self._lin(x, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias")
+            out.append(self._probs(q, k, B, H, L, L, hd, hd ** -0.5, causal=True, key_mask=attention_mask))
+        return torch.stack(out)
+
+    def qformer_attentions(self, image_embeds: torch.Tensor, hidden_states):
+        """`output_attentions` of the Q-Former [ref:eilev/model/v2.py:187-193 -> hf Blip2QFormerLayer]: (self-attention weights of every block
+        (q_layers, N, heads, nq, nq), cross-attention weights of the blocks that have one (list of (N, heads, nq, kv))).  hidden_states = the
+        tuple of `qformer_hidden_states` (block inputs); the cross-attention's queries come from the block's self-attention output, which is
+        recomputed here (attention, output dense + residual, LayerNorm) with the same C-ABI calls the stage itself is built from."""
+        d = self.dims
+        img = image_embeds.contiguous()
+        N, kv, Dv = img.shape
+        nq, Dq, H = d.num_query, d.q_hidden, d.q_heads
+        hd = Dq // H
+        selfs, crosses = [], []
+        for i in range(d.q_layers):
+            p = f"qformer.encoder.layer.{i}."
+            h = hidden_states[i].reshape(N * nq, Dq).contiguous()
+            q = self._lin(h, p + "attention.attention.query.weight", p + "attention.attention.query.bias")
+            k = self._lin(h, p + "attention.attention.key.weight", p + "attention.attention.key.bias")
+            selfs.append(self._probs(q, k, N, H, nq, nq, hd, hd ** -0.5))
+            if i % d.q_cross_freq == 0:
+                v = self._lin(h, p + "attention.attention.value.weight", p + "attention.attention.value.bias")
+                ctx = torch.empty_like(q)
+                abi.check(self.lib.eilev_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(ctx), N, H, nq, nq, hd, Dq, Dq, Dq, C.c_float(hd ** -0.5), 0, None,
+                                                   self._stream()), "eilev_attention")
+                ao = self._ln(self._lin(ctx, p + "attention.output.dense.weight", p + "attention.output.dense.bias", resid=h),
+                              p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias", d.q_eps)
+                qc = self._lin(ao, p + "crossattention.attention.query.weight", p + "crossattention.attention.query.bias")
+                kc = self._lin(img.reshape(N * kv, Dv), p + "crossattention.attention.key.weight", p + "crossattention.attention.key.bias")
+                crosses.append(self._probs(qc, kc, N, H, nq, kv, hd, hd ** -0.5))
+        return torch.stack(selfs), crosses
+
     def qformer_hidden_states(self, image_embeds: torch.Tensor):
         """Debug outputs of the Q-Former [ref:eilev/model/v2.py:187-193 `output_hidden_states`]: the tuple hf returns — the embedding output
         (LayerNorm of the query tokens) and every block's output, each (N, num_query, Dq) bf16.  Slow path: the stack is run with its first

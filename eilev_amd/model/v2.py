@@ -8,9 +8,9 @@ state-dict names; none of them has arithmetic in its ``forward``
 ``libeilev_hip.so`` through :class:`eilev_amd.engine.HipEngine`.  There is no CPU / eager fallback: calling
 ``forward`` or ``generate`` on a model that is not on an AMD GPU raises.
 
-Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling are); ``output_attentions`` of the language
-model and of the Q-Former and ``output_hidden_states`` of the T5 stacks inside the full model's ``forward`` (those fields stay ``None``) — the
-vision wrapper serves both flags from a slow path, the Q-Former and the OPT language model their hidden states.
+Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling
+are).  ``output_hidden_states`` / ``output_attentions`` inside the full model's ``forward`` are served from slow paths for the vision wrapper,
+the Q-Former (self- and cross-attention weights) and the OPT language model; the T5 stacks' per-block tensors stay ``None``.
 """
 from __future__ import annotations
 
@@ -276,6 +276,19 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                         vit_ln_fold=ln_fold))
         return self._hip[1]
 
+    def _qformer_attn_tuple(self, qa, dtype):
+        """`qformer_outputs.attentions` as the installed transformers fills it: the weights of EVERY attention module of the Q-Former in
+        execution order — self_0, cross_0, self_1, ... (cross-attention every `cross_attention_frequency` blocks); `cross_attentions` holds
+        the cross ones again (pinned by tests/golden/mid_attndebug.npz)."""
+        selfs, crosses = qa
+        out, ci = [], 0
+        for i in range(selfs.shape[0]):
+            out.append(selfs[i].to(dtype))
+            if i % self.config.qformer_config.cross_attention_frequency == 0:
+                out.append(crosses[ci].to(dtype))
+                ci += 1
+        return tuple(out)
+
     def _encode(self, pixel_values, input_ids, video_input_mask, vision_debug=(False, False)):
         eng = self.engine()
         feats = None
@@ -288,7 +301,9 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             else:
                 img, pooled = eng.vit(pixel_values, want_pooler=True)
             q = eng.qformer(img)
-            self._qformer_debug = eng.qformer_hidden_states(img) if vision_debug[0] else None
+            qh = eng.qformer_hidden_states(img) if any(vision_debug) else None
+            self._qformer_debug = qh if vision_debug[0] else None
+            self._qformer_attn = eng.qformer_attentions(img, qh) if vision_debug[1] else None
             feats = eng.project(q)
             vision, qf = (img, pooled), q
         emb = eng.embed_scatter(input_ids, video_input_mask if feats is not None else None, feats)
@@ -362,8 +377,9 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             assert video_input_mask is not None
         # output_hidden_states / output_attentions: the VISION outputs carry both (slow path of the library, what
         # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper) and the Q-Former output carries hidden_states (r3: the stack
-        # re-run with its first i blocks) and the OPT language model's output carries hidden_states (r3: eilev_opt_prefill_debug); the
-        # attention maps of the Q-Former and of the language model, and the T5 stacks' per-block tensors, are not exported: those stay None
+        # re-run with its first i blocks) and the OPT language model's output carries hidden_states (r3: eilev_opt_prefill_debug); r4: the
+        # attention weights of the Q-Former (self and cross) and of the OPT language model (eilev_attention_probs on q / k recomputed from the
+        # per-block inputs).  The T5 stacks' per-block tensors are not exported: those stay None
         self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
@@ -373,10 +389,13 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             attention_mask = torch.ones_like(input_ids)
         if self._is_t5:
             return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict)
-        lm_hidden = None
-        if output_hidden_states:  # hf OPTDecoder's tuple: every block's input, then the output of final_layer_norm
+        lm_hidden = lm_attn = None
+        if output_hidden_states or output_attentions:  # hf OPTDecoder's tuple: every block's input, then the output of final_layer_norm
             _, logits32, _, hs = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False, hidden_states=True)
-            lm_hidden = tuple(h.to(dtype) for h in hs.unbind(0))
+            if output_hidden_states:
+                lm_hidden = tuple(h.to(dtype) for h in hs.unbind(0))
+            if output_attentions:  # (round 4) hf eager `attn_weights` of every block: (B, heads, L, L)
+                lm_attn = tuple(a.to(dtype) for a in self.engine().lm_attentions(hs, attention_mask).unbind(0))
         else:
             _, logits32, _ = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False)
         loss = None
@@ -393,9 +412,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                                  hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
                                                  attentions=None if va is None else tuple(a.to(dtype) for a in va))
             qh = getattr(self, "_qformer_debug", None)
+            qa = getattr(self, "_qformer_attn", None)
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype),
-                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh))
-        lm_out = CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=lm_hidden)
+                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh),
+                                                                  attentions=None if qa is None else self._qformer_attn_tuple(qa, dtype),
+                                                                  cross_attentions=None if qa is None else tuple(a.to(dtype) for a in qa[1]))
+        lm_out = CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=lm_hidden, attentions=lm_attn)
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
             return ((loss,) + out) if loss is not None else out

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 11  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3) */
+#define EILEV_ABI_VERSION 12  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -255,14 +255,14 @@ int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, cons
 /* probe / test knob: minimum token rows of a launch for the folded ViT path (default 65 536; 0 = always when layers_fold is set) */
 void eilev_debug_ln_fold_min_rows(int64_t rows);
 /* The other process-global probe switches (all default 0 = the product path; tools/ and tests/ only; see the header comment):
- *   eilev_debug_gemm_flags(int)        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
- *   eilev_debug_gemm_trace(ptr, tiles) per-tile time stamps of the persistent GEMM (tools/gemm_trace.py)
- *   eilev_debug_patch_trace(ptr)       phase stamps of the fused patch kernel (tools/patch_trace.py)
- *   eilev_debug_attn_v1(int)           route attention to the round-1 kernels (A/B in tests/test_hip_kernels.py)
- *   eilev_debug_attn_ts(ptr)           phase stamps of the frame attention kernel (tools/attn_ts.py)
- *   eilev_debug_fused_patch(int) / eilev_debug_no_fused_patch(int)   select the fused patch-embed + LayerNorm kernel (opt-in since r3)
- *   eilev_debug_decode_rows(int)       force the row-dot (1) / MFMA (2) decode block regardless of the batch
- *   eilev_debug_decode_prefetch(int)   the rejected Infinity-Cache touch kernel of DESIGN 3b (off) */
+ *   eilev_debug_gemm_flags        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
+ *   eilev_debug_gemm_trace per-tile time stamps of the persistent GEMM (tools/gemm_trace.py)
+ *   eilev_debug_patch_trace       phase stamps of the fused patch kernel (tools/patch_trace.py)
+ *   eilev_debug_attn_v1           route attention to the round-1 kernels (A/B in tests/test_hip_kernels.py)
+ *   eilev_debug_attn_ts           phase stamps of the frame attention kernel (tools/attn_ts.py)
+ *   eilev_debug_fused_patch / eilev_debug_no_fused_patch   select the fused patch-embed + LayerNorm kernel (opt-in since r3)
+ *   eilev_debug_decode_rows       0: MFMA weight-streaming kernels at every batch size; 1 (default): row-dot kernels at <= 4 rows; 3: the round-3 row-dot kernels (<= 2 rows) instead of gemv1 / gemvm
+ *   eilev_debug_decode_prefetch   the rejected Infinity-Cache touch kernel of DESIGN 3b (off) */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.
@@ -442,6 +442,13 @@ int eilev_linear_rows(const void *x, const void *ln_gamma, const void *ln_beta, 
 int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_t batch, int64_t heads,
                     int64_t sq, int64_t skv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
                     float scale, int causal, const int32_t *key_mask, void *stream);
+/* ABI version 12 (round 4).  The attention WEIGHTS of the same call: probs (batch, heads, sq, skv) = softmax over the visible keys of
+ * scale * q . k (same layout, causal and key_mask arguments as eilev_attention; masked keys get 0; a row without a visible key is all 0) —
+ * what hf's eager attention returns as `attn_weights` and the reference passes through under `output_attentions=True`
+ * (ref:eilev/model/v2.py:187-193 Q-Former [hf modeling_blip_2.py Blip2QFormerMultiHeadAttention], :220-227 language model [hf modeling_opt.py
+ * eager_attention_forward]).  Slow path: one wave per query row, nothing tiled; probs bf16 (HIP) / f32 (oracle).  skv <= 4096. */
+int eilev_attention_probs(const void *q, const void *k, void *probs, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim,
+                          int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, void *stream);
 
 /* ---- gradient building blocks of the train_v2 path -------------------------------------------------
  * ref:scripts/general/train_v2.py:124-130,207-217: `loss = model(**batch).loss; accelerator.backward(loss)` with the

@@ -101,6 +101,83 @@ class OracleModel:
                                                  nbytes, None), "oracle qformer")
         return out
 
+    # ---- attention weights (`output_attentions=True` inside the full forward): the same composition as eilev_amd/engine.py, on the oracle's entries ----
+    def _lin(self, x2d, wname, bname=None, resid=None):
+        x = np.ascontiguousarray(x2d, np.float32)
+        w, b = self.w[wname], (self.w[bname] if bname else None)
+        out = np.empty((x.shape[0], w.shape[0]), np.float32)
+        abi.check(self.lib.eilev_linear(_p(x), _p(w), _p(b), _p(resid), _p(out), x.shape[0], w.shape[0], x.shape[1], 0, 1, None), "oracle linear")
+        return out
+
+    def _ln(self, x2d, wname, bname, eps):
+        x = np.ascontiguousarray(x2d, np.float32)
+        out = np.empty_like(x)
+        abi.check(self.lib.eilev_layernorm(_p(x), _p(self.w[wname]), _p(self.w[bname]), _p(out), x.shape[0], x.shape[1], C.c_float(eps), None), "oracle layernorm")
+        return out
+
+    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None):
+        out = np.empty((B, H, sq, skv), np.float32)
+        km = None if key_mask is None else np.ascontiguousarray(key_mask, np.int32)
+        abi.check(self.lib.eilev_attention_probs(_p(q), _p(k), _p(out), B, H, sq, skv, hd, q.shape[-1], k.shape[-1], C.c_float(scale), int(causal), _p(km), None),
+                  "oracle attention_probs")
+        return out
+
+    def lm_attentions(self, hidden_states, attn_mask):
+        """hf OPT eager `attn_weights` of every block from the block inputs (prefill(hidden_states=True)): (layers, B, heads, L, L)."""
+        d = self.dims
+        Lyr, B, L, D = hidden_states.shape[0] - 1, *hidden_states.shape[1:]
+        H, hd = d.t_heads, d.t_hidden // d.t_heads
+        out = []
+        for l in range(Lyr):
+            p = abi.OPT_PREFIX.format(l)
+            x = self._ln(hidden_states[l].reshape(B * L, D), p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias", d.t_eps)
+            q = self._lin(x, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias")
+            k = self._lin(x, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias")
+            out.append(self._probs(q, k, B, H, L, L, hd, hd ** -0.5, causal=True, key_mask=attn_mask))
+        return np.stack(out)
+
+    def qformer_hidden_states(self, image_embeds):
+        """embedding output + every block's output: the stack run with its first i blocks (the C ABI has no per-block export)."""
+        d = self.dims
+        img = np.ascontiguousarray(image_embeds, np.float32)
+        N, kv = img.shape[:2]
+        qt = np.ascontiguousarray(self.w["query_tokens"].reshape(d.num_query, d.q_hidden))
+        outs = [np.broadcast_to(self._ln(qt, "qformer.layernorm.weight", "qformer.layernorm.bias", d.q_eps)[None], (N, d.num_query, d.q_hidden)).copy()]
+        nbytes = self.lib.eilev_qformer_workspace_bytes(C.byref(d), N, kv)
+        ws = np.empty(nbytes // 4 + 1, np.float32)
+        for i in range(1, d.q_layers + 1):
+            di = type(d).from_buffer_copy(d)
+            di.q_layers = i
+            out = np.empty((N, d.num_query, d.q_hidden), np.float32)
+            abi.check(self.lib.eilev_qformer_forward(C.byref(di), C.byref(self.pack.qf), _p(img), N, kv, _p(out), _p(ws), nbytes, None), "oracle qformer")
+            outs.append(out)
+        return outs
+
+    def qformer_attentions(self, image_embeds, hidden_states):
+        """(self-attention weights per block, cross-attention weights of the blocks that have one) — hf Blip2QFormerLayer."""
+        d = self.dims
+        img = np.ascontiguousarray(image_embeds, np.float32)
+        N, kv, Dv = img.shape
+        nq, Dq, H = d.num_query, d.q_hidden, d.q_heads
+        hd = Dq // H
+        selfs, crosses = [], []
+        for i in range(d.q_layers):
+            p = f"qformer.encoder.layer.{i}."
+            h = np.ascontiguousarray(hidden_states[i].reshape(N * nq, Dq), np.float32)
+            q = self._lin(h, p + "attention.attention.query.weight", p + "attention.attention.query.bias")
+            k = self._lin(h, p + "attention.attention.key.weight", p + "attention.attention.key.bias")
+            selfs.append(self._probs(q, k, N, H, nq, nq, hd, hd ** -0.5))
+            if i % d.q_cross_freq == 0:
+                v = self._lin(h, p + "attention.attention.value.weight", p + "attention.attention.value.bias")
+                ctx = np.empty_like(q)
+                abi.check(self.lib.eilev_attention(_p(q), _p(k), _p(v), _p(ctx), N, H, nq, nq, hd, Dq, Dq, Dq, C.c_float(hd ** -0.5), 0, None, None), "oracle attention")
+                ao = self._ln(self._lin(ctx, p + "attention.output.dense.weight", p + "attention.output.dense.bias", resid=h),
+                              p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias", d.q_eps)
+                qc = self._lin(ao, p + "crossattention.attention.query.weight", p + "crossattention.attention.query.bias")
+                kc = self._lin(img.reshape(N * kv, Dv), p + "crossattention.attention.key.weight", p + "crossattention.attention.key.bias")
+                crosses.append(self._probs(qc, kc, N, H, nq, kv, hd, hd ** -0.5))
+        return selfs, crosses
+
     def project(self, query_out: np.ndarray):
         q = np.ascontiguousarray(query_out, dtype=np.float32).reshape(-1, self.dims.q_hidden)
         out = np.empty((q.shape[0], self.dims.t_hidden), np.float32)

@@ -313,3 +313,44 @@ def test_generate_passes_logits_processors_and_stopping_criteria(golden_dir):
     short = m.generate(**kw, num_beams=1, stopping_criteria=StoppingCriteriaList([Stop3()]))
     assert short.shape[1] == 3 and torch.equal(short, plain[:, :3])
     assert m.generate(**kw, num_beams=1, max_time=1e-9).shape[1] == 1  # the time budget is checked after the first token, as in hf
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_output_attentions_of_the_qformer_and_the_language_model(golden_dir, dtype):
+    """`forward(output_attentions=True)` [ref:eilev/model/v2.py:187-193, 220-227]: Q-Former self / cross and OPT attention weights on the HIP
+    path against the reference's eager run (tests/golden/mid_attndebug.npz); as close to its fp32 weights as its own bf16 run (+ slack)."""
+    import json
+    import os
+
+    g = np.load(os.path.join(golden_dir, "mid_attndebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    from eilev_amd.synth import synth_pixels
+
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)
+    m = build(meta["config"], dtype)
+    t = lambda a: torch.from_numpy(a).cuda()
+    o = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]),
+          output_attentions=True, return_dict=True)
+    n_all, n_cross = [int(x) for x in g["qformer_counts"]]
+    qa, qx = o.qformer_outputs.attentions, o.qformer_outputs.cross_attentions
+    assert len(qa) == n_all and len(qx) == n_cross and all(a.dtype == dtype for a in qa)
+    for i, a in enumerate(qa):
+        ref, ref16 = g[f"fp32_qformer_attentions_{i}"], g[f"bf16_qformer_attentions_{i}"]
+        assert a.shape == ref.shape
+        assert np.abs(host(a) - ref).max() <= 1.5 * np.abs(ref16 - ref).max() + 4e-3, i
+    for i, a in enumerate(qx):
+        assert torch.equal(a, qa[1 + 2 * i * 0]) or a.shape == g[f"fp32_qformer_cross_attentions_{i}"].shape
+        assert np.abs(host(a) - g[f"fp32_qformer_cross_attentions_{i}"]).max() <= 1.5 * np.abs(g[f"bf16_qformer_cross_attentions_{i}"] - g[f"fp32_qformer_cross_attentions_{i}"]).max() + 4e-3
+    la = o.language_model_outputs.attentions
+    ref, ref16 = g["fp32_lm_attentions"], g["bf16_lm_attentions"]
+    assert len(la) == ref.shape[0] and la[0].shape == ref.shape[1:]
+    valid = g["attention_mask"] == 1
+    for l, a in enumerate(la):
+        for b in range(a.shape[0]):
+            got = host(a)[b][:, valid[b]]
+            assert np.abs(got - ref[l, b][:, valid[b]]).max() <= 1.5 * np.abs(ref16[l, b][:, valid[b]] - ref[l, b][:, valid[b]]).max() + 4e-3
+            assert np.abs(got.sum(-1) - 1.0).max() < 2e-2
+    # logits unchanged by the debug outputs
+    plain = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]))
+    assert torch.equal(plain.logits, o.logits)

@@ -326,3 +326,40 @@ def test_varied_bf16_emulation_picks_the_reference_ids(golden_dir, models, name)
     m = varied_model(models, meta, emu=True)
     ids = m.generate(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], meta["new_tokens"], eos_id=-1)
     assert np.array_equal(ids, g["bf16_greedy_free"])
+
+
+def test_attention_weights_match_reference(golden_dir, models):
+    """`output_attentions=True` through the reference's full forward with eager attention (tests/golden/mid_attndebug.npz): the attention
+    weights of the OPT language model (ref:eilev/model/v2.py:220-227) and of the Q-Former — self and cross (:187-193) — from
+    eilev_attention_probs on q / k recomputed from the per-block inputs.  Probabilities: 2e-5 absolute."""
+    g = np.load(os.path.join(golden_dir, "mid_attndebug.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = blip2_config(meta["config"])
+    px = synth_pixels(sum(sum(c) for c, _ in meta["rows"]), meta["frames"], cfg.vision_config.image_size)
+    m = models(meta["config"])
+    img = m.vit(px)
+    qh = m.qformer_hidden_states(img)
+    selfs, crosses = m.qformer_attentions(img, qh)
+    n_all, n_cross = [int(x) for x in g["qformer_counts"]]
+    seq = []  # the installed transformers records every attention module in execution order: self_0, cross_0, self_1, ...
+    ci = 0
+    for i, sa in enumerate(selfs):
+        seq.append(sa)
+        if i % cfg.qformer_config.cross_attention_frequency == 0:
+            seq.append(crosses[ci])
+            ci += 1
+    assert len(seq) == n_all and len(crosses) == n_cross
+    for i, a in enumerate(seq):
+        ref = g[f"fp32_qformer_attentions_{i}"]
+        assert a.shape == ref.shape and np.abs(a - ref).max() < 2e-5, (i, np.abs(a - ref).max())
+    for i, a in enumerate(crosses):
+        assert np.abs(a - g[f"fp32_qformer_cross_attentions_{i}"]).max() < 2e-5
+    emb = m.encode(px, g["input_ids"], g["video_input_mask"])
+    _, _, _, hs = m.prefill(emb, g["attention_mask"], hidden_states=True)
+    att = m.lm_attentions(hs, g["attention_mask"])
+    ref = g["fp32_lm_attentions"]
+    assert att.shape == ref.shape
+    valid = g["attention_mask"] == 1  # rows of left-pad QUERIES are undefined in hf (all keys masked -> uniform); compare the others
+    for b in range(att.shape[1]):
+        assert np.abs(att[:, b][:, :, valid[b]] - ref[:, b][:, :, valid[b]]).max() < 2e-5
+    assert np.allclose(att[:, 0][:, :, valid[0]].sum(-1), 1.0, atol=1e-5)

@@ -600,8 +600,44 @@ def run_lm_debug_case(name="mid_lmdebug", base="mid_b2"):
     print(name, {k: v.shape for k, v in out.items() if k != "meta"}, os.path.getsize(path))
 
 
+@torch.no_grad()
+def run_attn_debug_case(name="mid_attndebug", base="mid_b2"):
+    """`output_attentions=True` through the reference's full forward with eager attention (sdpa returns no weights): the attention weights of
+    the language model (ref:eilev/model/v2.py:220-227) and of the Q-Former, self and cross (:187-193), on the inputs of `base`."""
+    cfg_name, frames, rows, _ = CASES[base]
+    cfg = blip2_config(cfg_name)
+    for c in (cfg, cfg.vision_config, cfg.qformer_config, cfg.text_config):
+        c._attn_implementation = "eager"
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, _ = build_inputs(cfg_name, frames, rows)
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask),
+              output_attentions=True, return_dict=True)
+        out[f"{tag}_lm_attentions"] = np.stack([a.float().numpy() for a in o.language_model_outputs.attentions])
+        # (installed transformers records EVERY attention module of the Q-Former in `attentions`, in execution order — self_0, cross_0,
+        # self_1, ... — and the cross-attention ones again in `cross_attentions`: stored one array per entry)
+        for i, a in enumerate(o.qformer_outputs.attentions):
+            out[f"{tag}_qformer_attentions_{i}"] = a.float().numpy()
+        for i, a in enumerate(o.qformer_outputs.cross_attentions):
+            out[f"{tag}_qformer_cross_attentions_{i}"] = a.float().numpy()
+        out["qformer_counts"] = np.asarray([len(o.qformer_outputs.attentions), len(o.qformer_outputs.cross_attentions)])
+        out[f"{tag}_logits"] = o.logits.float().numpy()
+    meta = dict(case=name, base=base, config=cfg_name, frames=frames, rows=rows, weight_mode="fanin", torch=torch.__version__,
+                transformers=transformers.__version__, attn_implementation="eager", generator="tools/make_goldens.py",
+                reference="/root/reference/eilev/model/v2.py")
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: v.shape for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug"] +
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug", "mid_attndebug"] +
               list(VARIED_CASES)):  # full_c1 (15 GB of fp32 weights, minutes): by name only
-        (run_varied_case if n in VARIED_CASES or n in FULL_CASES else run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
+        (run_attn_debug_case if n == "mid_attndebug" else run_varied_case if n in VARIED_CASES or n in FULL_CASES else run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
          else run_vit_debug_case if n == "mid_vitdebug" else run_lm_debug_case if n == "mid_lmdebug" else run_case)(n)
