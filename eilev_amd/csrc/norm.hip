@@ -248,9 +248,90 @@ __global__ __launch_bounds__(64) void reduce_ln_kernel(const float *__restrict__
     }
 }
 
+// Round 4: the same reduction with ONE 16-byte chunk per thread — a workgroup of N / 8 threads per row (N = 2560: 5 waves) instead of one
+// wave walking 5 chunks: a fifth of the loads per lane, gamma / beta requested with the partials (not after the statistics), the row
+// statistics through LDS.  The one-wave form took 9.2-9.7 us per launch at 32 rows, twice per block = 12 % of the batch-32 decode step
+// (profiles/r04_decode_b32_kernel_stats.md).  Summation order of the statistics differs from layernorm_kernel's (fp32, over 2560 values).
+template <int KS>
+__global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restrict__ part, int ks, int mr, int N, const float *__restrict__ wscale,
+                                                           const bf16 *__restrict__ bias, const bf16 *__restrict__ resid, int64_t ldr,
+                                                           bf16 *__restrict__ C, int64_t ldc, const bf16 *__restrict__ gamma,
+                                                           const bf16 *__restrict__ beta, bf16 *__restrict__ y, float eps) {
+    __shared__ float red[2][16];
+    const int c = threadIdx.x, row = blockIdx.x, lane = c & 63, wid = c >> 6, nw = (blockDim.x + 63) >> 6;
+    const bool on = c < (N >> 3);
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gv[8], bt[8];
+    if (on) {
+        auto add = [&](int s) {
+            const float4 *pp = reinterpret_cast<const float4 *>(part + ((int64_t)s * mr + row) * N + c * 8);
+            const float4 a = pp[0], b = pp[1];
+            t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
+        };
+        if constexpr (KS > 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) add(s);
+        } else {
+            for (int s = 0; s < ks; ++s) add(s);
+        }
+        float bv[8], rv[8];
+        if (bias) unpack8(*reinterpret_cast<const bf16x8 *>(bias + c * 8), bv);
+        if (resid) unpack8(*reinterpret_cast<const bf16x8 *>(resid + (int64_t)row * ldr + c * 8), rv);
+        unpack8(*reinterpret_cast<const bf16x8 *>(gamma + c * 8), gv);
+        unpack8(*reinterpret_cast<const bf16x8 *>(beta + c * 8), bt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = t[e];
+            if (wscale) x *= wscale[c * 8 + e];
+            if (bias) x += bv[e];
+            if (resid) x += rv[e];
+            t[e] = x;
+        }
+        const bf16x8 o = pack8(t);
+        *reinterpret_cast<bf16x8 *>(C + (int64_t)row * ldc + c * 8) = o;
+        unpack8(o, t);  // statistics over the ROUNDED row, like the LayerNorm kernel that read it back
+    }
+    float s1 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1 += t[e];
+    s1 = wave_sum(s1);
+    if (lane == 0) red[0][wid] = s1;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int w = 0; w < nw; ++w) tot += red[0][w];
+    const float mean = tot / (float)N;
+    float s2 = 0.0f;
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 = fmaf(t[e] - mean, t[e] - mean, s2);
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[1][wid] = s2;
+    __syncthreads();
+    tot = 0.0f;
+    for (int w = 0; w < nw; ++w) tot += red[1][w];
+    const float rstd = rsqrtf(tot / (float)N + eps);
+    if (on) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (t[e] - mean) * rstd * gv[e] + bt[e];
+        *reinterpret_cast<bf16x8 *>(y + (int64_t)row * N + c * 8) = pack8(o);
+    }
+}
+
+int g_reduce_ln_wave = 0;  // probe (eilev_debug_reduce_ln_wave): 1 = the one-wave-per-row kernel of round 2
+extern "C" int eilev_debug_reduce_ln_wave(int on) { g_reduce_ln_wave = on; return 0; }
+
 int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
                      int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s) {
     if (!part || !C || !gamma || !beta || !ln_out || M <= 0 || (N & 7) || N > 8 * 512) return EILEV_E_UNSUPPORTED;
+    if (!g_reduce_ln_wave) {
+        const int threads = (((N >> 3) + 63) / 64) * 64;
+#define EILEV_RLW(KS_) hipLaunchKernelGGL((reduce_ln_wg_kernel<KS_>), dim3(M), dim3(threads), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)
+        if (ks == 2) EILEV_RLW(2); else if (ks == 4) EILEV_RLW(4); else EILEV_RLW(0);
+#undef EILEV_RLW
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
 #define EILEV_RLN(MC, KS_) hipLaunchKernelGGL((reduce_ln_kernel<MC, KS_>), dim3(M), dim3(64), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)
     if (N <= 3 * 512) { if (ks == 2) EILEV_RLN(3, 2); else if (ks == 4) EILEV_RLN(3, 4); else EILEV_RLN(3, 0); }
     else if (N <= 5 * 512) { if (ks == 2) EILEV_RLN(5, 2); else if (ks == 4) EILEV_RLN(5, 4); else EILEV_RLN(5, 0); }

@@ -18,7 +18,11 @@ am = torch.ones(B, L, dtype=torch.int32, device=dev)
 outs = {}
 for rd in range(6):
     flag = (1 << 28) if rd % 2 else 0
-    raw.eilev_debug_gemm_flags(flag); eng._dec_cache = None
+    if os.environ.get("PROBE_SWITCH") == "reduce_ln":  # A/B of the split-K reduce + LayerNorm kernel instead (odd rounds: one wave per row)
+        raw.eilev_debug_reduce_ln_wave(1 if rd % 2 else 0)
+    else:
+        raw.eilev_debug_gemm_flags(flag)
+    eng._dec_cache = None
     e0, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     eng.timing = []; e0.record()
     out = eng.greedy_decode(emb, am, NEW, eos_id=-1, pad_id=1, use_graph=True)
@@ -26,5 +30,5 @@ for rd in range(6):
     pre = e0.elapsed_time(dict(eng.timing)["prefill_done"])
     outs[flag] = out.cpu()
     print(f"round {rd} ({'round-3 kernels' if flag else 'rows32'}): decode {(e0.elapsed_time(e2) - pre) / (NEW - 1):.3f} ms/token", flush=True)
-raw.eilev_debug_gemm_flags(0)
+raw.eilev_debug_gemm_flags(0); raw.eilev_debug_reduce_ln_wave(0)
 print("ids equal between the two:", float((outs[0] == outs[1 << 28]).float().mean()))
