@@ -211,7 +211,8 @@ int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, con
 // gemv.hip, M = 1: activations in registers, a 4-deep ring of weight sub-blocks, one workgroup per CU (round 4)
 bool gemv1_ok(int N, int K, int pro);
 int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid, void *out,
-                 int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s);
+                 int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s, const float *part = nullptr, int heads = 0, int hd = 0,
+                 int nsplit = 0);  // pro = 2: x = the merge of `part` (flash-decoding partials of one row: heads x nsplit x (hd + 2) floats)
 bool gemvm_ok(int M, int N, int K, int pro);  // 2 <= M <= 8 rows with the same geometry, rows staged in LDS (round 4)
 int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid,
                  int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N, int K, int epi, float scale, int scale_cols, hipStream_t s);
@@ -219,6 +220,9 @@ int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const b
 bool attn_decode1_ok(int batch, int cap, int hd);
 int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state, int batch, int seq_len,
                         int cap, int heads, int hd, hipStream_t s);
+int attn_decode_part_splits(int cap);  // misc.hip: the one-pass loading scheme over 128-key ranges, partials for gemv1_kernel's merge prologue (round 4)
+int launch_attn_decode_part(const bf16 *qkv, bf16 *kc, bf16 *vc, float *part, size_t part_bytes, const int32_t *attn_mask, const int32_t *state, int batch,
+                            int seq_len, int cap, int heads, int hd, hipStream_t s);
 int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, bf16 *y, int64_t ldy, int64_t rows,
                      int cols, float eps, hipStream_t s);
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,

@@ -326,6 +326,48 @@ __global__ __launch_bounds__(320) void gemv1_kernel(const GemvArgs a) {
                 for (int e = 0; e < 8; ++e) v[e] = (bf16)((f[e] - mean) * rstd * gm[e] + bt[e]);
                 xr[c] = __builtin_bit_cast(u32x4_t, v);
             }
+        } else if constexpr (PRO == PRO_MERGE) {
+            // x = the attention row, merged HERE from the flash-decoding partials of attn_decode_part_kernel (o = sum_s w_s o_s / sum_s w_s l_s,
+            // w_s = exp(max_s - max): attn_decode_merge_kernel's arithmetic).  Wave w of the workgroup merges chunk w — its lane's 8 elements
+            // belong to one head (hd % 8 == 0), all 8 x 5 loads of the (up to) 8 splits in flight at once — and the five chunks meet in LDS:
+            // one L2 round trip and one barrier.  (Every wave merging all five chunks in a run-time loop over the splits: 31.7 us per launch.)
+            static_assert(NCH == 5, "one chunk per wave of the 320-thread workgroup");
+            __shared__ __attribute__((aligned(16))) bf16 xm[NCH * 512];
+            const int wv_ = threadIdx.x >> 6, ns = a.nsplit;
+            {
+                const int k = wv_ * 512 + lane * 8, hh = k / a.hd, t0 = k - hh * a.hd;
+                const float *pp = a.part + (int64_t)hh * ns * (a.hd + 2);
+                float2 ml[8], ov[8][4];
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const float *pq = pp + (sp < ns ? sp : 0) * (a.hd + 2);
+                    ml[sp] = *reinterpret_cast<const float2 *>(pq);
+                    const float2 *po2 = reinterpret_cast<const float2 *>(pq + 2 + t0);  // (hd + 2 and t0 are even: 8-byte aligned)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ov[sp][q] = po2[q];
+                }
+                float mx = -1e30f;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) mx = fmaxf(mx, sp < ns ? ml[sp].x : -1e30f);
+                float l = 0.0f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const float wgt = (sp < ns && ml[sp].y > 0.0f) ? __expf(ml[sp].x - mx) : 0.0f;
+                    l += wgt * ml[sp].y;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[2 * q] += wgt * ov[sp][q].x;
+                        o[2 * q + 1] += wgt * ov[sp][q].y;
+                    }
+                }
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)(l > 0.0f ? o[e] / l : 0.0f);
+                *reinterpret_cast<bf16x8 *>(xm + k) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const u32x4_t *>(xm + c * 512 + lane * 8);
         } else {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const u32x4_t *>(a.x + c * 512 + lane * 8);
@@ -638,8 +680,11 @@ bool gemv1_ok(int N, int K, int pro) {
     return pro == PRO_X && (nch == 5 || nch == 8 || nch == 20);  // (K = 16384: 128 registers of x alone — the LDS kernel above)
 }
 int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid, void *out,
-                 int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s) {
-    if (!gemv1_ok(N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
+                 int out_f32, int N, int K, int epi, float scale, int scale_cols, hipStream_t s, const float *part, int heads, int hd, int nsplit) {
+    if (pro == PRO_MERGE) {
+        if (nsplit < 1 || nsplit > 8) return EILEV_E_UNSUPPORTED;
+        if (!part || heads * hd != K || (hd & 7) || (K >> 9) != 5 || K % 512 || !W || !out || ((uintptr_t)W & 15) || ((uintptr_t)part & 7)) return EILEV_E_UNSUPPORTED;
+    } else if (!gemv1_ok(N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
     if ((bias && ((uintptr_t)bias & 3)) || (resid && ((uintptr_t)resid & 3)) || (pro == PRO_LN && (!gamma || !beta))) return EILEV_E_BADARG;
     static int n_cu = 0;
     if (!n_cu) {
@@ -652,12 +697,14 @@ int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, fl
     GemvArgs a = {};
     a.x = x; a.ldx = K; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.out = out; a.ldo = N;
     a.out_f32 = out_f32; a.M = 1; a.N = N; a.K = K; a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;
+    a.part = part; a.heads = heads; a.hd = hd; a.nsplit = nsplit;
     int grid = n_cu;
     if ((int64_t)grid * 5 > N) grid = (N + 4) / 5;
     a.rows_per_wave = N / (grid * 5);
     a.KB = N % (grid * 5);  // (field reused: the first KB waves own one row more)
     const int nch = K >> 9;
     if (pro == PRO_LN) return launch_gemv1_c<5, PRO_LN>(a, grid, s);
+    if (pro == PRO_MERGE) return launch_gemv1_c<5, PRO_MERGE>(a, grid, s);
     switch (nch) {
         case 5: return launch_gemv1_c<5, PRO_X>(a, grid, s);
         case 8: return launch_gemv1_c<8, PRO_X>(a, grid, s);

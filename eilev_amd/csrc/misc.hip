@@ -486,6 +486,112 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
     }
 }
 
+// The same loading scheme over a RANGE of keys: 256 threads own keys [128 sp, 128 sp + 128) of one (row, head) and leave the un-normalised
+// partial (max, sum, o[hd]) in `part` — the flash-decoding format of attn_decode_split_kernel, merged by the consumer (gemv1_kernel's prologue
+// of out_proj).  One workgroup per head pulls 307 KB through ONE CU (12.1 us at batch 1); 8 splits put 38 KB on each of 256 CUs.
+template <int NCH, int VK>
+__global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
+                                                               float *__restrict__ part, const int32_t *__restrict__ attn_mask,
+                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
+    constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1, KEYS = 128;
+    static_assert(G * VK >= KEYS, "every key of the range needs an owner");
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ float ps[KEYS];
+    __shared__ float wred[8];
+    __shared__ float red[KEYS * RS > G * hd ? KEYS * RS : G * hd];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z, d = heads * hd;
+    const int kv_total = min(cap, seq_len + state[0]);
+    const int slot_new = kv_total - 1;
+    const int k0 = sp * KEYS, k1 = min(kv_total, k0 + KEYS);
+    float *po = part + (((int64_t)b * heads + h) * nsplit + sp) * (hd + 2);
+    if (k0 >= kv_total) {  // nothing in this split yet
+        if (tid == 0) {
+            po[0] = -1e30f;
+            po[1] = 0.0f;
+        }
+        return;
+    }
+    bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
+    const int c = tid % NCH, kg = tid / NCH;
+    bf16x8 kr[VK], vr[VK];
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        int key = k0 + kg + i * G;
+        key = key < k1 ? key : k1 - 1;
+        kr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? knew : kbase + (int64_t)key * hd) + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        int key = k0 + kg + i * G;
+        key = key < k1 ? key : k1 - 1;
+        vr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? vnew : vbase + (int64_t)key * hd) + c * 8);
+    }
+    const int jt = k0 + tid;  // thread t < KEYS owns key k0 + t for the softmax
+    const bool vis = tid < KEYS && jt < k1 && (jt >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + jt] != 0);
+    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
+    if (slot_new >= k0 && slot_new < k1 && tid >= 256 - 2 * NCH) {  // the split that owns the newest slot stores it to the cache
+        const int t2 = tid - (256 - 2 * NCH), which = t2 / NCH, cc = t2 - which * NCH;
+        *reinterpret_cast<bf16x8 *>((which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
+    }
+    __syncthreads();
+    if (kg < G) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]), q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+#pragma unroll
+        for (int i = 0; i < VK; ++i) {
+            const int kk = kg + i * G;
+            float kv[8];
+            unpack8(kr[i], kv);
+            if (kk < KEYS) red[kk * RS + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
+        }
+    }
+    __syncthreads();
+    float s = -1e30f;
+    if (tid < KEYS) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) acc += red[tid * RS + cc];
+        s = vis ? acc : -1e30f;
+    }
+    const float mxw = wave_max(s);
+    if (lane == 0) wred[wid] = mxw;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    const float p = s > -1e29f ? __expf(s - mx) : 0.0f;
+    if (tid < KEYS) ps[tid] = (float)(bf16)p;
+    const float sw = wave_sum(p);
+    if (lane == 0) wred[4 + wid] = sw;
+    __syncthreads();
+    const float lsum = wred[4] + wred[5] + wred[6] + wred[7];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+        const int kk = kg + i * G;
+        const float pj = (kk < KEYS && k0 + kk < k1) ? ps[kk] : 0.0f;
+        float vv[8];
+        unpack8(vr[i], vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
+    }
+    if (kg < G) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[kg * hd + c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float v = 0.0f;
+        for (int k2 = 0; k2 < G; ++k2) v += red[k2 * hd + tid];
+        po[2 + tid] = v;
+    }
+    if (tid == 0) {
+        po[0] = mx;
+        po[1] = lsum;
+    }
+}
+
 __global__ __launch_bounds__(128) void attn_decode_merge_kernel(const float *__restrict__ part, bf16 *__restrict__ out,
                                                                 int heads, int hd, int nsplit) {
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
@@ -765,6 +871,18 @@ int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const in
     const int64_t ldq = 3 * (int64_t)heads * hd;
     if (hd == 80) hipLaunchKernelGGL((attn_decode1_kernel<10, 12>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
     else hipLaunchKernelGGL((attn_decode1_kernel<8, 8>), dim3(heads, batch), dim3(1024), 0, s, qkv, kc, vc, out, attn_mask, state, seq_len, cap, heads, ldq);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+// partials of a small-batch decode step for a consumer that merges them itself: nsplit = ceil(cap / 128) splits of (hd + 2) floats
+int attn_decode_part_splits(int cap) { return (cap + 127) / 128; }
+int launch_attn_decode_part(const bf16 *qkv, bf16 *kc, bf16 *vc, float *part, size_t part_bytes, const int32_t *attn_mask, const int32_t *state, int batch,
+                            int seq_len, int cap, int heads, int hd, hipStream_t s) {
+    if (hd != 80 || cap > 1024 || !state || !part) return EILEV_E_UNSUPPORTED;
+    const int ns = attn_decode_part_splits(cap);
+    if (part_bytes < (size_t)batch * heads * ns * (hd + 2) * sizeof(float)) return EILEV_E_WORKSPACE;
+    hipLaunchKernelGGL((attn_decode_part_kernel<10, 6>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, kc, vc, part, attn_mask, state, seq_len, cap, heads,
+                       3 * (int64_t)heads * hd);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

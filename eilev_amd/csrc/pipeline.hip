@@ -871,8 +871,15 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
             const int Ft = d->t_ffn;
             RC(launch_gemv1(1, b.h, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, d->t_eps, (const bf16 *)L->q_w, (const bf16 *)L->q_b, nullptr, b.qkv, 0, 3 * D, D, 0,
                             1.0f / sqrtf((float)hd), D, s));
-            RC(launch_attn_decode1(b.qkv, kc, vc, b.att, attn_mask, state, 1, (int)seq_len, (int)kv_capacity, H, hd, s));
-            RC(launch_gemv1(0, b.att, nullptr, nullptr, 0.f, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, b.h, 0, D, D, 0, 1.0f, 0, s));
+            if (hd == 80 && g_decode_rows != 5) {  // 128-key splits over all CUs, merged in out_proj's prologue (eilev_debug_decode_rows(5): one workgroup per head)
+                float *part = b.scratch + kSkinnyScratch / 2 / sizeof(float);
+                RC(launch_attn_decode_part(b.qkv, kc, vc, part, kSkinnyScratch / 2, attn_mask, state, 1, (int)seq_len, (int)kv_capacity, H, hd, s));
+                RC(launch_gemv1(2, nullptr, nullptr, nullptr, 0.f, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, b.h, 0, D, D, 0, 1.0f, 0, s, part, H, hd,
+                                attn_decode_part_splits((int)kv_capacity)));
+            } else {
+                RC(launch_attn_decode1(b.qkv, kc, vc, b.att, attn_mask, state, 1, (int)seq_len, (int)kv_capacity, H, hd, s));
+                RC(launch_gemv1(0, b.att, nullptr, nullptr, 0.f, (const bf16 *)L->o_w, (const bf16 *)L->o_b, b.h, b.h, 0, D, D, 0, 1.0f, 0, s));
+            }
             RC(launch_gemv1(1, b.h, (const bf16 *)L->ln2_w, (const bf16 *)L->ln2_b, d->t_eps, (const bf16 *)L->fc1_w, (const bf16 *)L->fc1_b, nullptr, b.ffn, 0, Ft, D, 2,
                             1.0f, 0, s));
             RC(launch_gemv1(0, b.ffn, nullptr, nullptr, 0.f, (const bf16 *)L->fc2_w, (const bf16 *)L->fc2_b, b.h, b.h, 0, D, Ft, 0, 1.0f, 0, s));
