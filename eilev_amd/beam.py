@@ -117,9 +117,16 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
         best_running = run_score[:, :1] / float(ref_len) ** length_penalty
         worst_done = torch.where(finished, fin_score.min(dim=1, keepdim=True).values, torch.full_like(fin_score, NEG))
         can_improve = can_improve & torch.any(best_running > worst_done, dim=1, keepdim=True)
-        open_beam = not (bool(torch.all(finished)) and early_stopping is True)
-        if not (bool(torch.any(can_improve)) and open_beam and not bool(torch.all(hit))):
+        if cur >= T:  # the budget: every candidate of this step was forced to finish (hit is all ones) — known on the host, no read-back
             break
+        # The early exits (nothing can improve any more; early_stopping=True and every beam finished) read device values back: a host
+        # synchronisation per step, during which the GPU idles behind the ~20 small selection kernels above.  They are looked at every 4th
+        # step only: once an exit condition holds it keeps holding and the finished set is frozen (done_lp is masked by ~can_improve /
+        # all-finished), so up to three extra steps change nothing that is returned.
+        if cur % 4 == 0:
+            open_beam = not (bool(torch.all(finished)) and early_stopping is True)
+            if not (bool(torch.any(can_improve)) and open_beam):
+                break
         logits = step(run_seq[:, :, cur - 1].reshape(-1), (beam_src + offs).reshape(-1)).float()
 
     out = fin_seq[:, :num_return_sequences].reshape(B * num_return_sequences, T)
