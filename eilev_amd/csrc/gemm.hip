@@ -1979,6 +1979,9 @@ static bool rows32_plan(const GemmArgs &g, int nb, int n_cu, SkinnyArgs &a, int 
             if (nb * c >= n_cu || per_wave / c == 5 || !(g.dbg & 134217728)) break;
         }
     if (!k5) return false;
+    // fewer blocks than CUs (out_proj: 160): the unsplit form leaves a third of the chip idle and needs a separate LayerNorm launch after it
+    // (9.4 us: the split-K reduce of the round-2 kernel produces the LayerNorm for free) — those shapes keep the round-2 / round-3 kernels
+    if (k5 == 1 && nb < n_cu && g.ln_out && !(g.dbg & 134217728)) return false;
     if (k5 > 1 && !(g.dbg & 134217728)) return false;  // measured: the split-K forms (out_proj, fc2) lose to the round-3 kernels in the step; probe flag 1 << 27 enables them
     if (k5 > 1 && (!g.scratch || (size_t)k5 * a.mr * g.N * sizeof(float) > g.scratch_bytes)) return false;
     ks = k5;
