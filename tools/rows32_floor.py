@@ -1,6 +1,11 @@
 #!/usr/bin/env python
 """GPU probe: eilev_linear at M = 32 on the decode shapes: round-3 kernels (flag 1 << 28) vs gemm_rows32_kernel vs the same kernel without
-its activation loads / without its weight loads (variant libraries), weights rotated through > 256 MB so no cache serves them."""
+its activation loads / without its weight loads (variant libraries), weights rotated through > 256 MB so no cache serves them.
+
+    python eilev_amd/csrc/build.py --force --variant nox -DROWS32_NOX=1     # (add -DROWS32_NOW=1 as well for the kernel with NO operand loads)
+    python eilev_amd/csrc/build.py --force --variant now -DROWS32_NOW=1
+    python tools/rows32_floor.py
+"""
 import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
