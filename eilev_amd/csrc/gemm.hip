@@ -1804,11 +1804,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_nb_kernel(const SkinnyArgs a)
         // one barrier per weight block; the partials ping-pong between two LDS regions, so the waves that finish block j (below) are
         // done before anybody writes region j & 1 again (after the barrier of block j + 1)
         __syncthreads();
-        if (wid < MB && j < nbl) {  // wave mb finishes row tile mb of this block: the 4 K-quarter partials summed in a fixed order
-            const int mb = wid;
+        if (j < nbl) {  // (round 4) the MB x 4 (row tile, register) pairs of this block dealt over the four waves: the 4 K-quarter partials in a fixed order
             const int col = (b0 + j) * 16 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int cb = 0; cb < MB; ++cb) {
+                const int mb = (wid * MB + cb) >> 2, r = (wid * MB + cb) & 3;
                 float v = 0.0f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) v += red[j & 1][w][mb][lane][r];
