@@ -248,7 +248,7 @@ EXPORTS = [
     "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_prefill_debug", "eilev_opt_extend", "eilev_greedy_select",
     "eilev_opt_decode_step", "eilev_opt_decode_step_beam", "eilev_linear", "eilev_linear_rows", "eilev_layernorm", "eilev_attention", "eilev_attention_probs", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
-    "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_process_workspace_bytes", "eilev_process_frames",
+    "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_t5_encode_debug", "eilev_t5_decode_debug", "eilev_process_workspace_bytes", "eilev_process_frames",
     "eilev_linear_w8_scratch_bytes", "eilev_linear_w8", "eilev_quant_rows_e4m3", "eilev_linear_a8w8", "eilev_attention_bwd", "eilev_layernorm_bwd", "eilev_colsum",
     "eilev_act_fwd", "eilev_act_bwd", "eilev_ce_loss", "eilev_attention_rel", "eilev_attention_rel_bwd", "eilev_rmsnorm",
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
@@ -395,6 +395,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_t5_self_kv_bytes.argtypes = [TP, i64, i64]
     lib.eilev_t5_decode.restype = i32
     lib.eilev_t5_decode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.eilev_t5_encode_debug.restype = i32
+    lib.eilev_t5_encode_debug.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, vp, vp, vp, sz, vp]
+    lib.eilev_t5_decode_debug.restype = i32
+    lib.eilev_t5_decode_debug.argtypes = [TP, C.POINTER(T5Weights), vp, vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, vp, sz, vp]
     lib.eilev_t5_decode_step.restype = i32
     lib.eilev_t5_decode_step.argtypes = [TP, C.POINTER(T5Weights), vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, sz, vp]
     lib.eilev_comm_bind.restype = i32
@@ -418,7 +422,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 12:
+    if lib.eilev_abi_version() != 13:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

@@ -1265,8 +1265,11 @@ extern "C" size_t eilev_t5_workspace_bytes(const EilevT5Dims *d, int64_t batch, 
            16 * 256;
 }
 
-extern "C" int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
-                               int64_t batch, int64_t enc_len, void *enc_out, void *workspace, size_t workspace_bytes, void *stream) {
+// hidden_out (nullable): (enc_layers + 1, batch, enc_len, D) = hf T5Stack's hidden_states tuple: every block's input, then the output of
+// final_layer_norm (modeling_t5.py T5Stack.forward: all_hidden_states)
+static int t5_encode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                          int64_t batch, int64_t enc_len, void *enc_out, void *hidden_out, void *workspace, size_t workspace_bytes,
+                          void *stream) {
     if (!d || !w || !inputs_embeds || !attn_mask || !enc_out || !workspace || batch <= 0 || enc_len <= 0) return EILEV_E_BADARG;
     if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -1278,8 +1281,10 @@ extern "C" int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, co
     // bias(i, j) depends on j - i in [-(L-1), L-1]: table index (j - i) + L - 1
     RC(launch_t5_rel_table((const bf16 *)w->enc_rel_bias, b.rel, (int)(2 * enc_len - 1), (int)enc_len - 1, H, 1, d->rel_buckets,
                            d->rel_max_dist, s));
+    const size_t hid_bytes = (size_t)M * D * sizeof(bf16);
     for (int l = 0; l < d->enc_layers; ++l) {
         const EilevT5Layer *L = &w->enc_layers[l];
+        if (hidden_out) EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + l * hid_bytes, b.h, hid_bytes, hipMemcpyDeviceToDevice, s));
         RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
         AttnArgs a;
@@ -1294,7 +1299,20 @@ extern "C" int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, co
         RC(launch_gemm(t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I), 5, s));
         RC(t5_ff(d, L, b, M, s));
     }
-    return launch_rmsnorm(b.h, D, (const bf16 *)w->enc_final_ln, (bf16 *)enc_out, D, M, D, d->eps, s);
+    RC(launch_rmsnorm(b.h, D, (const bf16 *)w->enc_final_ln, (bf16 *)enc_out, D, M, D, d->eps, s));
+    if (hidden_out)
+        EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + d->enc_layers * hid_bytes, enc_out, hid_bytes, hipMemcpyDeviceToDevice, s));
+    return EILEV_OK;
+}
+
+extern "C" int eilev_t5_encode(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                               int64_t batch, int64_t enc_len, void *enc_out, void *workspace, size_t workspace_bytes, void *stream) {
+    return t5_encode_impl(d, w, inputs_embeds, attn_mask, batch, enc_len, enc_out, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int eilev_t5_encode_debug(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                                     int64_t batch, int64_t enc_len, void *enc_out, void *hidden_out, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    return t5_encode_impl(d, w, inputs_embeds, attn_mask, batch, enc_len, enc_out, hidden_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t eilev_t5_cross_kv_bytes(const EilevT5Dims *d, int64_t batch, int64_t enc_len) {
@@ -1331,8 +1349,9 @@ extern "C" int eilev_t5_cross_kv(const EilevT5Dims *d, const EilevT5Weights *w, 
 static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
                           int64_t batch, int64_t new_len, int64_t past_len, const int32_t *state, void *self_kv, int64_t kv_capacity,
                           const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
-                          void *stream) {
+                          void *stream, const int32_t *dec_mask = nullptr, void *hidden_out = nullptr) {
     if (!d || !w || !dec_ids || !enc_mask || !self_kv || !cross_kv || !logits || !workspace) return EILEV_E_BADARG;
+    if (state && (dec_mask || hidden_out)) return EILEV_E_BADARG;
     if (batch <= 0 || new_len <= 0 || past_len < 0 || past_len + new_len > kv_capacity || enc_len <= 0) return EILEV_E_BADARG;
     if (state && (new_len != 1 || past_len != 0)) return EILEV_E_BADARG;
     if (!dims_ok_t5(d)) return EILEV_E_UNSUPPORTED;
@@ -1352,10 +1371,12 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
     const int64_t kmax = kv_capacity > enc_len ? kv_capacity : enc_len;
     const bool single = new_len == 1 && attn_decode_scratch_bytes((int)batch, H, hd, (int)kmax) <= kSkinnyScratch / 2;
     if (state && !single) return EILEV_E_UNSUPPORTED;
+    const size_t hid_bytes = (size_t)M * D * sizeof(bf16);
     for (int l = 0; l < d->dec_layers; ++l) {
         const EilevT5Layer *L = &w->dec_layers[l];
         bf16 *kc = (bf16 *)self_kv + 2 * (size_t)l * splane, *vc = kc + splane;
         const bf16 *ck = (const bf16 *)cross_kv + 2 * (size_t)l * cplane, *cv = ck + cplane;
+        if (hidden_out) EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + l * hid_bytes, b.h, hid_bytes, hipMemcpyDeviceToDevice, s));
         // ---- self-attention against the cache (T5LayerSelfAttention :372-401)
         RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
@@ -1367,7 +1388,7 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
                 RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, state, (int)batch, 1, (int)kv_capacity, H, hd, b.scratch + skinny_f,
                                       kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, -1));
             else
-                RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd,
+                RC(launch_attn_decode(b.qkv, kc, vc, b.att, dec_mask, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd,
                                       b.scratch + skinny_f, kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, (int)total - 1));
         } else {
         AttnArgs a;
@@ -1377,7 +1398,7 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
             a.q_hs = a.o_hs = hd; a.k_hs = a.v_hs = kv_capacity * (int64_t)hd;
             a.ldq = 3 * I; a.ldk = a.ldv = hd; a.ldo = I;
             a.batch = (int)batch; a.heads = H; a.sq = (int)new_len; a.skv = (int)total; a.hd = hd; a.scale = 1.0f; a.causal = 1;
-            a.key_mask = nullptr; a.mask_ld = 0; a.dbg = 0;
+            a.key_mask = dec_mask; a.mask_ld = dec_mask ? total : 0; a.dbg = 0;  // decoder_attention_mask: keys of padded target positions
             a.rel_tab = b.rel; a.rel_hs = total; a.rel_off = (int)total - 1; a.rel_n = (int)total;
             RC(launch_attention(a, s));
         }
@@ -1403,6 +1424,7 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
         RC(t5_ff(d, L, b, M, s));
     }
     RC(launch_rmsnorm(b.h, D, (const bf16 *)w->dec_final_ln, b.x, D, M, D, d->eps, s));
+    if (hidden_out) EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + d->dec_layers * hid_bytes, b.x, hid_bytes, hipMemcpyDeviceToDevice, s));
     GemmArgs g = t5_gemm(b, b.x, D, w->lm_head, D, nullptr, 0, logits, d->vocab, M, d->vocab, D);
     g.out_f32 = 1;
     if (d->scale_decoder_outputs) { g.scale = 1.0f / sqrtf((float)D); g.scale_cols = d->vocab; }
@@ -1415,6 +1437,17 @@ extern "C" int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, co
                                void *stream) {
     return t5_decode_impl(d, w, dec_ids, enc_mask, batch, new_len, past_len, nullptr, self_kv, kv_capacity, cross_kv, enc_len, logits,
                           workspace, workspace_bytes, stream);
+}
+
+// eilev_t5_decode + decoder_attention_mask (dec_mask (batch, past_len + new_len) int32, nullable: keys of the target the self-attention must
+// not see, on top of the causal rule; hf T5Stack: create_causal_mask(attention_mask = decoder_attention_mask)) + the per-block tensors
+// (hidden_out (dec_layers + 1, batch, new_len, D), nullable)
+extern "C" int eilev_t5_decode_debug(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                                     const int32_t *dec_mask, int64_t batch, int64_t new_len, int64_t past_len, void *self_kv,
+                                     int64_t kv_capacity, const void *cross_kv, int64_t enc_len, float *logits, void *hidden_out,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    return t5_decode_impl(d, w, dec_ids, enc_mask, batch, new_len, past_len, nullptr, self_kv, kv_capacity, cross_kv, enc_len, logits,
+                          workspace, workspace_bytes, stream, dec_mask, hidden_out);
 }
 
 extern "C" int eilev_t5_decode_step(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *tokens, const int32_t *state,

@@ -731,6 +731,39 @@ class HipEngine:
         skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T)), dtype=torch.uint8, device=self.device)
         return self.t5_decode(decoder_input_ids, attention_mask, 0, skv, T, ckv, enc.shape[1]), enc
 
+    def t5_forward_debug(self, inputs_embeds, attention_mask, decoder_input_ids, decoder_attention_mask=None, hidden_states=False):
+        """t5_forward with what the reference's forward can also pass down (ref:eilev/model/v2.py:228-238): decoder_attention_mask (B, T)
+        and output_hidden_states -> (logits, enc, encoder hidden_states (layers + 1, B, L, D) | None, decoder hidden_states | None)."""
+        d = self.t5dims
+        x = inputs_embeds.contiguous()
+        B, L, D = x.shape
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        enc = torch.empty_like(x)
+        enc_hs = torch.empty((d.enc_layers + 1, B, L, D), dtype=x.dtype, device=self.device) if hidden_states else None
+        ws = self._workspace("t5", self.lib.eilev_t5_workspace_bytes(C.byref(d), B, L, L))
+        abi.check(self.lib.eilev_t5_encode_debug(C.byref(d), C.byref(self.pack.t5), _ptr(x), _ptr(am), B, L, _ptr(enc),
+                                                 _ptr(enc_hs) if hidden_states else None, _ptr(ws), ws.numel(), self._stream()), "eilev_t5_encode_debug")
+        ckv = self.t5_cross_kv(enc)
+        ids = decoder_input_ids.to(self.device, torch.int64).contiguous()
+        T = ids.shape[1]
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= d.vocab):
+            raise IndexError("decoder_input_ids out of range")
+        dm = None
+        if decoder_attention_mask is not None:
+            dm = (decoder_attention_mask.to(self.device) != 0).to(torch.int32).contiguous()
+            if dm.shape != ids.shape:
+                raise ValueError(f"decoder_attention_mask {tuple(dm.shape)} does not match decoder_input_ids {tuple(ids.shape)}")
+            if not bool(dm[:, 0].all()):  # a query row with no visible key at all: hf adds two finfo.min there, not a defined attention
+                raise NotImplementedError("decoder_attention_mask must keep the first target position of every row")
+        skv = torch.empty(int(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T)), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((B, T, d.vocab), dtype=torch.float32, device=self.device)
+        dec_hs = torch.empty((d.dec_layers + 1, B, T, D), dtype=x.dtype, device=self.device) if hidden_states else None
+        ws = self._workspace("t5", self.lib.eilev_t5_workspace_bytes(C.byref(d), B, T, max(L, T)))
+        abi.check(self.lib.eilev_t5_decode_debug(C.byref(d), C.byref(self.pack.t5), _ptr(ids), _ptr(am), None if dm is None else _ptr(dm), B, T, 0,
+                                                 _ptr(skv), T, _ptr(ckv), L, _ptr(logits), _ptr(dec_hs) if hidden_states else None, _ptr(ws),
+                                                 ws.numel(), self._stream()), "eilev_t5_decode_debug")
+        return logits, enc, enc_hs, dec_hs
+
     def t5_greedy(self, inputs_embeds, attention_mask, max_new_tokens, eos_id=1, pad_id=0, start_id=0, use_graph=True, poll_every=8):
         """Greedy generation for the encoder-decoder LM [ref:eilev/model/v2.py:318-322 -> hf _sample]: returns decoder ids
         (B, 1 + n) INCLUDING the start token, like HF does for encoder-decoder models.  One decoder step + token selection

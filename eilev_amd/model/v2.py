@@ -10,7 +10,8 @@ state-dict names; none of them has arithmetic in its ``forward``
 
 Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling
 are).  ``output_hidden_states`` / ``output_attentions`` inside the full model's ``forward`` are served from slow paths for the vision wrapper,
-the Q-Former (self- and cross-attention weights) and the OPT language model; the T5 stacks' per-block tensors stay ``None``.
+the Q-Former (self- and cross-attention weights), the OPT language model and the T5 stacks' hidden states; the T5 stacks' attention weights stay
+``None``.  ``decoder_attention_mask`` with padding is honoured on the evaluation route (the first target position of a row must stay visible).
 """
 from __future__ import annotations
 
@@ -322,6 +323,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         # _wants_graph: `model.eval()` + `loss.backward()` (fine-tuning with dropout off) gets a loss with a graph too; the module
         # mode decides whether dropout is applied, as in the reference
         if labels is not None and torch.is_grad_enabled() and self._wants_graph():
+            if decoder_input_ids is not None or (decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all())):
+                # (the reference's collators emit neither: ref:eilev/data/utils.py:148-200; hf derives decoder_input_ids from labels)
+                raise NotImplementedError("the training graph shifts `labels` into decoder_input_ids itself: explicit decoder_input_ids / a padded "
+                                          "decoder_attention_mask are served by the evaluation route only (torch.no_grad())")
             return self._forward_train(input_ids, attention_mask, pixel_values, video_input_mask, labels, return_dict)
         return self._forward_eval(input_ids, attention_mask, pixel_values, video_input_mask, decoder_input_ids, decoder_attention_mask,
                                   output_attentions, output_hidden_states, labels, return_dict)
@@ -379,7 +384,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper) and the Q-Former output carries hidden_states (r3: the stack
         # re-run with its first i blocks) and the OPT language model's output carries hidden_states (r3: eilev_opt_prefill_debug); r4: the
         # attention weights of the Q-Former (self and cross) and of the OPT language model (eilev_attention_probs on q / k recomputed from the
-        # per-block inputs).  The T5 stacks' per-block tensors are not exported: those stay None
+        # per-block inputs); the T5 stacks serve hidden_states (eilev_t5_*_debug), their attention weights stay None
         self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
@@ -388,7 +393,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if self._is_t5:
-            return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict)
+            return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict,
+                                    bool(output_hidden_states))
         lm_hidden = lm_attn = None
         if output_hidden_states or output_attentions:  # hf OPTDecoder's tuple: every block's input, then the output of final_layer_norm
             _, logits32, _, hs = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False, hidden_states=True)
@@ -424,12 +430,13 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         return Blip2ForConditionalGenerationModelOutput(loss=loss, logits=logits, vision_outputs=vis_out, qformer_outputs=qf_out,
                                                         language_model_outputs=lm_out)
 
-    def _forward_t5(self, emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict):
-        """Encoder-decoder branch [ref:eilev/model/v2.py:228-238 -> hf T5ForConditionalGeneration.forward :939-1055]."""
+    def _forward_t5(self, emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict,
+                    output_hidden_states=False):
+        """Encoder-decoder branch [ref:eilev/model/v2.py:228-238 -> hf T5ForConditionalGeneration.forward :939-1055].  decoder_attention_mask
+        with padding and output_hidden_states (both stacks' tuples) go through the *_debug entries (round 4); the T5 stacks' attention
+        weights are not exported (None)."""
         from transformers.modeling_outputs import Seq2SeqLMOutput
 
-        if decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all()):
-            raise NotImplementedError("decoder_attention_mask with padding inside the target is not built on the HIP path")
         t = self.config.text_config
         if decoder_input_ids is None:
             if labels is None:
@@ -439,7 +446,13 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             decoder_input_ids = torch.cat((torch.full_like(labels[:, :1], start), labels[:, :-1]), dim=1)
             decoder_input_ids = decoder_input_ids.masked_fill(decoder_input_ids == -100, t.pad_token_id)
         dtype = self.dtype
-        logits32, enc = self.engine().t5_forward(emb, attention_mask, decoder_input_ids)
+        enc_hs = dec_hs = None
+        padded = decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all())
+        if padded or output_hidden_states:
+            logits32, enc, enc_hs, dec_hs = self.engine().t5_forward_debug(emb, attention_mask, decoder_input_ids,
+                                                                         decoder_attention_mask if padded else None, output_hidden_states)
+        else:
+            logits32, enc = self.engine().t5_forward(emb, attention_mask, decoder_input_ids)
         loss = None
         if labels is not None:
             loss = self.engine().ce_mean(logits32.reshape(-1, logits32.size(-1)), labels.to(logits32.device).reshape(-1)).to(dtype)
@@ -451,9 +464,14 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                                  hidden_states=None if vh is None else tuple(h.to(dtype) for h in vh),
                                                  attentions=None if va is None else tuple(a.to(dtype) for a in va))
             qh = getattr(self, "_qformer_debug", None)
+            qa = getattr(self, "_qformer_attn", None)
             qf_out = BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=qf.to(dtype), pooler_output=qf[:, 0].to(dtype),
-                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh))
-        lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype))
+                                                                  hidden_states=None if qh is None else tuple(h.to(dtype) for h in qh),
+                                                                  attentions=None if qa is None else self._qformer_attn_tuple(qa, dtype),
+                                                                  cross_attentions=None if qa is None else tuple(a.to(dtype) for a in qa[1]))
+        lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype),
+                                 encoder_hidden_states=None if enc_hs is None else tuple(h.to(dtype) for h in enc_hs.unbind(0)),
+                                 decoder_hidden_states=None if dec_hs is None else tuple(h.to(dtype) for h in dec_hs.unbind(0)))
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
             return ((loss,) + out) if loss is not None else out

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 12  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs (round 4) */
+#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -377,6 +377,20 @@ int eilev_t5_decode(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t
                     int64_t batch, int64_t new_len, int64_t past_len, void *self_kv, int64_t kv_capacity,
                     const void *cross_kv, int64_t enc_len, float *logits, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* The same two stacks with what the reference's forward can also ask of them (ref:eilev/model/v2.py:228-238 hands decoder_attention_mask,
+ * output_hidden_states to hf T5ForConditionalGeneration):
+ *  - hidden_out (nullable): hf T5Stack's `hidden_states` tuple as one tensor (layers + 1, batch, rows, D): every block's input, then the
+ *    output of final_layer_norm (modeling_t5.py T5Stack.forward, all_hidden_states);
+ *  - dec_mask (nullable): decoder_attention_mask (batch, past_len + new_len) int32: target keys the decoder self-attention must not
+ *    see, on top of the causal rule (key 0 of every row must be visible: no query row may lose all of its keys). */
+int eilev_t5_encode_debug(const EilevT5Dims *d, const EilevT5Weights *w, const void *inputs_embeds, const int32_t *attn_mask,
+                          int64_t batch, int64_t enc_len, void *enc_out, void *hidden_out, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int eilev_t5_decode_debug(const EilevT5Dims *d, const EilevT5Weights *w, const int64_t *dec_ids, const int32_t *enc_mask,
+                          const int32_t *dec_mask, int64_t batch, int64_t new_len, int64_t past_len, void *self_kv,
+                          int64_t kv_capacity, const void *cross_kv, int64_t enc_len, float *logits, void *hidden_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* One generation step of the decoder with the step counter on the DEVICE (so that a captured hipGraph replays for every
  * step): position = state[0] = number of tokens fed so far; tokens (batch) int64 = the ids to feed (start token at step 0,

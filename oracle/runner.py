@@ -323,6 +323,32 @@ class OracleModel:
                                            enc_len, _p(logits), _p(ws), nb, None), "oracle t5 decode")
         return logits
 
+    def t5_forward_debug(self, pixels, input_ids, attn_mask, video_mask, decoder_input_ids, decoder_attention_mask=None):
+        """Teacher-forced forward with decoder_attention_mask and the per-block tensors of both stacks (ref:eilev/model/v2.py:228-238 with
+        output_hidden_states=True): logits, encoder hidden_states (layers + 1, B, L, D), decoder hidden_states (layers + 1, B, T, D)."""
+        d = self.t5dims
+        emb = np.ascontiguousarray(self.encode(pixels, input_ids, video_mask), dtype=np.float32)
+        B, L, D = emb.shape
+        am = np.ascontiguousarray(attn_mask, dtype=np.int32)
+        enc = np.empty_like(emb)
+        enc_hs = np.empty((d.enc_layers + 1, B, L, D), np.float32)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, L, L)
+        ws = np.empty(nb // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_t5_encode_debug(C.byref(d), C.byref(self.pack.t5), _p(emb), _p(am), B, L, _p(enc), _p(enc_hs), _p(ws), nb, None),
+                  "oracle t5 encode debug")
+        ckv = self.t5_cross_kv(enc)
+        ids = np.ascontiguousarray(decoder_input_ids, dtype=np.int64)
+        T = ids.shape[1]
+        dm = None if decoder_attention_mask is None else np.ascontiguousarray(decoder_attention_mask, dtype=np.int32)
+        skv = np.zeros(self.lib.eilev_t5_self_kv_bytes(C.byref(d), B, T) // 4, np.float32)
+        logits = np.empty((B, T, d.vocab), np.float32)
+        dec_hs = np.empty((d.dec_layers + 1, B, T, D), np.float32)
+        nb = self.lib.eilev_t5_workspace_bytes(C.byref(d), B, T, max(L, T))
+        ws = np.empty(nb // 4 + 1, np.float32)
+        abi.check(self.lib.eilev_t5_decode_debug(C.byref(d), C.byref(self.pack.t5), _p(ids), _p(am), None if dm is None else _p(dm), B, T, 0, _p(skv), T,
+                                                 _p(ckv), L, _p(logits), _p(dec_hs), _p(ws), nb, None), "oracle t5 decode debug")
+        return logits, enc_hs, dec_hs
+
     def t5_forward_logits(self, pixels, input_ids, attn_mask, video_mask, decoder_input_ids):
         """= reference forward(..., decoder_input_ids / labels).logits for the encoder-decoder LM (ref:eilev/model/v2.py:228-238);
         also returns the encoder's last hidden state."""

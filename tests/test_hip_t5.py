@@ -122,6 +122,55 @@ def test_t5_model_class_like_the_reference(golden_dir, dtype):
     assert np.array_equal(ids.cpu().numpy()[:, : ref_ids.shape[1]], ref_ids)
 
 
+def test_t5_decoder_mask_and_hidden_states(golden_dir):
+    """decoder_attention_mask with padding + both stacks' hidden_states (eilev_t5_encode_debug / eilev_t5_decode_debug) against the
+    reference's runs of the same call (tests/golden/mid_t5_dbg.npz) and the oracle; then the same through the drop-in class."""
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+    from oracle.runner import synth_state_dict
+
+    g, meta, px = load_case(golden_dir, "mid_t5_dbg")
+    cfg, oracle, eng = models(meta["config"])
+    t = lambda a: torch.from_numpy(a).cuda()
+    emb = _encode(eng, g, px)
+    logits, enc, enc_hs, dec_hs = eng.t5_forward_debug(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]), t(g["decoder_attention_mask"]), True)
+    truth, ref = g["fp32_logits"], g["bf16_logits"]
+    assert rel_rms(host(logits), truth) <= 1.2 * rel_rms(ref, truth) + 2e-3
+    assert np.abs(host(logits) - truth).max() <= 2.0 * np.abs(ref - truth).max() + 1e-3
+    # the mask is really applied: the unmasked run is far away from both
+    assert rel_rms(host(logits), g["fp32_logits_nomask"]) > 5 * rel_rms(host(logits), truth)
+    valid = g["attention_mask"] == 1
+    for got, key, sel in ((enc_hs, "enc_hidden", (slice(None), valid)), (dec_hs, "dec_hidden", (slice(None),))):
+        tr, rf = g[f"fp32_{key}"][sel], g[f"bf16_{key}"][sel]
+        assert host(got).shape == g[f"fp32_{key}"].shape
+        for l in range(tr.shape[0]):
+            assert rel_rms(host(got)[sel][l], tr[l]) <= 1.2 * rel_rms(rf[l], tr[l]) + 2e-3, (key, l)
+    assert torch.equal(enc_hs[-1], enc)
+    lo, eo, do = oracle.t5_forward_debug(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"],
+                                         g["decoder_attention_mask"])
+    assert rel_rms(host(logits), lo) <= 1.2 * rel_rms(ref, truth) + 2e-3
+    # the plain entries are the same arithmetic when nothing is masked
+    l0, e0 = eng.t5_forward(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]))
+    l1, e1, _, _ = eng.t5_forward_debug(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]), torch.ones_like(t(g["decoder_attention_mask"])), False)
+    assert torch.equal(l0, l1) and torch.equal(e0, e1)
+    with pytest.raises(NotImplementedError):
+        bad = g["decoder_attention_mask"].copy()
+        bad[0, 0] = 0
+        eng.t5_forward_debug(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]), t(bad), False)
+    # ---- the model class: ref:eilev/model/v2.py:228-238
+    m = VideoBlipForConditionalGeneration(cfg).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}, strict=False)
+    m = m.to(torch.bfloat16).to("cuda")
+    out = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(torch.bfloat16),
+            video_input_mask=t(g["video_input_mask"]), decoder_input_ids=t(g["decoder_input_ids"]),
+            decoder_attention_mask=t(g["decoder_attention_mask"]), output_hidden_states=True, return_dict=True)
+    lm = out.language_model_outputs
+    assert len(lm.encoder_hidden_states) == cfg.text_config.num_layers + 1 and len(lm.decoder_hidden_states) == cfg.text_config.num_decoder_layers + 1
+    assert rel_rms(host(out.logits), truth) <= 1.5 * rel_rms(ref, truth) + 4e-3
+    assert rel_rms(host(torch.stack(lm.decoder_hidden_states)), g["fp32_dec_hidden"]) <= 1.5 * rel_rms(g["bf16_dec_hidden"], g["fp32_dec_hidden"]) + 4e-3
+    assert torch.equal(lm.encoder_hidden_states[-1], lm.encoder_last_hidden_state)
+    assert out.qformer_outputs.hidden_states is not None and out.vision_outputs.hidden_states is not None
+
+
 def test_t5_xl_widths_decode_equals_teacher_forcing():
     """flan-t5-xl widths (d_model 2048, 32 heads x 64, d_ff 5120, vocab 32128; 2 + 2 layers), L = 300 with right padding:
     size-independent properties — cached single-step decoding == teacher forcing, and padded encoder positions do not

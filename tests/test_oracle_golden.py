@@ -195,6 +195,24 @@ def test_t5_path_matches_reference(golden_dir, models, name):
     assert np.array_equal(ids[:, : ref.shape[1]], ref) and ids.shape[1] == ref.shape[1]
 
 
+def test_t5_decoder_mask_and_hidden_states_match_reference(golden_dir, models):
+    """decoder_attention_mask with padding (a hole, a padded tail) + output_hidden_states of both T5 stacks, as the reference's forward
+    hands them to the language model (ref:eilev/model/v2.py:228-238): oracle vs the reference's fp32 run."""
+    g, meta, cfg, px = load_case(golden_dir, "mid_t5_dbg")
+    m = models(meta["config"])
+    logits, enc_hs, dec_hs = m.t5_forward_debug(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"],
+                                                g["decoder_attention_mask"])
+    assert np.abs(logits - g["fp32_logits"]).max() < 5e-4
+    assert np.abs(g["fp32_logits"] - g["fp32_logits_nomask"]).max() > 1e-2  # the fixture's mask matters
+    valid = g["attention_mask"] == 1
+    assert enc_hs.shape == g["fp32_enc_hidden"].shape and dec_hs.shape == g["fp32_dec_hidden"].shape
+    assert np.abs(enc_hs - g["fp32_enc_hidden"])[:, valid].max() < 2e-4
+    assert np.abs(dec_hs - g["fp32_dec_hidden"]).max() < 2e-4
+    # without the mask the same entry reproduces the plain forward
+    plain, _, _ = m.t5_forward_debug(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"], None)
+    assert np.abs(plain - g["fp32_logits_nomask"]).max() < 5e-4
+
+
 def shifted_ce_loss_t5(logits, labels):
     """CrossEntropyLoss(ignore_index=-100) of logits (B, T, V) against labels (B, T) — no shift for encoder-decoder models."""
     x = logits.astype(np.float64)

@@ -160,6 +160,54 @@ def run_t5_case(name):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
 
 
+@torch.no_grad()
+def run_t5_debug_case(name="mid_t5_dbg"):
+    """Encoder-decoder LM with what else the reference's forward hands down (ref:eilev/model/v2.py:228-238): a decoder_attention_mask with
+    padding (row 1: right padding; row 0: a hole in the middle) and output_hidden_states=True (both stacks' tuples)."""
+    cfg_name, frames, rows, tgt_len, _ = T5_CASES["mid_t5_b2"]
+    cfg = blip2_config(cfg_name)
+    torch.manual_seed(0)
+    model = RefModel(cfg).eval()
+    load_det_weights(model)
+    pixels, input_ids, attn, vmask, _ = build_inputs(cfg_name, frames, rows)
+    B, L = input_ids.shape
+    for b in range(B):  # right padding, as run_t5_case
+        n = int(attn[b].sum())
+        input_ids[b] = np.concatenate([input_ids[b, L - n:], np.zeros(L - n, np.int64)])
+        vmask[b] = np.concatenate([vmask[b, L - n:], np.zeros(L - n, np.int64)])
+        attn[b] = np.concatenate([np.ones(n, np.int64), np.zeros(L - n, np.int64)])
+    vocab = cfg.text_config.vocab_size
+    rng = np.random.default_rng(23)
+    T = tgt_len + 2
+    dec_in = np.concatenate([np.zeros((B, 1), np.int64), rng.integers(2, vocab, size=(B, T - 1))], axis=1).astype(np.int64)
+    dec_mask = np.ones((B, T), np.int64)
+    dec_mask[0, 3] = 0
+    dec_mask[1, T - 3:] = 0
+    dec_in[1, T - 3:] = 0
+    t = lambda a: torch.from_numpy(a)
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask),
+              decoder_input_ids=t(dec_in), decoder_attention_mask=t(dec_mask), output_hidden_states=True, return_dict=True)
+        lm = o.language_model_outputs
+        out[f"{tag}_logits"] = o.logits.float().numpy()
+        out[f"{tag}_enc_hidden"] = torch.stack(lm.encoder_hidden_states).float().numpy()
+        out[f"{tag}_dec_hidden"] = torch.stack(lm.decoder_hidden_states).float().numpy()
+        o2 = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask),
+               decoder_input_ids=t(dec_in), return_dict=True)
+        out[f"{tag}_logits_nomask"] = o2.logits.float().numpy()  # (shows the mask matters: differs from *_logits after the masked keys)
+        assert not torch.equal(o2.logits, o.logits)
+    meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, weight_mode="fanin", torch=torch.__version__,
+                transformers=transformers.__version__, generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py",
+                padding="right")
+    out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, decoder_input_ids=dec_in, decoder_attention_mask=dec_mask,
+               meta=np.asarray(json.dumps(meta)))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"}, os.path.getsize(path))
+
+
 class _legacy_kv_compat:
     """The reference's classify() was written against the tuple-of-(k, v) KV cache of the transformers release it pins
     (ref:pyproject.toml); the installed release iterates a DynamicCache as (k, v, sliding_window) triples and only takes
@@ -637,7 +685,7 @@ def run_attn_debug_case(name="mid_attndebug", base="mid_b2"):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug", "mid_attndebug"] +
+    for n in (sys.argv[1:] or list(CASES) + list(T5_CASES) + list(REAL_CASES) + list(REAL_T5_CASES) + ["mid_vitdebug", "mid_lmdebug", "mid_attndebug", "mid_t5_dbg"] +
               list(VARIED_CASES)):  # full_c1 (15 GB of fp32 weights, minutes): by name only
-        (run_attn_debug_case if n == "mid_attndebug" else run_varied_case if n in VARIED_CASES or n in FULL_CASES else run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
+        (run_attn_debug_case if n == "mid_attndebug" else run_t5_debug_case if n == "mid_t5_dbg" else run_varied_case if n in VARIED_CASES or n in FULL_CASES else run_t5_case if n in T5_CASES else run_real_case if n in REAL_CASES else run_real_t5_case if n in REAL_T5_CASES
          else run_vit_debug_case if n == "mid_vitdebug" else run_lm_debug_case if n == "mid_lmdebug" else run_case)(n)
