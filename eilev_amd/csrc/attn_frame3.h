@@ -52,18 +52,30 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
 
     // DMA piece k (of PPW) of this wave: 64 lanes x 16 bytes of the image at src -> LDS buffer buf.  Issued one at a time BETWEEN compute
     // steps: 48 pieces (+ 48 Q loads) issued together at a barrier stall every wave at the texture-address unit for 3-4 k cycles.
+    // (r4) the chunk -> (key, 16-byte column) split: piece i starts at chunk 64 i = CH q + r with q, r on the SCALAR unit; lane l's chunk is
+    // key q + (r + l) / CH with (r + l) < 64 + CH divided by a 24-bit multiply and a shift (DIVM, checked below), and the row offset is a
+    // 24-bit multiply-add: 5 full-rate VALU instructions per piece where pch / CH, key * ld2 compiled to v_mul_hi_i32 + v_mad_u64_u32 +
+    // v_mul_lo_u32 (quarter rate: ~72 issue cycles per piece, 24 pieces per SIMD and pair = 12 % of the issue budget of a pair).
+    // Rows past S - 1 are outside the descriptor's range and read zeros (masked keys of the last tile; V rows that meet P = 0).
+    constexpr int DIVS = 9, DIVM = ((1 << DIVS) + CH - 1) / CH;
+    static_assert([] {
+        for (int t = 0; t < 64 + CH; ++t)
+            if (((t * DIVM) >> DIVS) != t / CH) return false;
+        return true;
+    }(), "chunk / CH by multiply-shift");
     auto stage_piece = [&](const bf16 *src, int buf, int k) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
-        const unsigned ld2 = (unsigned)(a.ldk * 2);
+        const int ld2 = __builtin_amdgcn_readfirstlane((int)(a.ldk * 2));
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, (S - 1) * ld2 + HD * 2, 0x00020000);
         int ln = lane;
         asm volatile("" : "+v"(ln));  // opaque: the piece geometry is recomputed per call (a handful of VALU ops), not kept in registers
         int i = wid + NW * k;
         i = i < NPIECE ? i : NPIECE - 1;
-        const int pch = i * 64 + ln;
-        int key = pch / CH;
-        const int c = pch - key * CH;
-        key = key < S ? key : S - 1;
-        attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), (unsigned)key * ld2 + c * 16);
+        const int q0 = (i * 64) / CH, r0 = i * 64 - q0 * CH;  // wave-uniform
+        const unsigned t = (unsigned)(ln + r0);
+        const unsigned kq = __umul24(t, DIVM) >> DIVS;
+        // (q0 + kq) ld2 + 16 (t - CH kq) = kq (ld2 - 16 CH) + (q0 ld2 + 16 t): no remainder to form
+        const unsigned voff = __umul24(kq, (unsigned)(ld2 - 16 * CH)) + ((unsigned)(q0 * ld2) + (t << 4));  // kq < 2^9, ld2 < 2^24
+        attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), voff);
     };
     auto stage = [&](const bf16 *src, int buf) {
 #pragma unroll
@@ -92,11 +104,12 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         // one descriptor per (frame, head): rows past S and head-dim slots past HD read 0 through the bounds / the offset trick below
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs), 0,
                                                                             (int)(((int64_t)(S - 1) * a.ldq + HD) * 2), 0x00020000);
-        const unsigned rb = row < S ? (unsigned)row * (unsigned)(a.ldq * 2) : 0x7ffffff0u;  // out of bounds -> 0
+        const unsigned rb = row < S ? __umul24((unsigned)row, (unsigned)(a.ldq * 2)) : 0x7ffffff0u;  // out of bounds -> 0 (row < 2^9, ldq < 2^23)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 32 + 4 * go, d1 = d0 + 16;
-            const unsigned o0 = d0 + 4 <= HD ? rb + d0 * 2 : 0x7ffffff0u, o1 = d1 + 4 <= HD ? rb + d1 * 2 : 0x7ffffff0u;
+            const int d0 = ks * 32 + 4 * go, d1 = d0 + 16;  // go < 4: only a slot whose LAST lane group passes HD needs the per-lane test
+            const unsigned o0 = (ks * 32 + 16 <= HD || d0 + 4 <= HD) ? rb + d0 * 2 : 0x7ffffff0u;
+            const unsigned o1 = (ks * 32 + 32 <= HD || d1 + 4 <= HD) ? rb + d1 * 2 : 0x7ffffff0u;
             asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(lo[ks]) : "v"(o0), "s"(rq));
             asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(hi[ks]) : "v"(o1), "s"(rq));
         }
@@ -161,6 +174,27 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
             if ((NT - 1) * 16 + (ar < 8 ? 2 * ar : 2 * ar - 15) >= S) v[r] = -1e30f;
         }
     };
+    // Reductions over lanes l, l ^ 16, l ^ 32, l ^ 48 through v_permlane16_swap / v_permlane32_swap of two copies (after the swap one copy
+    // holds the own row / half, the other the partner's): six VALU instructions where two __shfl_xor are two ds_bpermute round trips behind
+    // s_waitcnt lgkmcnt(0) — twelve of them per wave and pair, inside the VALU-bound softmax phase (r4).  Same operands, same sums.
+    // Inline asm: hipcc -O3 folds the second result of __builtin_amdgcn_permlane16_swap into the first when both feed one max / add
+    // (ROCm 7.2: `fadd %p, %p` in the IR), and fmaxf on asm results adds two canonicalising v_max.  The s_nop mirror the wait states hipcc
+    // itself places between a VALU write and a lane swap that reads it.
+#define FA_QUAD(OP, x)                                                                                                                   \
+    do {                                                                                                                                 \
+        float fa_b_ = (x);                                                                                                               \
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\t" OP " %0, %0, %1\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\t"                  \
+                     "v_permlane32_swap_b32 %0, %1\n\t" OP " %0, %0, %1"                                                                 \
+                     : "+v"(x), "+v"(fa_b_));                                                                                            \
+    } while (0)
+    auto quad_max = [&](float x) -> float {
+        FA_QUAD("v_max_f32", x);
+        return x;
+    };
+    auto quad_sum = [&](float x) -> float {
+        FA_QUAD("v_add_f32", x);
+        return x;
+    };
     auto row_offset = [&](f32x4 (&sc)[NT]) -> float {
         mask_last(sc[NT - 1]);
         float m4[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
@@ -168,10 +202,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         for (int t = 0; t < NT; t += 2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m4[r] = t + 1 < NT ? fmaxf(fmaxf(m4[r], sc[t][r]), sc[t + 1][r]) : fmaxf(m4[r], sc[t][r]);
-        float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        return -mx * sl2;
+        return -quad_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]))) * sl2;
     };
     auto sm_tile = [&](const f32x4 &sv, bf16x4 &pv, float nm, f32x2 &la, f32x2 &lb) {
         const f32x2 x0 = (f32x2){sv[0], sv[1]} * sl2 + nm, x1 = (f32x2){sv[2], sv[3]} * sl2 + nm;
@@ -182,10 +213,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         pv = (bf16x4){(bf16)p0.x, (bf16)p0.y, (bf16)p1.x, (bf16)p1.y};
     };
     auto row_sum = [&](f32x2 la, f32x2 lb) -> float {
-        float l = (la.x + la.y) + (lb.x + lb.y);
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        return l;
+        return quad_sum((la.x + la.y) + (lb.x + lb.y));
     };
     auto softmax = [&](f32x4 (&sc)[NT], bf16x4 (&pr)[NT]) -> float {
         const float nm = row_offset(sc);
@@ -227,17 +255,21 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         int l15o = l15, go = lane >> 4;
         asm volatile("" : "+v"(l15o), "+v"(go));  // (opaque: see stage)
         const int row = tile * 16 + l15o;
-        const float inv = 1.0f / l;
+        const float inv = __builtin_amdgcn_rcpf(l);  // l >= 1 (the row's maximum contributes exp2(0)); 1 ulp, the output is bf16
+        const f32x2 inv2 = {inv, inv};
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)ob, 0, (int)(((int64_t)(S - 1) * a.ldo + HD) * 2), 0x00020000);
-        const unsigned ob_off = (unsigned)row * (unsigned)(a.ldo * 2) + ((go & 1) * 16 + (go >> 1) * 8) * 2;
+        const unsigned ob_off = __umul24((unsigned)row, (unsigned)(a.ldo * 2)) + ((go & 1) * 16 + (go >> 1) * 8) * 2;
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_o;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             union { bf16x4 v; unsigned w[2]; } e, odd, lo, hi;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e.v[r] = (bf16)(o[2 * m][r] * inv);
-                odd.v[r] = (bf16)(o[2 * m + 1][r] * inv);
+            for (int w = 0; w < 2; ++w) {  // (the accumulators' even-aligned register pairs: v_pk_mul_f32 + v_cvt_pk_bf16_f32 per dword)
+                const f32x2 ev = (f32x2){o[2 * m][2 * w], o[2 * m][2 * w + 1]} * inv2, ov = (f32x2){o[2 * m + 1][2 * w], o[2 * m + 1][2 * w + 1]} * inv2;
+                e.v[2 * w] = (bf16)ev.x;
+                e.v[2 * w + 1] = (bf16)ev.y;
+                odd.v[2 * w] = (bf16)ov.x;
+                odd.v[2 * w + 1] = (bf16)ov.y;
             }
             // lanes g and g ^ 1 (16 lanes apart) trade halves: even g keeps its even tile and takes the partner's, odd g the odd tiles.
             // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second: one VALU
@@ -339,9 +371,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
             for (int u = 0; u < 3; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, scC[u][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            mC = mx * sl2;
+            mC = quad_max(mx) * sl2;
             f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -372,8 +402,6 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         constexpr bf16x4 z4 = {0, 0, 0, 0};
         {
             f32x4 oA[DT], oB[DT];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oA[dt] = oB[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // software pipeline in half steps: the V^T fragments of d tiles 0-2 (H0) and 3-5 (H1) of a key-tile pair are separate
             // register sets, and each is re-requested for the next pair as soon as its MFMAs have been issued: six reads are in flight
             // under every group of six MFMAs (issue-wait-compute per whole step left the matrix pipe idle for an LDS round trip per step)
@@ -394,15 +422,17 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
                              : "+v"(vf[6 * hh]), "+v"(vf[6 * hh + 1]), "+v"(vf[6 * hh + 2]), "+v"(vf[6 * hh + 3]), "+v"(vf[6 * hh + 4]), "+v"(vf[6 * hh + 5])
                              : "n"(N));
             };
-            auto mma_half = [&](const bf16x4 (&vf)[2 * DT], f32x4 (&o)[DT], bf16x4 p0, bf16x4 p1, auto h_c, auto two_c) {
+            // (the first key step starts from the inline constant 0: no accumulator initialisation, 48 v_mov per wave and pair)
+            auto mma_half = [&](const bf16x4 (&vf)[2 * DT], f32x4 (&o)[DT], bf16x4 p0, bf16x4 p1, auto h_c, auto two_c, auto first_c) {
                 constexpr int hh = decltype(h_c)::value;
-                constexpr bool two = decltype(two_c)::value;
+                constexpr bool two = decltype(two_c)::value, first = decltype(first_c)::value;
                 const bf16x8 pb = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll
                 for (int dt = 3 * hh; dt < 3 * hh + 3; ++dt) {
                     const bf16x4 lo = vf[2 * dt], hi = two ? vf[2 * dt + 1] : z4;
                     const bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, pb, o[dt], 0, 0, 0);
+                    if constexpr (first) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, pb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, pb, o[dt], 0, 0, 0);
                 }
             };
             using H0 = std::integral_constant<int, 0>;
@@ -415,14 +445,15 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
                 constexpr int n_this = two ? 6 : 3;                                    // reads per half of this step
                 constexpr int n_next = last ? 0 : (2 * (k2 + 1) + 1 < NT ? 6 : 3);    // ... of the next step
                 using TWO = std::integral_constant<bool, two>;
+                using FIRST = std::integral_constant<bool, k2 == 0>;
                 const bf16x4 pa1 = two ? prA[two ? 2 * k2 + 1 : 0] : z4, pb1 = two ? prB[two ? 2 * k2 + 1 : 0] : z4;
                 wait_half(vf, H0{}, std::integral_constant<int, n_this>{});  // H1 of this step is younger
-                mma_half(vf, oA, prA[2 * k2], pa1, H0{}, TWO{});
-                mma_half(vf, oB, prB[2 * k2], pb1, H0{}, TWO{});
+                mma_half(vf, oA, prA[2 * k2], pa1, H0{}, TWO{}, FIRST{});
+                mma_half(vf, oB, prB[2 * k2], pb1, H0{}, TWO{}, FIRST{});
                 if constexpr (!last) issue_half(vf, std::integral_constant<int, last ? k2 : k2 + 1>{}, H0{});
                 wait_half(vf, H1{}, std::integral_constant<int, n_next>{});  // H0 of the next step is younger
-                mma_half(vf, oA, prA[2 * k2], pa1, H1{}, TWO{});
-                mma_half(vf, oB, prB[2 * k2], pb1, H1{}, TWO{});
+                mma_half(vf, oA, prA[2 * k2], pa1, H1{}, TWO{}, FIRST{});
+                mma_half(vf, oB, prB[2 * k2], pb1, H1{}, TWO{}, FIRST{});
                 if constexpr (!last) issue_half(vf, std::integral_constant<int, last ? k2 : k2 + 1>{}, H1{});
                 step_hook(k_c);
             });
@@ -604,6 +635,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         cls_merge(ob_prev);
     }
 #undef FA_TS
+#undef FA_QUAD
 #undef FA_QWAIT2
 #undef FA_QWAIT
 #undef FA_VMCNT
