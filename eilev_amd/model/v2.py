@@ -530,8 +530,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         if min_new >= max_new:
             eos_ids = []  # EOS can never fire before the budget is exhausted
             min_new = 0
-        for k in ("use_cache", "return_dict_in_generate", "output_scores"):
-            kw.pop(k, None)
+        kw.pop("use_cache", None)
+        for k in ("return_dict_in_generate", "output_scores", "output_logits"):  # a tensor of ids is all this path returns: say so instead of ignoring
+            if kw.pop(k, None):
+                raise NotImplementedError(f"generate({k}=True) is not built on the HIP path (it returns the generated ids, as the reference's callers use it)")
         # hf hands every other kwarg to GenerationMixin (ref:eilev/model/v2.py:318-322).  Logits processors and stopping criteria run in the
         # host loops over the same HIP decode step, with transformers' own processor classes (exactly hf's arithmetic and order).
         from transformers import (LogitsProcessorList, MaxTimeCriteria, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
