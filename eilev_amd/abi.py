@@ -350,7 +350,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_attention.restype = i32
     lib.eilev_attention.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
     lib.eilev_attention_probs.restype = i32
-    lib.eilev_attention_probs.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp]
+    lib.eilev_attention_probs.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, i64, i64, vp]
     lib.eilev_attention_bwd.restype = i32
     lib.eilev_attention_bwd.argtypes = [vp] * 9 + [i64] * 11 + [f32, i32, vp, vp]
     lib.eilev_layernorm_bwd.restype = i32

@@ -1028,7 +1028,8 @@ namespace {
 // eilev_attention_probs: one wave per (batch, head, query row); a lane owns keys lane, lane + 64, ... (up to 64 per lane = 4096 keys)
 __global__ void __launch_bounds__(256) attn_probs_masked_kernel(const bf16 *__restrict__ q, const bf16 *__restrict__ k, bf16 *__restrict__ probs, int heads,
                                                                 int sq, int skv, int hd, int64_t ldq, int64_t ldk, float scale, int causal,
-                                                                const int32_t *__restrict__ key_mask) {
+                                                                const int32_t *__restrict__ key_mask, const float *__restrict__ rel_tab, int64_t rel_stride,
+                                                                int rel_off, int rel_n) {
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= sq) return;
@@ -1052,6 +1053,7 @@ __global__ void __launch_bounds__(256) attn_probs_masked_kernel(const bf16 *__re
                     for (int u = 0; u < 8; ++u) s = fmaf((float)qa[u], (float)ka[u], s);
                 }
                 s *= scale;
+                if (rel_tab) s += rel_tab[(int64_t)h * rel_stride + min(max(j - i - (skv - sq) + rel_off, 0), rel_n - 1)];
             }
             if (pass == 0) mx = fmaxf(mx, s);
             else sum += s == -INFINITY ? 0.0f : __expf(s - keep_mx);
@@ -1073,7 +1075,9 @@ __global__ void __launch_bounds__(256) attn_probs_masked_kernel(const bf16 *__re
 #pragma unroll
                     for (int u = 0; u < 8; ++u) s = fmaf((float)qa[u], (float)ka[u], s);
                 }
-                p = sum > 0.0f ? __expf(s * scale - keep_mx) / sum : 0.0f;
+                s *= scale;
+                if (rel_tab) s += rel_tab[(int64_t)h * rel_stride + min(max(j - i - (skv - sq) + rel_off, 0), rel_n - 1)];
+                p = sum > 0.0f ? __expf(s - keep_mx) / sum : 0.0f;
             }
             out[j] = (bf16)p;
         }
@@ -1082,12 +1086,15 @@ __global__ void __launch_bounds__(256) attn_probs_masked_kernel(const bf16 *__re
 }  // namespace
 
 extern "C" int eilev_attention_probs(const void *q, const void *k, void *probs, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim,
-                                     int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, void *stream) {
+                                     int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, const float *rel_tab,
+                                     int64_t rel_stride, int64_t rel_off, int64_t rel_n, void *stream) {
     if (!q || !k || !probs || batch < 0 || heads <= 0 || sq < 0 || skv <= 0 || skv > 4096) return EILEV_E_BADARG;
+    if (rel_tab && (rel_n <= 0 || rel_stride < rel_n)) return EILEV_E_BADARG;
     if ((head_dim & 7) || (ldq & 7) || (ldk & 7) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15)) return EILEV_E_UNSUPPORTED;
     if (batch == 0 || sq == 0) return EILEV_OK;
     attn_probs_masked_kernel<<<dim3((unsigned)(batch * heads), (unsigned)((sq + 3) / 4)), 256, 0, (hipStream_t)stream>>>(
-        (const bf16 *)q, (const bf16 *)k, (bf16 *)probs, (int)heads, (int)sq, (int)skv, (int)head_dim, ldq, ldk, scale, causal, key_mask);
+        (const bf16 *)q, (const bf16 *)k, (bf16 *)probs, (int)heads, (int)sq, (int)skv, (int)head_dim, ldq, ldk, scale, causal, key_mask, rel_tab, rel_stride,
+        (int)rel_off, (int)rel_n);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -256,12 +256,77 @@ class HipEngine:
                                            C.c_float(eps), self._stream()), "eilev_layernorm")
         return out
 
-    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None):
+    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None, rel=None):
+        """rel = (table (heads, n) f32, offset): the additive relative position bias of eilev_attention_rel (T5)."""
         out = torch.empty((B, H, sq, skv), dtype=torch.bfloat16, device=self.device)
         km = None if key_mask is None else key_mask.to(self.device, torch.int32).contiguous()
+        tab, off = rel if rel is not None else (None, 0)
         abi.check(self.lib.eilev_attention_probs(_ptr(q), _ptr(k), _ptr(out), B, H, sq, skv, hd, q.shape[-1], k.shape[-1], C.c_float(scale), int(causal),
-                                                 _ptr(km), self._stream()), "eilev_attention_probs")
+                                                 _ptr(km), _ptr(tab), 0 if tab is None else tab.shape[1], off, 0 if tab is None else tab.shape[1],
+                                                 self._stream()), "eilev_attention_probs")
         return out
+
+    def t5_rel_table(self, stack: str, L: int):
+        """f32 (heads, 2 L - 1) relative position bias over key - query in [-(L-1), L-1] and the offset L - 1 (hf T5Attention.compute_bias /
+        _relative_position_bucket, modeling_t5.py: the same torch ops in the same order, on the stack's relative_attention_bias weight)."""
+        import math
+
+        d = self.t5dims
+        w = self._keep[f"language_model.{stack}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]  # (buckets, heads)
+        rp = torch.arange(-(L - 1), L, device=w.device)  # memory position - context position
+        nb = d.rel_buckets
+        ret = torch.zeros_like(rp)
+        if stack == "encoder":  # bidirectional
+            nb //= 2
+            ret = ret + (rp > 0).to(torch.long) * nb
+            rp = rp.abs()
+        else:
+            rp = -torch.min(rp, torch.zeros_like(rp))
+        max_exact = nb // 2
+        large = max_exact + (torch.log(rp.float() / max_exact) / math.log(d.rel_max_dist / max_exact) * (nb - max_exact)).to(torch.long)
+        large = torch.min(large, torch.full_like(large, nb - 1))
+        bucket = ret + torch.where(rp < max_exact, rp, large)
+        return w.float()[bucket].t().contiguous(), L - 1
+
+    def _rms(self, x2d, wname, eps):
+        out = torch.empty_like(x2d)
+        abi.check(self.lib.eilev_rmsnorm(_ptr(x2d.contiguous()), _ptr(self._keep[wname]), _ptr(out), x2d.shape[0], x2d.shape[1], C.c_float(eps), self._stream()),
+                  "eilev_rmsnorm")
+        return out
+
+    def t5_attentions(self, enc_hs, dec_hs, attention_mask, decoder_attention_mask=None):
+        """`output_attentions` of the T5 stacks [ref:eilev/model/v2.py:228-238 -> hf T5Attention: softmax(q . k + position_bias + mask), no
+        scaling]: (encoder self (layers, B, H, L, L), decoder self (layers, B, H, T, T), cross (layers, B, H, T, L)) bf16.  enc_hs / dec_hs = the
+        tuples of t5_forward_debug (block inputs, final norm last); q / k are recomputed from them with the C-ABI calls the stacks are built from
+        (the decoder's cross-attention queries need the block's self-attention output: attention, o + residual, layer norm)."""
+        from .abi import t5_layer_keys
+
+        d = self.t5dims
+        H, hd = d.heads, d.d_kv
+        I = H * hd
+        B, L, D = enc_hs.shape[1:]
+        T = dec_hs.shape[2]
+        am = attention_mask.to(self.device, torch.int32).contiguous()
+        dm = None if decoder_attention_mask is None else (decoder_attention_mask.to(self.device) != 0).to(torch.int32).contiguous()
+        enc_rel, dec_rel = self.t5_rel_table("encoder", L), self.t5_rel_table("decoder", T)
+        enc_a, dec_a, cross_a = [], [], []
+        for l in range(d.enc_layers):
+            k_ = t5_layer_keys("encoder", l)
+            x = self._rms(enc_hs[l].reshape(B * L, D), k_["ln_sa"], d.eps)
+            enc_a.append(self._probs(self._lin(x, k_["q_w"]), self._lin(x, k_["k_w"]), B, H, L, L, hd, 1.0, key_mask=am, rel=enc_rel))
+        enc_out = enc_hs[-1].reshape(B * L, D).contiguous()
+        for l in range(d.dec_layers):
+            k_ = t5_layer_keys("decoder", l)
+            h = dec_hs[l].reshape(B * T, D).contiguous()
+            x = self._rms(h, k_["ln_sa"], d.eps)
+            q, k, v = self._lin(x, k_["q_w"]), self._lin(x, k_["k_w"]), self._lin(x, k_["v_w"])
+            dec_a.append(self._probs(q, k, B, H, T, T, hd, 1.0, causal=True, key_mask=dm, rel=dec_rel))
+            ctx = torch.empty_like(q)
+            abi.check(self.lib.eilev_attention_rel(_ptr(q), _ptr(k), _ptr(v), _ptr(ctx), B, H, T, T, hd, I, I, I, C.c_float(1.0), 1, _ptr(dm), _ptr(dec_rel[0]),
+                                                   dec_rel[0].shape[1], dec_rel[1], dec_rel[0].shape[1], self._stream()), "eilev_attention_rel")
+            x2 = self._rms(self._lin(ctx, k_["o_w"], resid=h), k_["ln_ca"], d.eps)
+            cross_a.append(self._probs(self._lin(x2, k_["cq_w"]), self._lin(enc_out, k_["ck_w"]), B, H, T, L, hd, 1.0, key_mask=am))
+        return torch.stack(enc_a), torch.stack(dec_a), torch.stack(cross_a)
 
     def lm_attentions(self, hidden_states: torch.Tensor, attention_mask: torch.Tensor):
         """`output_attentions` of the OPT language model [ref:eilev/model/v2.py:220-227 -> hf modeling_opt.py eager_attention_forward]:

@@ -10,8 +10,7 @@ state-dict names; none of them has arithmetic in its ``forward``
 
 Not built (raise ``NotImplementedError``): contrastive / group-beam decoding (greedy, multinomial sampling, beam search and beam-search sampling
 are).  ``output_hidden_states`` / ``output_attentions`` inside the full model's ``forward`` are served from slow paths for the vision wrapper,
-the Q-Former (self- and cross-attention weights), the OPT language model and the T5 stacks' hidden states; the T5 stacks' attention weights stay
-``None``.  ``decoder_attention_mask`` with padding is honoured on the evaluation route (the first target position of a row must stay visible).
+the Q-Former (self- and cross-attention weights), the OPT language model and the T5 stacks (hidden states; self- and cross-attention weights).  ``decoder_attention_mask`` with padding is honoured on the evaluation route (the first target position of a row must stay visible).
 """
 from __future__ import annotations
 
@@ -384,7 +383,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         # ref:tests/model/test_model_v2.py:57-83 asserts on the vision wrapper) and the Q-Former output carries hidden_states (r3: the stack
         # re-run with its first i blocks) and the OPT language model's output carries hidden_states (r3: eilev_opt_prefill_debug); r4: the
         # attention weights of the Q-Former (self and cross) and of the OPT language model (eilev_attention_probs on q / k recomputed from the
-        # per-block inputs); the T5 stacks serve hidden_states (eilev_t5_*_debug), their attention weights stay None
+        # per-block inputs); the T5 stacks serve both (eilev_t5_*_debug, eilev_attention_probs with the relative position bias)
         self._vision_debug = (None, None)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         dtype = self.dtype
@@ -394,7 +393,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             attention_mask = torch.ones_like(input_ids)
         if self._is_t5:
             return self._forward_t5(emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict,
-                                    bool(output_hidden_states))
+                                    bool(output_hidden_states), bool(output_attentions))
         lm_hidden = lm_attn = None
         if output_hidden_states or output_attentions:  # hf OPTDecoder's tuple: every block's input, then the output of final_layer_norm
             _, logits32, _, hs = self.engine().prefill(emb, attention_mask, all_logits=True, last_logits=False, hidden_states=True)
@@ -431,10 +430,10 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                                         language_model_outputs=lm_out)
 
     def _forward_t5(self, emb, vision, qf, attention_mask, decoder_input_ids, decoder_attention_mask, labels, return_dict,
-                    output_hidden_states=False):
+                    output_hidden_states=False, output_attentions=False):
         """Encoder-decoder branch [ref:eilev/model/v2.py:228-238 -> hf T5ForConditionalGeneration.forward :939-1055].  decoder_attention_mask
-        with padding and output_hidden_states (both stacks' tuples) go through the *_debug entries (round 4); the T5 stacks' attention
-        weights are not exported (None)."""
+        with padding and output_hidden_states (both stacks' tuples) go through the *_debug entries (round 4); output_attentions: the three
+        hf tuples (encoder / decoder self-attention, cross-attention) from eilev_attention_probs on q / k recomputed from the block inputs."""
         from transformers.modeling_outputs import Seq2SeqLMOutput
 
         t = self.config.text_config
@@ -448,9 +447,16 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         dtype = self.dtype
         enc_hs = dec_hs = None
         padded = decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all())
-        if padded or output_hidden_states:
+        enc_at = dec_at = cross_at = None
+        if padded or output_hidden_states or output_attentions:
             logits32, enc, enc_hs, dec_hs = self.engine().t5_forward_debug(emb, attention_mask, decoder_input_ids,
-                                                                         decoder_attention_mask if padded else None, output_hidden_states)
+                                                                         decoder_attention_mask if padded else None,
+                                                                         output_hidden_states or output_attentions)
+            if output_attentions:
+                enc_at, dec_at, cross_at = (tuple(a.to(self.dtype) for a in t_.unbind(0)) for t_ in
+                                            self.engine().t5_attentions(enc_hs, dec_hs, attention_mask, decoder_attention_mask if padded else None))
+            if not output_hidden_states:
+                enc_hs = dec_hs = None
         else:
             logits32, enc = self.engine().t5_forward(emb, attention_mask, decoder_input_ids)
         loss = None
@@ -471,7 +477,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
                                                                   cross_attentions=None if qa is None else tuple(a.to(dtype) for a in qa[1]))
         lm_out = Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc.to(dtype),
                                  encoder_hidden_states=None if enc_hs is None else tuple(h.to(dtype) for h in enc_hs.unbind(0)),
-                                 decoder_hidden_states=None if dec_hs is None else tuple(h.to(dtype) for h in dec_hs.unbind(0)))
+                                 decoder_hidden_states=None if dec_hs is None else tuple(h.to(dtype) for h in dec_hs.unbind(0)),
+                                 encoder_attentions=enc_at, decoder_attentions=dec_at, cross_attentions=cross_at)
         if not return_dict:
             out = (logits, vis_out, qf_out, lm_out)
             return ((loss,) + out) if loss is not None else out

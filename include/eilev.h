@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug (round 4) */
+#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -461,9 +461,12 @@ int eilev_attention(const void *q, const void *k, const void *v, void *o, int64_
  * scale * q . k (same layout, causal and key_mask arguments as eilev_attention; masked keys get 0; a row without a visible key is all 0) —
  * what hf's eager attention returns as `attn_weights` and the reference passes through under `output_attentions=True`
  * (ref:eilev/model/v2.py:187-193 Q-Former [hf modeling_blip_2.py Blip2QFormerMultiHeadAttention], :220-227 language model [hf modeling_opt.py
- * eager_attention_forward]).  Slow path: one wave per query row, nothing tiled; probs bf16 (HIP) / f32 (oracle).  skv <= 4096. */
+ * eager_attention_forward]).  Slow path: one wave per query row, nothing tiled; probs bf16 (HIP) / f32 (oracle).  skv <= 4096.
+ * ABI version 13: + rel_tab (nullable; the additive relative position bias of eilev_attention_rel, same indexing: the T5 stacks' weights,
+ * hf modeling_t5.py T5Attention `attn_weights` = softmax(q . k + position_bias + mask), scale 1). */
 int eilev_attention_probs(const void *q, const void *k, void *probs, int64_t batch, int64_t heads, int64_t sq, int64_t skv, int64_t head_dim,
-                          int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, void *stream);
+                          int64_t ldq, int64_t ldk, float scale, int causal, const int32_t *key_mask, const float *rel_tab, int64_t rel_stride,
+                          int64_t rel_off, int64_t rel_n, void *stream);
 
 /* ---- gradient building blocks of the train_v2 path -------------------------------------------------
  * ref:scripts/general/train_v2.py:124-130,207-217: `loss = model(**batch).loss; accelerator.backward(loss)` with the

@@ -115,12 +115,71 @@ class OracleModel:
         abi.check(self.lib.eilev_layernorm(_p(x), _p(self.w[wname]), _p(self.w[bname]), _p(out), x.shape[0], x.shape[1], C.c_float(eps), None), "oracle layernorm")
         return out
 
-    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None):
+    def _probs(self, q, k, B, H, sq, skv, hd, scale, causal=False, key_mask=None, rel=None):
         out = np.empty((B, H, sq, skv), np.float32)
         km = None if key_mask is None else np.ascontiguousarray(key_mask, np.int32)
-        abi.check(self.lib.eilev_attention_probs(_p(q), _p(k), _p(out), B, H, sq, skv, hd, q.shape[-1], k.shape[-1], C.c_float(scale), int(causal), _p(km), None),
-                  "oracle attention_probs")
+        tab, off = rel if rel is not None else (None, 0)
+        abi.check(self.lib.eilev_attention_probs(_p(q), _p(k), _p(out), B, H, sq, skv, hd, q.shape[-1], k.shape[-1], C.c_float(scale), int(causal), _p(km),
+                                                 None if tab is None else _p(tab), 0 if tab is None else tab.shape[1], off, 0 if tab is None else tab.shape[1],
+                                                 None), "oracle attention_probs")
         return out
+
+    def t5_rel_table(self, stack, L):
+        """(heads, 2 L - 1) f32 bias over key - query and the offset L - 1: hf T5Attention._relative_position_bucket (modeling_t5.py) in numpy
+        float32 (half the buckets per sign when bidirectional; exact below max_exact, logarithmic up to max_distance)."""
+        d = self.t5dims
+        w = self.w[f"language_model.{stack}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]  # (buckets, heads)
+        rp = np.arange(-(L - 1), L, dtype=np.int64)
+        nb = int(d.rel_buckets)
+        ret = np.zeros_like(rp)
+        if stack == "encoder":
+            nb //= 2
+            ret = ret + (rp > 0).astype(np.int64) * nb
+            rp = np.abs(rp)
+        else:
+            rp = -np.minimum(rp, 0)
+        max_exact = nb // 2
+        with np.errstate(divide="ignore"):
+            lg = np.log(rp.astype(np.float32) / np.float32(max_exact)) / np.float32(np.log(d.rel_max_dist / max_exact)) * np.float32(nb - max_exact)
+        large = max_exact + np.where(np.isfinite(lg), lg, 0).astype(np.int64)
+        large = np.minimum(large, nb - 1)
+        bucket = ret + np.where(rp < max_exact, rp, large)
+        return np.ascontiguousarray(w.astype(np.float32)[bucket].T), L - 1
+
+    def _rms(self, x2d, wname, eps):
+        x = np.ascontiguousarray(x2d, np.float32)
+        out = np.empty_like(x)
+        abi.check(self.lib.eilev_rmsnorm(_p(x), _p(self.w[wname]), _p(out), x.shape[0], x.shape[1], C.c_float(eps), None), "oracle rmsnorm")
+        return out
+
+    def t5_attentions(self, enc_hs, dec_hs, attn_mask, dec_mask=None):
+        """hf T5Attention `attn_weights` of every block of both stacks from the block inputs (t5_forward_debug): encoder self (layers, B, H, L, L),
+        decoder self (layers, B, H, T, T), cross (layers, B, H, T, L)."""
+        d = self.t5dims
+        H, hd = d.heads, d.d_kv
+        I = H * hd
+        B, L, D = enc_hs.shape[1:]
+        T = dec_hs.shape[2]
+        enc_rel, dec_rel = self.t5_rel_table("encoder", L), self.t5_rel_table("decoder", T)
+        dm = None if dec_mask is None else np.ascontiguousarray(dec_mask, np.int32)
+        enc_a, dec_a, cross_a = [], [], []
+        for l in range(d.enc_layers):
+            k_ = abi.t5_layer_keys("encoder", l)
+            x = self._rms(enc_hs[l].reshape(B * L, D), k_["ln_sa"], d.eps)
+            enc_a.append(self._probs(self._lin(x, k_["q_w"]), self._lin(x, k_["k_w"]), B, H, L, L, hd, 1.0, key_mask=attn_mask, rel=enc_rel))
+        enc_out = np.ascontiguousarray(enc_hs[-1].reshape(B * L, D))
+        for l in range(d.dec_layers):
+            k_ = abi.t5_layer_keys("decoder", l)
+            h = np.ascontiguousarray(dec_hs[l].reshape(B * T, D), np.float32)
+            x = self._rms(h, k_["ln_sa"], d.eps)
+            q, k, v = self._lin(x, k_["q_w"]), self._lin(x, k_["k_w"]), self._lin(x, k_["v_w"])
+            dec_a.append(self._probs(q, k, B, H, T, T, hd, 1.0, causal=True, key_mask=dm, rel=dec_rel))
+            ctx = np.empty_like(q)
+            abi.check(self.lib.eilev_attention_rel(_p(q), _p(k), _p(v), _p(ctx), B, H, T, T, hd, I, I, I, C.c_float(1.0), 1, None if dm is None else _p(dm),
+                                                   _p(dec_rel[0]), dec_rel[0].shape[1], dec_rel[1], dec_rel[0].shape[1], None), "oracle attention_rel")
+            x2 = self._rms(self._lin(ctx, k_["o_w"], resid=h), k_["ln_ca"], d.eps)
+            cross_a.append(self._probs(self._lin(x2, k_["cq_w"]), self._lin(enc_out, k_["ck_w"]), B, H, T, L, hd, 1.0, key_mask=attn_mask))
+        return np.stack(enc_a), np.stack(dec_a), np.stack(cross_a)
 
     def lm_attentions(self, hidden_states, attn_mask):
         """hf OPT eager `attn_weights` of every block from the block inputs (prefill(hidden_states=True)): (layers, B, heads, L, L)."""

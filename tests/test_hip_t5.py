@@ -148,6 +148,16 @@ def test_t5_decoder_mask_and_hidden_states(golden_dir):
     lo, eo, do = oracle.t5_forward_debug(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"],
                                          g["decoder_attention_mask"])
     assert rel_rms(host(logits), lo) <= 1.2 * rel_rms(ref, truth) + 2e-3
+    # output_attentions: T5Attention weights of every block (encoder self, decoder self with the mask, cross) vs the reference's eager runs
+    enc_a, dec_a, cross_a = eng.t5_attentions(enc_hs, dec_hs, t(g["attention_mask"]), t(g["decoder_attention_mask"]))
+    for got, key in ((enc_a, "enc_attn"), (dec_a, "dec_attn"), (cross_a, "cross_attn")):
+        tr, rf = g[f"fp32_{key}"], g[f"bf16_{key}"]
+        assert host(got).shape == tr.shape
+        sel = np.broadcast_to(valid[None, :, None, :, None], tr.shape) if key == "enc_attn" else np.ones_like(tr, bool)  # (padded encoder query rows: any)
+        assert np.abs(host(got) - tr)[sel].max() <= 1.5 * np.abs(rf - tr)[sel].max() + 4e-3, key  # probabilities: bf16 output grid 2^-9
+    oe, od, oc = oracle.t5_attentions(eo, do, g["attention_mask"], g["decoder_attention_mask"])
+    assert np.abs(host(dec_a) - od).max() <= 1.5 * np.abs(g["bf16_dec_attn"] - g["fp32_dec_attn"]).max() + 4e-3
+    assert float(dec_a[:, 1, :, :, 5:].abs().max()) == 0.0 and float(dec_a[:, 0, :, :, 3].abs().max()) == 0.0  # the masked target keys
     # the plain entries are the same arithmetic when nothing is masked
     l0, e0 = eng.t5_forward(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]))
     l1, e1, _, _ = eng.t5_forward_debug(emb, t(g["attention_mask"]), t(g["decoder_input_ids"]), torch.ones_like(t(g["decoder_attention_mask"])), False)
@@ -162,8 +172,11 @@ def test_t5_decoder_mask_and_hidden_states(golden_dir):
     m = m.to(torch.bfloat16).to("cuda")
     out = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(torch.bfloat16),
             video_input_mask=t(g["video_input_mask"]), decoder_input_ids=t(g["decoder_input_ids"]),
-            decoder_attention_mask=t(g["decoder_attention_mask"]), output_hidden_states=True, return_dict=True)
+            decoder_attention_mask=t(g["decoder_attention_mask"]), output_hidden_states=True, output_attentions=True, return_dict=True)
     lm = out.language_model_outputs
+    assert len(lm.encoder_attentions) == cfg.text_config.num_layers and len(lm.decoder_attentions) == len(lm.cross_attentions) == cfg.text_config.num_decoder_layers
+    assert lm.cross_attentions[0].shape == g["fp32_cross_attn"].shape[1:] and lm.decoder_attentions[0].dtype == torch.bfloat16
+    assert np.abs(host(torch.stack(lm.cross_attentions)) - g["fp32_cross_attn"]).max() <= 1.5 * np.abs(g["bf16_cross_attn"] - g["fp32_cross_attn"]).max() + 4e-3
     assert len(lm.encoder_hidden_states) == cfg.text_config.num_layers + 1 and len(lm.decoder_hidden_states) == cfg.text_config.num_decoder_layers + 1
     assert rel_rms(host(out.logits), truth) <= 1.5 * rel_rms(ref, truth) + 4e-3
     assert rel_rms(host(torch.stack(lm.decoder_hidden_states)), g["fp32_dec_hidden"]) <= 1.5 * rel_rms(g["bf16_dec_hidden"], g["fp32_dec_hidden"]) + 4e-3

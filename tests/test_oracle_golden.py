@@ -208,6 +208,14 @@ def test_t5_decoder_mask_and_hidden_states_match_reference(golden_dir, models):
     assert enc_hs.shape == g["fp32_enc_hidden"].shape and dec_hs.shape == g["fp32_dec_hidden"].shape
     assert np.abs(enc_hs - g["fp32_enc_hidden"])[:, valid].max() < 2e-4
     assert np.abs(dec_hs - g["fp32_dec_hidden"]).max() < 2e-4
+    # output_attentions=True: hf T5Attention weights of every block of both stacks (the reference's eager run)
+    enc_a, dec_a, cross_a = m.t5_attentions(enc_hs, dec_hs, g["attention_mask"], g["decoder_attention_mask"])
+    for got, key in ((enc_a, "enc_attn"), (dec_a, "dec_attn"), (cross_a, "cross_attn")):
+        want = g[f"fp32_{key}"]
+        assert got.shape == want.shape
+        sel = valid[None, :, None, :, None] & np.ones_like(want, bool) if key == "enc_attn" else np.ones_like(want, bool)  # (padded encoder QUERY rows: any)
+        assert np.abs(got - want)[sel].max() < 2e-5, key
+    assert (dec_a[:, 1, :, :, 5:] == 0).all() and (dec_a[:, 0, :, :, 3] == 0).all()  # the masked target keys
     # without the mask the same entry reproduces the plain forward
     plain, _, _ = m.t5_forward_debug(px, g["input_ids"], g["attention_mask"], g["video_input_mask"], g["decoder_input_ids"], None)
     assert np.abs(plain - g["fp32_logits_nomask"]).max() < 5e-4

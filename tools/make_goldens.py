@@ -198,9 +198,25 @@ def run_t5_debug_case(name="mid_t5_dbg"):
                decoder_input_ids=t(dec_in), return_dict=True)
         out[f"{tag}_logits_nomask"] = o2.logits.float().numpy()  # (shows the mask matters: differs from *_logits after the masked keys)
         assert not torch.equal(o2.logits, o.logits)
+    # output_attentions=True: the same call on the same weights with EAGER attention (the default implementation returns no weights)
+    cfg_e = blip2_config(cfg_name)
+    for c in (cfg_e, cfg_e.vision_config, cfg_e.qformer_config, cfg_e.text_config):
+        c._attn_implementation = "eager"
+    torch.manual_seed(0)
+    model_e = RefModel(cfg_e).eval()
+    load_det_weights(model_e)
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model_e.to(dtype)
+        o = m(input_ids=t(input_ids), attention_mask=t(attn), pixel_values=t(pixels).to(dtype), video_input_mask=t(vmask),
+              decoder_input_ids=t(dec_in), decoder_attention_mask=t(dec_mask), output_attentions=True, return_dict=True)
+        lm = o.language_model_outputs
+        assert np.abs(o.logits.float().numpy() - out[f"{tag}_logits"]).max() < (1e-4 if dtype == torch.float32 else 0.5)
+        out[f"{tag}_enc_attn"] = torch.stack(lm.encoder_attentions).float().numpy()    # (layers, B, heads, L, L)
+        out[f"{tag}_dec_attn"] = torch.stack(lm.decoder_attentions).float().numpy()    # (layers, B, heads, T, T)
+        out[f"{tag}_cross_attn"] = torch.stack(lm.cross_attentions).float().numpy()    # (layers, B, heads, T, L)
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, weight_mode="fanin", torch=torch.__version__,
                 transformers=transformers.__version__, generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py",
-                padding="right")
+                padding="right", attentions="attn_implementation=eager")
     out.update(input_ids=input_ids, attention_mask=attn, video_input_mask=vmask, decoder_input_ids=dec_in, decoder_attention_mask=dec_mask,
                meta=np.asarray(json.dumps(meta)))
     path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
