@@ -97,7 +97,9 @@ extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms,
 
 extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
 // probe / test switch: 1 = take the unfused patch path (im2col -> GEMM -> CLS rows -> LayerNorm) even where the fused kernel applies
-static int64_t g_ln_fold_min_rows = 65536;
+// (r4) 24 576: tools/vit_small_launch.py — the fold wins from 96 frames per launch (53.3 vs 55.7 ms; 136 frames 69.3 vs 71.5), ties at 32-64
+// frames and loses below (8 frames 11.2 vs 8.9 ms: too few 256 x 256 tiles for the persistent kernel)
+static int64_t g_ln_fold_min_rows = 24576;
 extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }
 // Round 3: the UNFUSED patch path is the default — im2col_strip_kernel reads the frame tensor with coalesced 16-byte loads at 3.9 TB/s
 // (168 us per 1088 frames) and im2col + GEMM + CLS rows + LayerNorm take 0.93 ms per launch, while the fused patch_embed_ln_kernel takes

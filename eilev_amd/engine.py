@@ -49,7 +49,7 @@ class HipEngine:
         if lm_weights != "bf16":
             self._quantize_opt(act_fp8=lm_weights == "fp8_mfma")
         # LayerNorm folding of the ViT blocks: the folded qkv / fc1 copies (+1.1 GB at ViT-g) are built lazily by the first
-        # launch large enough to use them (>= 65536 token rows); vit_ln_fold=False keeps the LayerNorm kernels for every launch
+        # launch large enough to use them (>= 24576 token rows); vit_ln_fold=False keeps the LayerNorm kernels for every launch
         self.vit_ln_fold = bool(vit_ln_fold)
         self._vit_folded = False
         self.tokens_per_frame = (self.dims.image_size // self.dims.patch_size) ** 2 + 1
@@ -138,7 +138,7 @@ class HipEngine:
         abi.attach_opt_w8(self.pack, per_layer, expand.data_ptr(), nb, act_fp8=act_fp8)
 
     def ensure_vit_fold(self):
-        """Build the folded qkv / fc1 copies now (normally done by the first launch of >= 65536 token rows); no-op when folding is off."""
+        """Build the folded qkv / fc1 copies now (normally done by the first launch of >= 24576 token rows); no-op when folding is off."""
         if self.vit_ln_fold and not self._vit_folded:
             self._fold_vit_layernorms()
 
@@ -193,7 +193,7 @@ class HipEngine:
         out = torch.empty((N, T * self.tokens_per_frame, d.v_hidden), dtype=torch.bfloat16, device=self.device)
         pool = torch.empty((N, T, d.v_hidden), dtype=torch.bfloat16, device=self.device) if want_pooler else None
         step = max(1, max_frames_per_call // T)
-        if min(N, step) * T * self.tokens_per_frame >= 65536:
+        if min(N, step) * T * self.tokens_per_frame >= 24576:
             self.ensure_vit_fold()
         dt = abi_dtype(px)
         for n0 in range(0, N, step):

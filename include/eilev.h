@@ -87,7 +87,7 @@ typedef struct EilevVitWeights {
     const void *cls, *pos;         /* [Dv], [1 + (image/patch)^2, Dv] */
     const void *post_ln_w, *post_ln_b;
     const EilevVitLayer *layers;   /* host array, v_layers entries */
-    /* ABI version 9.  NULL, or a host array of v_layers entries.  With it, launches of at least 65 536 token rows run the blocks
+    /* ABI version 9.  NULL, or a host array of v_layers entries.  With it, launches of at least 24 576 token rows (round 4; 65 536 before) run the blocks
      * WITHOUT LayerNorm kernels: proj / fc2 (+ residual) also emit per-row (sum, sum of squares) of the stream they write, and
      * qkv / fc1 read the raw stream and compute rstd * (x . w^T - mean * csum) + b (hf modeling_blip_2.py:383-402:
      * the same function; the bf16 rounding the reference puts on the LayerNorm output sits on gamma (.) W instead).  `layers`
@@ -252,7 +252,7 @@ int eilev_linear_stats(const void *a, const void *w, const void *bias, const voi
 int eilev_ln_finalize(const float *stats, int64_t m, int64_t n, float eps, float *ln_rows, void *stream);
 int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, const float *csum, const float *ln_rows, void *c, int64_t m,
                         int64_t n, int64_t k, int epilogue, void *stream);
-/* probe / test knob: minimum token rows of a launch for the folded ViT path (default 65 536; 0 = always when layers_fold is set) */
+/* probe / test knob: minimum token rows of a launch for the folded ViT path (default 24 576; 0 = always when layers_fold is set) */
 void eilev_debug_ln_fold_min_rows(int64_t rows);
 /* The other process-global probe switches (all default 0 = the product path; tools/ and tests/ only; see the header comment):
  *   eilev_debug_gemm_flags        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)

@@ -157,7 +157,7 @@ def _vit_three_ways(cfg_name, frames):
     from hip_utils import models, rel_rms
 
     cfg, oracle, eng = models(cfg_name)
-    eng.ensure_vit_fold()  # (built lazily by the first launch of >= 65536 token rows; these fixtures are smaller)
+    eng.ensure_vit_fold()  # (built lazily by the first launch of >= 24576 token rows; these fixtures are smaller)
     assert bool(eng.pack.vit.layers_fold)
     px = synth_pixels(1, frames, cfg.vision_config.image_size)
     ref = oracle.vit(px)
@@ -169,7 +169,7 @@ def _vit_three_ways(cfg_name, frames):
         eng.lib.eilev_debug_ln_fold_min_rows(1 << 40)
         plain = eng.vit(pxd).float().cpu().numpy()
     finally:
-        eng.lib.eilev_debug_ln_fold_min_rows(65536)
+        eng.lib.eilev_debug_ln_fold_min_rows(24576)
     return ref, folded, folded2, plain, rel_rms
 
 
