@@ -24,6 +24,128 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
+def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int,
+                       length_penalty: float = 1.0, eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1,
+                       use_graph: bool = True, check_every: int = 4) -> torch.Tensor:
+    """The plain beam search of `beam_search` (no sampler, processors, stopping criteria or minimum length: the sample script's call,
+    ref:samples/eilev_generate_action_narration.py:60-73) with NOTHING per step on the host: the step index lives on the device, every
+    slice by it is an index tensor, the hypotheses are updated in place — so selection + ancestor-table update + the HIP decode step
+    are ONE captured graph replayed per generated token (the loop of `beam_search` launches ~25 small torch kernels per step from Python).
+
+    ``step_dev(next_tokens (R,), beam_src (R,) int64)``: capture-safe decode step that leaves the fp32 logits of every row in
+    ``logits_buf`` (R, V).  Same arithmetic, same torch ops and tie behaviour as `beam_search` (tests/test_beam_device_loop.py compares
+    the two loops step for step on the CPU); the early exits are looked at every ``check_every`` steps as there."""
+    dev = first_logits.device
+    B, nb, T = batch, num_beams, max_new_tokens
+    V = first_logits.shape[-1]
+    from .sampling import eos_list
+
+    eos = eos_list(eos_id)
+    eos_t = torch.tensor(eos, dtype=torch.int64, device=dev) if eos else None
+    keep = max(2, 1 + len(eos)) * nb
+    top_mask = (torch.arange(keep, device=dev) < nb)[None, :]
+    lp = float(length_penalty)
+
+    run_seq = torch.full((B, nb, T), pad_id, dtype=torch.int64, device=dev)
+    fin_seq = run_seq.clone()
+    run_len = torch.zeros((B, nb), dtype=torch.int64, device=dev)
+    fin_len = run_len.clone()
+    run_score = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+    run_score[:, 1:] = NEG
+    fin_score = torch.full((B, nb), NEG, dtype=torch.float32, device=dev)
+    finished = torch.zeros((B, nb), dtype=torch.bool, device=dev)
+    can_improve = torch.ones((B, 1), dtype=torch.bool, device=dev)
+    offs = (torch.arange(B, device=dev) * nb).view(B, 1)
+    cur_t = torch.zeros((), dtype=torch.int64, device=dev)  # tokens selected so far
+    next_tok = torch.zeros(B * nb, dtype=torch.int64, device=dev)
+    next_src = torch.zeros(B * nb, dtype=torch.int64, device=dev)
+    flags = torch.zeros(2, dtype=torch.bool, device=dev)  # [any(can_improve), all(finished)]
+    # x / float(n) ** length_penalty of `beam_search` (a tensor divided by a Python scalar) as a table over n = 1..T: ATen divides by the
+    # scalar cast to fp32 on the CPU and multiplies by its fp32 reciprocal on the GPU (BinaryDivTrueKernel) — the same here, bit for bit
+    pow_tab = torch.tensor([float(n) ** lp for n in range(1, T + 1)], dtype=torch.float64).to(torch.float32).to(dev)
+    on_gpu = dev.type == "cuda"
+    if on_gpu:
+        pow_tab = torch.ones((), dtype=torch.float32, device=dev) / pow_tab
+
+    def over_len_pow(x, idx):  # x / float(idx + 1) ** lp; idx: 0-d int64 tensor on the device
+        f = pow_tab[idx]
+        return x * f if on_gpu else x / f
+
+    def select():
+        logp = torch.log_softmax(logits_buf.view(B * nb, V).float(), dim=-1).view(B, nb, V) + run_score[:, :, None]
+        top_lp, top_ix = torch.topk(logp.view(B, nb * V), keep, dim=1)
+        src = top_ix // V
+        tok = top_ix % V
+        cand = _take(run_seq, src)
+        cand.scatter_(2, cur_t.view(1, 1, 1).expand(B, keep, 1), tok.unsqueeze(-1))  # cand[:, :, cur] = tok
+        hit = (tok.unsqueeze(-1) == eos_t).any(-1) if eos_t is not None else torch.zeros_like(tok, dtype=torch.bool)
+        hit = hit | (cur_t + 1 >= T)  # the budget: every candidate of the last step finishes
+        live_lp = top_lp + hit.float() * NEG
+        nxt = torch.topk(live_lp, nb, dim=1).indices
+        new_run_seq, new_run_score, beam_src = _take(cand, nxt), _take(live_lp, nxt), _take(src, nxt)
+        just_done = hit & top_mask
+        done_lp = over_len_pow(top_lp, cur_t)
+        if early_stopping is True:
+            done_lp = done_lp + torch.all(finished, dim=1, keepdim=True).float() * NEG
+        done_lp = done_lp + (~can_improve).float() * NEG + (~just_done).float() * NEG
+        all_seq = torch.cat((fin_seq, cand), dim=1)
+        all_score = torch.cat((fin_score, done_lp), dim=1)
+        all_len = torch.cat((fin_len, (cur_t + 1).expand_as(tok)), dim=1)
+        all_done = torch.cat((finished, just_done), dim=1)
+        best = torch.topk(all_score, nb, dim=1).indices
+        n_fs, n_fsc, n_fl, n_fd = _take(all_seq, best), _take(all_score, best), _take(all_len, best), _take(all_done, best)
+        ref_idx = torch.full_like(cur_t, T - 1) if (early_stopping == "never" and lp > 0.0) else cur_t
+        best_running = over_len_pow(new_run_score[:, :1], ref_idx)
+        worst_done = torch.where(n_fd, n_fsc.min(dim=1, keepdim=True).values, torch.full_like(n_fsc, NEG))
+        n_ci = can_improve & torch.any(best_running > worst_done, dim=1, keepdim=True)
+        # the hypotheses are updated IN PLACE (a replayed graph works on the same storage)
+        next_tok.copy_(_take(tok, nxt).reshape(-1))
+        next_src.copy_((beam_src + offs).reshape(-1))
+        run_seq.copy_(new_run_seq); run_score.copy_(new_run_score)
+        fin_seq.copy_(n_fs); fin_score.copy_(n_fsc); fin_len.copy_(n_fl); finished.copy_(n_fd); can_improve.copy_(n_ci)
+        flags[0] = n_ci.any()
+        flags[1] = n_fd.all()
+        cur_t.add_(1)
+
+    def iteration():
+        select()
+        step_dev(next_tok, next_src)
+
+    logits_buf.view(B * nb, V).copy_(first_logits.float().repeat_interleave(nb, dim=0))
+    graph = None
+    cur = 0
+    while True:
+        if cur + 1 >= T:  # the last selection: no decode step follows
+            select()
+            cur += 1
+            break
+        if graph is None or not use_graph:
+            iteration()  # (the first one runs eagerly: it is also the warm-up the capture needs)
+            if use_graph and dev.type == "cuda" and T > 3:
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                snap = [t_.clone() for t_ in (run_seq, run_score, fin_seq, fin_score, fin_len, finished, can_improve, cur_t, next_tok, next_src, flags)]
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        iteration()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                # (capture records, it does not run — but keep the state exactly as the eager iteration left it whatever the runtime did)
+                for t_, v in zip((run_seq, run_score, fin_seq, fin_score, fin_len, finished, can_improve, cur_t, next_tok, next_src, flags), snap):
+                    t_.copy_(v)
+        else:
+            graph.replay()
+        cur += 1
+        if cur % check_every == 0:
+            f = flags.tolist()
+            if not (f[0] and not (f[1] and early_stopping is True)):
+                break
+    out = fin_seq[:, :num_return_sequences].reshape(B * num_return_sequences, T)
+    n = int(fin_len[:, :num_return_sequences].max().item())
+    return out[:, : max(n, 0)]
+
+
+@torch.no_grad()
 def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
                 eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None,
                 min_new_tokens: int = 0, processors=None, stopping=None, prefix: torch.Tensor | None = None) -> torch.Tensor:

@@ -609,22 +609,44 @@ __global__ __launch_bounds__(128) void attn_decode_merge_kernel(const float *__r
 }
 
 // ---- greedy selection (hf generation/utils.py:2894-2937) ------------------------------------------------
+// finalize != 0 (one row: this block is the whole step): the step counter / unfinished count of finalize_step_kernel written here
 __global__ __launch_bounds__(1024) void select_kernel(const float *__restrict__ logits, int vocab,
-                                                      const int32_t *__restrict__ state, uint8_t *__restrict__ finished,
+                                                      int32_t *__restrict__ state, uint8_t *__restrict__ finished,
                                                       int64_t eos_id, int64_t pad_id, int64_t *__restrict__ tokens,
-                                                      int64_t *__restrict__ out_tokens, int64_t max_new) {
+                                                      int64_t *__restrict__ out_tokens, int64_t max_new, int finalize) {
     __shared__ float wv[16];
     __shared__ int wi[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float *lr = logits + (int64_t)b * vocab;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < vocab; i += 1024) {
-        const float v = lr[i];
+    auto take = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) {
             best = v;
             bi = i;
         }
+    };
+    if ((vocab & 3) == 0 && (((uintptr_t)lr) & 15) == 0) {
+        // 16-byte loads, four independent requests in flight per thread (the scalar walk below was one dependent 4-byte load per step:
+        // 20.6 us per step for 200 KB of logits, r4); a thread still meets its indices in increasing order: same winner on ties
+        const float4 *l4 = reinterpret_cast<const float4 *>(lr);
+        const int n4 = vocab >> 2;
+        for (int i0 = tid; i0 < n4; i0 += 4 * 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = i0 + u * 1024 < n4 ? l4[i0 + u * 1024] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (i0 + u * 1024) * 4;
+                if (i >= vocab) continue;
+                take(v[u].x, i);
+                take(v[u].y, i + 1);
+                take(v[u].z, i + 2);
+                take(v[u].w, i + 3);
+            }
+        }
+    } else {
+        for (int i = tid; i < vocab; i += 1024) take(lr[i], i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -651,7 +673,12 @@ __global__ __launch_bounds__(1024) void select_kernel(const float *__restrict__ 
         const int64_t tok = finished[b] ? pad_id : (int64_t)bi;
         tokens[b] = tok;
         if (step < max_new) out_tokens[(int64_t)b * max_new + step] = tok;
+        const bool fin = finished[b] || (eos_id >= 0 && tok == eos_id);
         if (eos_id >= 0 && tok == eos_id) finished[b] = 1;
+        if (finalize) {
+            state[0] = step + 1;
+            state[1] = fin ? 0 : 1;
+        }
     }
 }
 
@@ -888,8 +915,10 @@ int launch_attn_decode_part(const bf16 *qkv, bf16 *kc, bf16 *vc, float *part, si
 }
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s) {
-    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new);
+    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new,
+                       batch == 1 ? 1 : 0);
     EILEV_LAUNCH_CHECK();
+    if (batch == 1) return EILEV_OK;  // (the single block finished the step itself)
     hipLaunchKernelGGL(finalize_step_kernel, dim3(1), dim3(64), 0, s, state, finished, batch);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;

@@ -734,6 +734,26 @@ class HipEngine:
                 trace.append((next_tokens.clone(), beam_src.clone(), logits.clone()))
             return logits
 
+        if sampler is None and not rules and int(min_new_tokens) == 0 and trace is None and num_beams > 1 and getattr(self, "beam_device_loop", True):
+            # (r4) plain beam search — the sample script's call: selection, ancestor-table update and the decode step as ONE captured graph per
+            # generated token, nothing indexed by the step on the host (eilev_amd/beam.py::beam_search_device)
+            from .beam import beam_search_device
+
+            tpos = torch.zeros(1, dtype=torch.int64, device=self.device)
+            ident_row = ident32.view(1, R)
+            state[0] = 1
+
+            def step_dev(next_tokens, beam_src):
+                anc.copy_(anc.index_select(1, beam_src))  # rows of steps not reached yet hold stale slots: row t is set before it is ever read
+                anc.index_copy_(0, tpos, ident_row)
+                tokens.copy_(next_tokens)
+                launch()
+                tpos.add_(1)
+
+            out = beam_search_device(step_dev, logits, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
+                                     num_return_sequences, use_graph=use_graph)
+            self._decode_warm = True
+            return out
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step
             from .sampling import sample_loop
 
