@@ -245,7 +245,7 @@ class WeightPack:
 EXPORTS = [
     "eilev_abi_version", "eilev_backend", "eilev_vit_workspace_bytes", "eilev_vit_forward", "eilev_vit_forward_debug",
     "eilev_qformer_workspace_bytes", "eilev_qformer_forward", "eilev_project_rows", "eilev_embed_scatter",
-    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_prefill_debug", "eilev_opt_extend", "eilev_greedy_select",
+    "eilev_opt_workspace_bytes", "eilev_opt_kv_cache_bytes", "eilev_opt_prefill", "eilev_opt_prefill_debug", "eilev_opt_extend", "eilev_greedy_select", "eilev_topk_logprob", "eilev_beam_scratch_bytes", "eilev_beam_advance",
     "eilev_opt_decode_step", "eilev_opt_decode_step_beam", "eilev_linear", "eilev_linear_rows", "eilev_layernorm", "eilev_attention", "eilev_attention_probs", "eilev_prof_enable",
     "eilev_prof_collect", "eilev_t5_workspace_bytes", "eilev_t5_encode", "eilev_t5_cross_kv_bytes", "eilev_t5_cross_kv",
     "eilev_t5_self_kv_bytes", "eilev_t5_decode", "eilev_t5_decode_step", "eilev_t5_encode_debug", "eilev_t5_decode_debug", "eilev_process_workspace_bytes", "eilev_process_frames",
@@ -395,6 +395,12 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_t5_self_kv_bytes.argtypes = [TP, i64, i64]
     lib.eilev_t5_decode.restype = i32
     lib.eilev_t5_decode.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.eilev_beam_scratch_bytes.restype = sz
+    lib.eilev_beam_scratch_bytes.argtypes = [i64, i64, i64, i64]
+    lib.eilev_beam_advance.restype = i32
+    lib.eilev_beam_advance.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, sz, vp]
+    lib.eilev_topk_logprob.restype = i32
+    lib.eilev_topk_logprob.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
     lib.eilev_t5_encode_debug.restype = i32
     lib.eilev_t5_encode_debug.argtypes = [TP, C.POINTER(T5Weights), vp, vp, i64, i64, vp, vp, vp, sz, vp]
     lib.eilev_t5_decode_debug.restype = i32

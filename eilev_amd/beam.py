@@ -26,7 +26,7 @@ def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int,
                        length_penalty: float = 1.0, eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1,
-                       use_graph: bool = True, check_every: int = 4) -> torch.Tensor:
+                       use_graph: bool = True, check_every: int = 4, topk_fn=None, advance_fn=None, anc_state=None) -> torch.Tensor:
     """The plain beam search of `beam_search` (no sampler, processors, stopping criteria or minimum length: the sample script's call,
     ref:samples/eilev_generate_action_narration.py:60-73) with NOTHING per step on the host: the step index lives on the device, every
     slice by it is an index tensor, the hypotheses are updated in place — so selection + ancestor-table update + the HIP decode step
@@ -34,7 +34,16 @@ def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.T
 
     ``step_dev(next_tokens (R,), beam_src (R,) int64)``: capture-safe decode step that leaves the fp32 logits of every row in
     ``logits_buf`` (R, V).  Same arithmetic, same torch ops and tie behaviour as `beam_search` (tests/test_beam_device_loop.py compares
-    the two loops step for step on the CPU); the early exits are looked at every ``check_every`` steps as there."""
+    the two loops step for step on the CPU); the early exits are looked at every ``check_every`` steps as there.
+
+    ``topk_fn(logits_buf, run_score (B, K) f32) -> (values (R, keep) f32, token ids (R, keep) int32)``: the per-row best `keep` of
+    log_softmax + running score (`eilev_topk_logprob`: one kernel instead of torch's log_softmax + top-k over K x vocabulary, ~0.25 ms per
+    step at 5 x 50 272); the global top `keep` of a sample lie among its rows' top `keep`, merged here.
+
+    ``advance_fn(row_lp, row_tok, st)`` (with ``topk_fn``): the WHOLE bookkeeping of a step as one kernel (`eilev_beam_advance`; st = the
+    state tensors below, updated in place, plus the tokens to feed) — the ~35 small torch kernels of `select` cost ~4 us each even inside a
+    graph.  ``anc_state`` = (state, tokens): the decode step's device counter (cur = state[0] - 1) and token buffer; `step_dev` is then
+    called with (None, None): the kernel already wrote the tokens and the ancestor table."""
     dev = first_logits.device
     B, nb, T = batch, num_beams, max_new_tokens
     V = first_logits.shape[-1]
@@ -68,14 +77,36 @@ def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.T
         pow_tab = torch.ones((), dtype=torch.float32, device=dev) / pow_tab
 
     def over_len_pow(x, idx):  # x / float(idx + 1) ** lp; idx: 0-d int64 tensor on the device
-        f = pow_tab[idx]
+        f = pow_tab.index_select(0, idx.view(1))  # (not pow_tab[idx]: indexing by a 0-d tensor reads it back on the host)
         return x * f if on_gpu else x / f
 
+    fused = advance_fn is not None and topk_fn is not None
+    if fused:
+        finished = finished.to(torch.uint8)
+        can_improve = can_improve.view(B).to(torch.uint8)
+        st = dict(run_seq=run_seq, run_score=run_score, fin_seq=fin_seq, fin_score=fin_score, fin_len=fin_len, finished=finished,
+                  can_improve=can_improve, pow_tab=pow_tab, reciprocal=on_gpu, eos=eos, keep=keep,
+                  early=1 if early_stopping is True else (2 if (early_stopping == "never" and lp > 0.0) else 0))
+
+    def select_fused():
+        row_lp, row_tok = topk_fn(logits_buf, run_score)
+        advance_fn(row_lp, row_tok, st)
+        flags[0] = can_improve.any()
+        flags[1] = finished.all()
+
     def select():
-        logp = torch.log_softmax(logits_buf.view(B * nb, V).float(), dim=-1).view(B, nb, V) + run_score[:, :, None]
-        top_lp, top_ix = torch.topk(logp.view(B, nb * V), keep, dim=1)
-        src = top_ix // V
-        tok = top_ix % V
+        if fused:
+            return select_fused()
+        if topk_fn is not None:
+            row_lp, row_tok = topk_fn(logits_buf, run_score)
+            top_lp, pos = torch.topk(row_lp.view(B, nb * keep), keep, dim=1)
+            src = pos // keep
+            tok = row_tok.view(B, nb * keep).gather(1, pos).to(torch.int64)
+        else:
+            logp = torch.log_softmax(logits_buf.view(B * nb, V).float(), dim=-1).view(B, nb, V) + run_score[:, :, None]
+            top_lp, top_ix = torch.topk(logp.view(B, nb * V), keep, dim=1)
+            src = top_ix // V
+            tok = top_ix % V
         cand = _take(run_seq, src)
         cand.scatter_(2, cur_t.view(1, 1, 1).expand(B, keep, 1), tok.unsqueeze(-1))  # cand[:, :, cur] = tok
         hit = (tok.unsqueeze(-1) == eos_t).any(-1) if eos_t is not None else torch.zeros_like(tok, dtype=torch.bool)
@@ -109,7 +140,10 @@ def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.T
 
     def iteration():
         select()
-        step_dev(next_tok, next_src)
+        if fused:
+            step_dev(None, None)
+        else:
+            step_dev(next_tok, next_src)
 
     logits_buf.view(B * nb, V).copy_(first_logits.float().repeat_interleave(nb, dim=0))
     graph = None

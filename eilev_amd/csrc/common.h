@@ -218,6 +218,11 @@ int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const b
                  int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N, int K, int epi, float scale, int scale_cols, hipStream_t s);
 // misc.hip: single-query attention at small batch, one workgroup per (row, head), merged output (round 4)
 bool attn_decode1_ok(int batch, int cap, int hd);
+int launch_beam_advance(const float *row_lp, const int32_t *row_tok, int batch, int beams, int keep, int max_new, const int32_t *state,
+                        const int64_t *eos_ids, int n_eos, const float *len_pow, int recip, int early, int64_t *run_seq, float *run_score,
+                        int64_t *fin_seq, float *fin_score, int64_t *fin_len, uint8_t *finished, uint8_t *can_improve, int64_t *tokens, int32_t *anc,
+                        int gen_cap, int64_t *scratch, hipStream_t s);
+int launch_topk_logprob(const float *logits, const float *row_score, int rows, int vocab, int keep, float *out_val, int32_t *out_idx, hipStream_t s);
 int launch_attn_decode1(const bf16 *qkv, bf16 *kc, bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state, int batch, int seq_len,
                         int cap, int heads, int hd, hipStream_t s);
 int attn_decode_part_splits(int cap);  // misc.hip: the one-pass loading scheme over 128-key ranges, partials for gemv1_kernel's merge prologue (round 4)

@@ -682,6 +682,263 @@ __global__ __launch_bounds__(1024) void select_kernel(const float *__restrict__ 
     }
 }
 
+// ---- beam search: the best `keep` continuations of every row (hf generation/utils.py `_get_top_k_continuations`: log_softmax of the row's
+// logits + the row's running score, top 2K over beams x vocabulary — the global top 2K lie among the per-row top 2K, which is this
+// kernel; the merge over a sample's rows is K x 2K numbers).  One 1024-thread workgroup per row: max, sum of exp (log_softmax exactly as
+// torch evaluates it: (x - max) - log(sum exp(x - max)), fp32), then `keep` rounds of (workgroup arg-max, the owning thread drops the
+// winner and rescans its own <= 64 elements, which it holds in registers).  vocab <= 65536, vocab % 4 == 0.
+__global__ __launch_bounds__(1024) void topk_logprob_kernel(const float *__restrict__ logits, const float *__restrict__ row_score, int vocab,
+                                                            int keep, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    __shared__ float bcast[2];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float4 *l4 = reinterpret_cast<const float4 *>(logits + (int64_t)row * vocab);
+    const int n4 = vocab >> 2;
+    // the thread's <= 16 chunks of 16 bytes (chunk j = float4 index tid + 1024 j) stay in registers: every later pass is VALU only
+    float4 e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = tid + 1024 * j < n4 ? l4[tid + 1024 * j] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    // ---- row maximum
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mx = fmaxf(fmaxf(mx, fmaxf(e[j].x, e[j].y)), fmaxf(e[j].z, e[j].w));
+    mx = wave_max(mx);
+    if (lane == 0) wv[wid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float m = wv[0];
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, wv[w]);
+        bcast[0] = m;
+    }
+    __syncthreads();
+    mx = bcast[0];
+    // ---- sum of exp(x - max) (padding entries are -inf: exp = 0)
+    float sm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (tid + 1024 * j < n4) sm += (expf(e[j].x - mx) + expf(e[j].y - mx)) + (expf(e[j].z - mx) + expf(e[j].w - mx));
+    sm = wave_sum(sm);
+    __syncthreads();  // (wv is reused)
+    if (lane == 0) wv[wid] = sm;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += wv[w];
+        bcast[1] = logf(t);
+    }
+    __syncthreads();
+    const float lg = bcast[1], sc = row_score ? row_score[row] : 0.0f;
+    // ---- `keep` rounds of arg-max; `taken`: bit (j * 4 + u) = element u of chunk j already won
+    unsigned long long taken = 0;
+    float best;
+    int bi;
+    auto rescan = [&]() {
+        best = -INFINITY;
+        bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float ev[4] = {e[j].x, e[j].y, e[j].z, e[j].w};
+            const int i = tid + 1024 * j;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i < n4 && !((taken >> (j * 4 + u)) & 1ull) && (ev[u] > best || (ev[u] == best && i * 4 + u < bi))) {
+                    best = ev[u];
+                    bi = i * 4 + u;
+                }
+        }
+    };
+    rescan();
+    for (int k = 0; k < keep; ++k) {
+        float b = best;
+        int ix = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(b, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov > b || (ov == b && oi < ix)) {
+                b = ov;
+                ix = oi;
+            }
+        }
+        __syncthreads();  // (the previous round's wv / wi have been read)
+        if (lane == 0) {
+            wv[wid] = b;
+            wi[wid] = ix;
+        }
+        __syncthreads();
+        b = wv[0];
+        ix = wi[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w)
+            if (wv[w] > b || (wv[w] == b && wi[w] < ix)) {
+                b = wv[w];
+                ix = wi[w];
+            }
+        if (tid == 0) {
+            out_val[(int64_t)row * keep + k] = ((b - mx) - lg) + sc;
+            out_idx[(int64_t)row * keep + k] = ix == 0x7fffffff ? 0 : ix;
+        }
+        if (ix != 0x7fffffff && ((ix >> 2) & 1023) == tid) {  // this thread owned the winner: chunk j = (ix / 4) / 1024, element ix % 4
+            taken |= 1ull << ((((ix >> 2) >> 10) << 2) + (ix & 3));
+            rescan();
+        }
+    }
+}
+
+// ---- beam search bookkeeping of one step (include/eilev.h eilev_beam_advance; oracle/eilev_ref.c holds the plain restatement).  One
+// workgroup per sample: lane-parallel arg-max rounds for the three small top-k selections, thread 0 for the scalar rules, all threads
+// for the sequence rows (T int64 each).  Everything a step needs from the previous one is read before the first write (LDS / registers),
+// then a barrier, then the in-place update.
+struct BeamAdvanceArgs {
+    const float *row_lp;
+    const int32_t *row_tok;
+    const int32_t *state;
+    const float *len_pow;
+    int64_t eos[8];
+    int n_eos, beams, keep, T, early, recip, gen_cap, batch;
+    int64_t *run_seq, *fin_seq, *fin_len, *tokens, *scratch;  // scratch: (batch, keep + 2 * beams, T)
+    float *run_score, *fin_score;
+    uint8_t *finished, *can_improve;
+    int32_t *anc;
+};
+
+__device__ __forceinline__ void beam_topk_lds(float *v, int n, int k, int *out, float *red_v, int *red_i) {  // v is consumed (winners -> -inf-like)
+    const int tid = threadIdx.x;
+    for (int a = 0; a < k; ++a) {
+        float b = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            const float x = v[i];
+            if (!(__builtin_bit_cast(unsigned, x) == 0xffc00001u) && (bi == 0x7fffffff || x > b)) {  // (0xffc00001: the "taken" marker, a NaN no score is)
+                b = x;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(b, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > b || (ov == b && oi < bi))) {
+                b = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            red_v[tid >> 6] = b;
+            red_i[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (red_i[w] != 0x7fffffff && (bi == 0x7fffffff || red_v[w] > b || (red_v[w] == b && red_i[w] < bi))) {
+                    b = red_v[w];
+                    bi = red_i[w];
+                }
+            out[a] = bi;
+            v[bi] = __builtin_bit_cast(float, 0xffc00001u);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_advance_kernel(const BeamAdvanceArgs a) {
+    constexpr float NEG = -1.0e9f;
+    __shared__ float cv[2048], cv0[2048], live[64], live0[64], top_lp[64], all_score[96], all_score0[96], red_v[4], nfsc[32], nrsc[32];
+    __shared__ int order[64], nxt[32], best[32], src[64], red_i[4], hit[64], jd[64];
+    __shared__ int64_t tok[64], nfl[32];
+    __shared__ uint8_t nfd[32];
+    __shared__ int32_t acol[32 * 64];  // gen_cap <= 64 ancestor rows of the sample's columns (larger tables: scratch-free second pass below)
+    const int b = blockIdx.x, tid = threadIdx.x, K = a.beams, keep = a.keep, T = a.T, C = K * keep, R = a.batch * K;
+    const int cur = a.state[0] - 1;
+    for (int c = tid; c < C; c += 256) cv[c] = cv0[c] = a.row_lp[(int64_t)(b * K + c / keep) * keep + c % keep];
+    __syncthreads();
+    beam_topk_lds(cv, C, keep, order, red_v, red_i);
+    if (tid < keep) {
+        const int k = tid, o = order[k];
+        top_lp[k] = cv0[o];
+        src[k] = o / keep;
+        const int64_t t_ = a.row_tok[(int64_t)(b * K + src[k]) * keep + o % keep];
+        tok[k] = t_;
+        int h = cur + 1 >= T;
+        for (int e = 0; e < a.n_eos; ++e) h |= t_ == a.eos[e];
+        hit[k] = h;
+        live[k] = live0[k] = top_lp[k] + (h ? 1.0f : 0.0f) * NEG;
+    }
+    __syncthreads();
+    // candidate sequences -> scratch rows 0 .. keep - 1
+    int64_t *cand = a.scratch + (int64_t)b * (keep + 2 * K) * T, *nfs = cand + (int64_t)keep * T, *nrs = nfs + (int64_t)K * T;
+    for (int i = tid; i < keep * T; i += 256) {
+        const int k = i / T, p = i - k * T;
+        cand[i] = p == cur ? tok[k] : a.run_seq[(int64_t)(b * K + src[k]) * T + p];
+    }
+    beam_topk_lds(live, keep, K, nxt, red_v, red_i);
+    if (tid == 0) {
+        int all_fin = 1;
+        for (int j = 0; j < K; ++j) all_fin &= a.finished[b * K + j] != 0;
+        const float lp_f = a.len_pow[cur];
+        const bool ci = a.can_improve[b] != 0;
+        for (int k = 0; k < keep; ++k) {
+            jd[k] = hit[k] && k < K;
+            float d = a.recip ? top_lp[k] * lp_f : top_lp[k] / lp_f;
+            if (a.early == 1) d = d + (all_fin ? 1.0f : 0.0f) * NEG;
+            d = d + (ci ? 0.0f : 1.0f) * NEG;
+            d = d + (jd[k] ? 0.0f : 1.0f) * NEG;
+            all_score[K + k] = all_score0[K + k] = d;
+        }
+        for (int j = 0; j < K; ++j) all_score[j] = all_score0[j] = a.fin_score[b * K + j];
+    }
+    __syncthreads();
+    beam_topk_lds(all_score, K + keep, K, best, red_v, red_i);
+    if (tid == 0) {
+        for (int j = 0; j < K; ++j) {
+            const int s_ = best[j];
+            nfsc[j] = all_score0[s_];
+            nfl[j] = s_ < K ? a.fin_len[b * K + s_] : (int64_t)(cur + 1);
+            nfd[j] = s_ < K ? a.finished[b * K + s_] : (uint8_t)jd[s_ - K];
+            nrsc[j] = live0[nxt[j]];
+        }
+        const float rp = a.len_pow[a.early == 2 ? T - 1 : cur];
+        const float best_running = a.recip ? nrsc[0] * rp : nrsc[0] / rp;
+        float mn = nfsc[0];
+        for (int j = 1; j < K; ++j) mn = fminf(mn, nfsc[j]);
+        int any = 0;
+        for (int j = 0; j < K; ++j) any |= best_running > (nfd[j] ? mn : NEG);
+        a.can_improve[b] = (uint8_t)(a.can_improve[b] && any);
+    }
+    __syncthreads();
+    // new finished / running rows -> scratch (they gather from rows that are about to be overwritten), ancestor columns -> LDS
+    for (int i = tid; i < K * T; i += 256) {
+        const int j = i / T, p = i - j * T, s_ = best[j];
+        nfs[i] = s_ < K ? a.fin_seq[(int64_t)(b * K + s_) * T + p] : cand[(int64_t)(s_ - K) * T + p];
+        nrs[i] = cand[(int64_t)nxt[j] * T + p];
+    }
+    if (a.anc)
+        for (int i = tid; i < a.gen_cap * K; i += 256) {
+            const int g = i / K, j = i - g * K;
+            acol[i] = a.anc[(int64_t)g * R + b * K + src[nxt[j]]];
+        }
+    __syncthreads();
+    __threadfence_block();
+    for (int i = tid; i < K * T; i += 256) {
+        a.fin_seq[(int64_t)b * K * T + i] = nfs[i];
+        a.run_seq[(int64_t)b * K * T + i] = nrs[i];
+    }
+    if (a.anc)
+        for (int i = tid; i < a.gen_cap * K; i += 256) {
+            const int g = i / K, j = i - g * K;
+            a.anc[(int64_t)g * R + b * K + j] = g == cur ? b * K + j : acol[i];
+        }
+    if (tid < K) {
+        const int j = tid;
+        a.tokens[b * K + j] = tok[nxt[j]];
+        a.run_score[b * K + j] = nrsc[j];
+        a.fin_score[b * K + j] = nfsc[j];
+        a.fin_len[b * K + j] = nfl[j];
+        a.finished[b * K + j] = nfd[j];
+    }
+}
+
 __global__ void finalize_step_kernel(int32_t *__restrict__ state, const uint8_t *__restrict__ finished, int batch) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         int unf = 0;
@@ -910,6 +1167,27 @@ int launch_attn_decode_part(const bf16 *qkv, bf16 *kc, bf16 *vc, float *part, si
     if (part_bytes < (size_t)batch * heads * ns * (hd + 2) * sizeof(float)) return EILEV_E_WORKSPACE;
     hipLaunchKernelGGL((attn_decode_part_kernel<10, 6>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, kc, vc, part, attn_mask, state, seq_len, cap, heads,
                        3 * (int64_t)heads * hd);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_topk_logprob(const float *logits, const float *row_score, int rows, int vocab, int keep, float *out_val, int32_t *out_idx, hipStream_t s) {
+    if (vocab > 65536 || (vocab & 3) || keep < 1 || keep > 64 || (((uintptr_t)logits) & 15)) return EILEV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(topk_logprob_kernel, dim3(rows), dim3(1024), 0, s, logits, row_score, vocab, keep, out_val, out_idx);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+int launch_beam_advance(const float *row_lp, const int32_t *row_tok, int batch, int beams, int keep, int max_new, const int32_t *state,
+                        const int64_t *eos_ids, int n_eos, const float *len_pow, int recip, int early, int64_t *run_seq, float *run_score,
+                        int64_t *fin_seq, float *fin_score, int64_t *fin_len, uint8_t *finished, uint8_t *can_improve, int64_t *tokens, int32_t *anc,
+                        int gen_cap, int64_t *scratch, hipStream_t s) {
+    if (beams * keep > 2048 || keep > 64 || beams > 32 || (anc && gen_cap * beams > 32 * 64) || n_eos > 8) return EILEV_E_UNSUPPORTED;
+    BeamAdvanceArgs a;
+    a.row_lp = row_lp; a.row_tok = row_tok; a.state = state; a.len_pow = len_pow;
+    for (int e = 0; e < n_eos; ++e) a.eos[e] = eos_ids[e];  // (host array)
+    a.n_eos = n_eos; a.beams = beams; a.keep = keep; a.T = max_new; a.early = early; a.recip = recip; a.gen_cap = gen_cap; a.batch = batch;
+    a.run_seq = run_seq; a.fin_seq = fin_seq; a.fin_len = fin_len; a.tokens = tokens; a.scratch = scratch;
+    a.run_score = run_score; a.fin_score = fin_score; a.finished = finished; a.can_improve = can_improve; a.anc = anc;
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(batch), dim3(256), 0, s, a);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

@@ -849,6 +849,30 @@ extern "C" int eilev_greedy_select(const float *logits, int64_t batch, int64_t v
                          (hipStream_t)stream);
 }
 
+extern "C" int eilev_topk_logprob(const float *logits, const float *row_score, int64_t rows, int64_t vocab, int64_t keep, float *out_val,
+                                  int32_t *out_idx, void *stream) {
+    if (!logits || !out_val || !out_idx || rows < 0 || vocab <= 0 || keep <= 0 || keep > vocab) return EILEV_E_BADARG;
+    if (rows == 0) return EILEV_OK;
+    return launch_topk_logprob(logits, row_score, (int)rows, (int)vocab, (int)keep, out_val, out_idx, (hipStream_t)stream);
+}
+
+extern "C" size_t eilev_beam_scratch_bytes(int64_t batch, int64_t beams, int64_t keep, int64_t max_new) {
+    return sizeof(int64_t) * (size_t)batch * (size_t)(keep + 2 * beams) * (size_t)max_new;
+}
+extern "C" int eilev_beam_advance(const float *row_lp, const int32_t *row_tok, int64_t batch, int64_t beams, int64_t keep, int64_t max_new,
+                                  const int32_t *state, const int64_t *eos_ids, int64_t n_eos, const float *len_pow, int len_pow_reciprocal,
+                                  int early_stopping, int64_t *run_seq, float *run_score, int64_t *fin_seq, float *fin_score, int64_t *fin_len,
+                                  uint8_t *finished, uint8_t *can_improve, int64_t *tokens, int32_t *anc, int64_t gen_cap, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
+    if (!row_lp || !row_tok || !state || !len_pow || !run_seq || !run_score || !fin_seq || !fin_score || !fin_len || !finished || !can_improve ||
+        !tokens || batch <= 0 || beams <= 0 || keep < beams || max_new <= 0 || n_eos < 0 || (n_eos > 0 && !eos_ids))
+        return EILEV_E_BADARG;
+    if (!scratch || scratch_bytes < eilev_beam_scratch_bytes(batch, beams, keep, max_new)) return EILEV_E_WORKSPACE;
+    return launch_beam_advance(row_lp, row_tok, (int)batch, (int)beams, (int)keep, (int)max_new, state, eos_ids, (int)n_eos, len_pow,
+                               len_pow_reciprocal, early_stopping, run_seq, run_score, fin_seq, fin_score, fin_len, finished, can_improve, tokens,
+                               anc, (int)gen_cap, (int64_t *)scratch, (hipStream_t)stream);
+}
+
 extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *w, int64_t *tokens, int32_t *state,
                                      const int32_t *attn_mask, const int32_t *n_valid, int64_t batch, int64_t seq_len,
                                      void *kv_cache, int64_t kv_capacity, float *logits, uint8_t *finished, int64_t eos_id,

@@ -750,8 +750,42 @@ class HipEngine:
                 launch()
                 tpos.add_(1)
 
+            from .sampling import eos_list
+
+            keep = max(2, 1 + len(eos_list(eos_id))) * num_beams
+            topk_fn = None
+            if d.vocab <= 65536 and d.vocab % 4 == 0 and keep <= 64 and getattr(self, "beam_topk_kernel", True):
+                row_lp = torch.empty((R, keep), dtype=torch.float32, device=self.device)
+                row_tok = torch.empty((R, keep), dtype=torch.int32, device=self.device)
+
+                def topk_fn(buf, run_score):
+                    abi.check(self.lib.eilev_topk_logprob(_ptr(buf), _ptr(run_score), R, d.vocab, keep, _ptr(row_lp), _ptr(row_tok), self._stream()),
+                              "eilev_topk_logprob")
+                    return row_lp, row_tok
+
+            advance_fn = None
+            if topk_fn is not None and num_beams * keep <= 2048 and gen_cap * num_beams <= 2048 and len(eos_list(eos_id)) <= 8 and \
+                    getattr(self, "beam_advance_kernel", True):
+                eos_l = eos_list(eos_id)
+                eos_arr = (C.c_int64 * max(1, len(eos_l)))(*eos_l)
+                scratch = torch.empty(int(self.lib.eilev_beam_scratch_bytes(B, num_beams, keep, max_new_tokens)), dtype=torch.uint8, device=self.device)
+
+                def advance_fn(lp_rows, tok_rows, st):  # the whole bookkeeping of a step, the tokens to feed and the ancestor table: one kernel
+                    abi.check(self.lib.eilev_beam_advance(
+                        _ptr(lp_rows), _ptr(tok_rows), B, num_beams, keep, max_new_tokens, _ptr(state), eos_arr, len(eos_l), _ptr(st["pow_tab"]),
+                        int(st["reciprocal"]), int(st["early"]), _ptr(st["run_seq"]), _ptr(st["run_score"]), _ptr(st["fin_seq"]), _ptr(st["fin_score"]),
+                        _ptr(st["fin_len"]), _ptr(st["finished"]), _ptr(st["can_improve"]), _ptr(tokens), _ptr(anc), gen_cap, _ptr(scratch),
+                        scratch.numel(), self._stream()), "eilev_beam_advance")
+
+                def step_dev(next_tokens, beam_src):  # noqa: F811 (tokens / ancestors were written by eilev_beam_advance)
+                    launch()
+
+            # with the two selection kernels a step is ONE C call that enqueues ~260 kernels (2.5 ms of GPU work): capturing it buys nothing per
+            # token (2.565 vs 2.554 ms) and costs ~1.2 ms per generate() call — replayed graphs only on request (`engine.beam_capture = True`)
+            # or when the selection runs as torch ops
+            capture = use_graph and (advance_fn is None or getattr(self, "beam_capture", False))
             out = beam_search_device(step_dev, logits, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
-                                     num_return_sequences, use_graph=use_graph)
+                                     num_return_sequences, use_graph=capture, topk_fn=topk_fn, advance_fn=advance_fn)
             self._decode_warm = True
             return out
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step

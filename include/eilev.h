@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs (round 4) */
+#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -411,6 +411,31 @@ int eilev_t5_decode_step(const EilevT5Dims *d, const EilevT5Weights *w, const in
  * 32 blocks against the KV cache (slot seq_len + step - 1), final LN, lm_head, then
  * eilev_greedy_select.  Every launch parameter that changes between steps is read from `state`
  * on the device, so the call can be captured once into a hipGraph and replayed. */
+/* ABI version 13 (round 4).  Beam search, the vocabulary-sized part of one step (hf generation/utils.py `_beam_search` ->
+ * `_get_top_k_continuations`, the sample script's default: ref:samples/eilev_generate_action_narration.py:60-73): for every row r
+ *   out_val[r, 0..keep) = the `keep` largest of log_softmax(logits[r, :]) + row_score[r], descending (ties: lower token id first),
+ *   out_idx[r, 0..keep) = their token ids.
+ * The top 2K over a sample's K rows x vocabulary are among its rows' top 2K: the merge is K x 2K numbers (eilev_amd/beam.py).
+ * log_softmax as torch evaluates it in fp32: (x - max) - log(sum exp(x - max)).  row_score nullable (0).  HIP: vocab <= 65536, % 4 == 0. */
+int eilev_topk_logprob(const float *logits, const float *row_score, int64_t rows, int64_t vocab, int64_t keep, float *out_val,
+                       int32_t *out_idx, void *stream);
+/* ABI version 13 (round 4).  The bookkeeping of that step for every sample, on eilev_topk_logprob's output (rows = batch * beams, row b * beams + j =
+ * beam j of sample b): merge to the sample's top `keep` continuations, next running beams (the best `beams` that did not stop), finished set
+ * (only the top `beams` candidates may finish; score / len ** length_penalty; frozen once nothing can improve), the early_stopping=False
+ * heuristic (hf `_get_running_beams_for_next_iteration`, `_update_finished_beams`, `_check_early_stop_heuristic`), then what the decode step
+ * reads: tokens (rows) to feed and, when anc != NULL, the ancestor table of eilev_opt_decode_step_beam updated in place (column r continues the
+ * hypothesis that lived in row src[r]; row `cur` = identity).  cur = state[0] - 1 (state = the decode step's counter, on the device for the HIP
+ * library: preset to 1 before the first step).  len_pow[n - 1] = float(n) ** length_penalty, or its fp32 reciprocal when len_pow_reciprocal
+ * (x / scalar is x * (1 / scalar) in torch's GPU kernel, a true division on the CPU: eilev_amd/beam.py keeps either bit for bit).
+ * early_stopping: 0 False / "never" with length_penalty <= 0, 1 True, 2 "never" with length_penalty > 0.  eos_ids: host array (n_eos <= 8).
+ * Sequences (batch, beams, max_new) int64, scores f32, fin_len int64, finished / can_improve uint8, all updated in place.  Equal scores: the
+ * lower candidate index wins.  HIP: beams <= 32, keep <= 64, beams * keep <= 2048, gen_cap * beams <= 2048. */
+size_t eilev_beam_scratch_bytes(int64_t batch, int64_t beams, int64_t keep, int64_t max_new);
+int eilev_beam_advance(const float *row_lp, const int32_t *row_tok, int64_t batch, int64_t beams, int64_t keep, int64_t max_new,
+                       const int32_t *state, const int64_t *eos_ids, int64_t n_eos, const float *len_pow, int len_pow_reciprocal,
+                       int early_stopping, int64_t *run_seq, float *run_score, int64_t *fin_seq, float *fin_score, int64_t *fin_len,
+                       uint8_t *finished, uint8_t *can_improve, int64_t *tokens, int32_t *anc, int64_t gen_cap, void *scratch,
+                       size_t scratch_bytes, void *stream);
 int eilev_greedy_select(const float *logits, int64_t batch, int64_t vocab, int32_t *state,
                         uint8_t *finished, int64_t eos_id, int64_t pad_id, int64_t *tokens,
                         int64_t *out_tokens, int64_t max_new, void *stream);

@@ -1,0 +1,93 @@
+"""-m gpu: eilev_topk_logprob (the vocabulary-sized part of a beam-search step, one kernel) against the CPU oracle and torch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from eilev_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,vocab,keep,scale", [(5, 50272, 10, 3.0), (15, 50272, 6, 0.5), (32, 512, 10, 2.0), (3, 65536, 20, 6.0), (1, 8, 8, 1.0)])
+def test_topk_logprob_vs_oracle_and_torch(rows, vocab, keep, scale):
+    from oracle import runner
+
+    torch.manual_seed(rows * 7 + keep)
+    x = (torch.randn(rows, vocab, device="cuda") * scale).float().contiguous()
+    sc = torch.randn(rows, device="cuda")
+    val = torch.empty((rows, keep), dtype=torch.float32, device="cuda")
+    idx = torch.empty((rows, keep), dtype=torch.int32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    abi.check(abi.load_hip().eilev_topk_logprob(P(x), P(sc), rows, vocab, keep, P(val), P(idx), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "topk")
+    xh, sh = x.cpu().numpy(), sc.cpu().numpy()
+    ov, oi = np.empty((rows, keep), np.float32), np.empty((rows, keep), np.int32)
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert runner.lib().eilev_topk_logprob(pp(xh), pp(sh), rows, vocab, keep, pp(ov), pp(oi), None) == 0
+    assert np.array_equal(idx.cpu().numpy(), oi)  # bit-exact for the index work
+    assert np.abs(val.cpu().numpy() - ov).max() < 4e-6  # (sum of exp in another order)
+    tv, ti = torch.topk(torch.log_softmax(x, -1) + sc[:, None], keep, dim=1)
+    assert torch.equal(ti.int(), idx) and float((tv - val).abs().max()) < 4e-6
+
+
+def test_topk_logprob_ties_and_masked_entries():
+    """equal logits: lower token id first; -inf entries (a masked vocabulary slot) never win while finite ones remain"""
+    x = torch.zeros(2, 64, device="cuda")
+    x[0, 10] = x[0, 3] = 5.0
+    x[1, :] = float("-inf")
+    x[1, 7] = 1.0
+    x[1, 9] = 1.0
+    val = torch.empty((2, 3), dtype=torch.float32, device="cuda")
+    idx = torch.empty((2, 3), dtype=torch.int32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    abi.check(abi.load_hip().eilev_topk_logprob(P(x), None, 2, 64, 3, P(val), P(idx), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "topk")
+    assert idx[0].tolist() == [3, 10, 0] and idx[1].tolist()[:2] == [7, 9]
+    assert torch.isinf(val[1, 2]) and float(val[1, 2]) < 0
+
+
+@pytest.mark.parametrize("B,nb,n_eos,T,early,recip", [(1, 5, 1, 32, 0, 1), (3, 4, 2, 12, 1, 0), (2, 8, 0, 40, 2, 1), (6, 5, 1, 7, 0, 1), (1, 32, 1, 16, 0, 1)])
+def test_beam_advance_vs_oracle_step_by_step(B, nb, n_eos, T, early, recip):
+    """eilev_beam_advance (one kernel: the whole hf beam bookkeeping of a step, tokens, ancestor table) against the C restatement, driven for
+    several consecutive steps from random per-row candidates: every state tensor bit-exact after every step."""
+    from oracle import runner
+
+    hip, orc = abi.load_hip(), runner.lib()
+    keep = max(2, 1 + n_eos) * nb
+    R = B * nb
+    g = torch.Generator().manual_seed(B * 100 + nb)
+    eos = [3, 11][:n_eos]
+    eos_arr = (C.c_int64 * max(1, n_eos))(*eos)
+    lp = -1.0 if early != 2 else 1.5
+    pw = torch.tensor([float(n) ** lp for n in range(1, T + 1)], dtype=torch.float64).float()
+    if recip:
+        pw = torch.ones((), dtype=torch.float32) / pw
+
+    def fresh(dev):
+        st = dict(run_seq=torch.full((B, nb, T), 1, dtype=torch.int64), fin_seq=torch.full((B, nb, T), 1, dtype=torch.int64),
+                  fin_len=torch.zeros((B, nb), dtype=torch.int64), run_score=torch.zeros((B, nb)), fin_score=torch.full((B, nb), -1.0e9),
+                  finished=torch.zeros((B, nb), dtype=torch.uint8), can_improve=torch.ones(B, dtype=torch.uint8),
+                  tokens=torch.zeros(R, dtype=torch.int64), anc=torch.zeros((T, R), dtype=torch.int32), state=torch.ones(2, dtype=torch.int32),
+                  pw=pw.clone())
+        st["run_score"][:, 1:] = -1.0e9
+        return {k: v.to(dev) for k, v in st.items()}
+
+    sh, so = fresh("cuda"), fresh("cpu")
+    scratch = torch.empty(int(hip.eilev_beam_scratch_bytes(B, nb, keep, T)), dtype=torch.uint8, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(T):
+        row_lp = (torch.randn(R, keep, generator=g).sort(dim=1, descending=True).values * 2 - 4) + so["run_score"].reshape(R, 1).clamp(min=-50)
+        row_lp = row_lp.float().contiguous()
+        row_tok = torch.randint(0, 20, (R, keep), generator=g, dtype=torch.int32)
+        for lib, st, dev, scr, nscr, strm in ((hip, sh, "cuda", scratch, scratch.numel(), stream), (orc, so, "cpu", None, 0, None)):
+            a, b_ = row_lp.to(dev), row_tok.to(dev)
+            rc = lib.eilev_beam_advance(P(a), P(b_), B, nb, keep, T, P(st["state"]), eos_arr, n_eos, P(st["pw"]), recip, early, P(st["run_seq"]),
+                                        P(st["run_score"]), P(st["fin_seq"]), P(st["fin_score"]), P(st["fin_len"]), P(st["finished"]), P(st["can_improve"]),
+                                        P(st["tokens"]), P(st["anc"]), T, None if scr is None else P(scr), nscr, strm)
+            assert rc == 0, rc
+            st["state"][0] += 1  # (the decode step's increment)
+        torch.cuda.synchronize()
+        for k in ("run_seq", "fin_seq", "fin_len", "run_score", "fin_score", "finished", "can_improve", "tokens", "anc"):
+            assert torch.equal(sh[k].cpu(), so[k]), (step, k)
+    assert so["finished"].any()

@@ -168,3 +168,25 @@ def test_varied_beam_steps_teacher_forced(golden_dir, name, nb, use_graph):
             assert e <= 1e-2, (t, r, e)
     assert len(parents_used) >= 2  # the search really re-parented rows (otherwise the ancestor table was never exercised)
     record_parity(f"varied[{name}]", **{f"beam{nb}_teacher_forced_rel_rms_max": worst})
+
+
+@pytest.mark.parametrize("name,nb,lp,eos_key", [("mid_v1", 5, -1.0, "fp32_eos_id"), ("mid_v2", 3, 1.0, None), ("real_v1", 5, -1.0, None)])
+def test_device_beam_loop_equals_host_loop(golden_dir, name, nb, lp, eos_key):
+    """generate(num_beams=k)'s default route (round 4: eilev_amd/beam.py::beam_search_device — selection, ancestor-table update and the
+    decode step as one captured graph per token, the step index on the device) returns the hypotheses of the host loop, graph and eager."""
+    g, meta, px = load(golden_dir, name)
+    cfg, oracle, eng = models(meta["config"], meta["weight_mode"], seed=meta["weight_seed"])
+    emb, am = prompt(eng, g, px)
+    n = max(8, int(meta.get("beam_new_tokens", meta["new_tokens"])))
+    eos = int(g[eos_key]) if eos_key else -1
+    runs = {}
+    # host loop | device loop with the two selection kernels (eager launches, the default; captured) | device loop with torch selection ops
+    for tag, dev_loop, graph, capture, kernels in (("host", False, True, False, True), ("kernels eager", True, True, False, True),
+                                                   ("kernels graph", True, True, True, True), ("torch graph", True, True, False, False),
+                                                   ("torch eager", True, False, False, False)):
+        eng.beam_device_loop, eng.beam_capture, eng.beam_advance_kernel, eng.beam_topk_kernel = dev_loop, capture, kernels, kernels
+        runs[tag] = eng.beam_decode(emb, am, n, nb, lp, eos_id=eos, pad_id=1, use_graph=graph, num_return_sequences=min(2, nb)).cpu().numpy()
+    eng.beam_device_loop, eng.beam_capture, eng.beam_advance_kernel, eng.beam_topk_kernel = True, False, True, True
+    for tag in runs:
+        assert np.array_equal(runs[tag], runs["host"]), (tag, runs[tag], runs["host"])
+    assert runs["host"].shape[0] == g["input_ids"].shape[0] * min(2, nb)
