@@ -607,7 +607,7 @@ __global__ __launch_bounds__(576) void attn_frame_kernel(const AttnArgs a) {
     // tile 2 m, odd g: tile 2 m + 1) -> 16-byte stores, 64 contiguous bytes per query row
     auto store_o = [&](const f32x4 (&o)[DT], float l, bf16 *ob, int ti) {
         const int row = (wid + NW * ti) * 16 + l15;
-        const float inv = 1.0f / l;
+        const float inv = __builtin_amdgcn_rcpf(l);  // (l >= 1; the same reciprocal as attn_frame3_kernel: patch rows stay bit-identical between the two)
         bf16 *op = ob + (int64_t)(row < S ? row : 0) * a.ldo + ((g & 1) * 16 + (g >> 1) * 8);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
