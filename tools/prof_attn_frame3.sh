@@ -11,4 +11,4 @@ for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_VALU_
     echo "== $grp"
     python $R/tools/rocpd_pmc.py /tmp/pm/pm_results.db attn_frame 2>&1 | tail -14
 done
-} > $O/r03_attn_frame3_pmc.txt 2>&1
+} > $O/${TAG:-r04}_attn_frame3_pmc.txt 2>&1
