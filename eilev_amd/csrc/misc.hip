@@ -489,10 +489,16 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
 // The same loading scheme over a RANGE of keys: 256 threads own keys [128 sp, 128 sp + 128) of one (row, head) and leave the un-normalised
 // partial (max, sum, o[hd]) in `part` — the flash-decoding format of attn_decode_split_kernel, merged by the consumer (gemv1_kernel's prologue
 // of out_proj).  One workgroup per head pulls 307 KB through ONE CU (12.1 us at batch 1); 8 splits put 38 KB on each of 256 CUs.
-template <int NCH, int VK>
+// BEAM (r4, eilev_opt_decode_step_beam at <= 8 rows of head size 80): the addressing of attn_decode_split_kernel's beam form — keys below
+// seq_len in the prompt cache of sample b / beams, key seq_len + g in generation-cache row anc[g][b], the new token to this row's own slot —
+// with this kernel's 128-key ranges and up-front loads: 5 rows x 32 heads x 8 ranges = 1280 workgroups where the 256-key split kernel ran 640
+// of twice the length (15.3 us per block for 5 rows).
+template <int NCH, int VK, bool BEAM = false>
 __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                                float *__restrict__ part, const int32_t *__restrict__ attn_mask,
-                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
+                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq,
+                                                               bf16 *__restrict__ kg_ = nullptr, bf16 *__restrict__ vg_ = nullptr,
+                                                               const int32_t *__restrict__ anc = nullptr, int beams = 1, int cap_g = 0, int rows = 0) {
     constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1, KEYS = 128;
     static_assert(G * VK >= KEYS, "every key of the range needs an owner");
     __shared__ __attribute__((aligned(16))) float qs[128];
@@ -501,8 +507,9 @@ __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__res
     __shared__ float red[KEYS * RS > G * hd ? KEYS * RS : G * hd];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z, d = heads * hd;
-    const int kv_total = min(cap, seq_len + state[0]);
-    const int slot_new = kv_total - 1;
+    const int kv_total = BEAM ? min(seq_len + cap_g, seq_len + state[0]) : min(cap, seq_len + state[0]);
+    // (beam form: a caller that passes a step count of 0, or more than the generation cache holds, must not make this row write outside its slots)
+    const int slot_new = BEAM && (kv_total - 1 < seq_len || state[0] > cap_g) ? -1 : kv_total - 1;
     const int k0 = sp * KEYS, k1 = min(kv_total, k0 + KEYS);
     float *po = part + (((int64_t)b * heads + h) * nsplit + sp) * (hd + 2);
     if (k0 >= kv_total) {  // nothing in this split yet
@@ -512,28 +519,37 @@ __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__res
         }
         return;
     }
-    bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    const int srow = BEAM ? b / beams : b;  // row of the prompt cache and of the attention mask
+    bf16 *kbase = kc + ((int64_t)srow * heads + h) * cap * hd, *vbase = vc + ((int64_t)srow * heads + h) * cap * hd;
     const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
+    auto key_row = [&](const bf16 *base, const bf16 *gen, int j) -> const bf16 * {
+        if (!BEAM || j < seq_len) return base + (int64_t)j * hd;
+        const int gi = j - seq_len;
+        int a = anc[(int64_t)gi * rows + b];  // (an entry outside [0, rows) must not become an address)
+        a = a < 0 ? 0 : (a >= rows ? rows - 1 : a);
+        return gen + (((int64_t)a * heads + h) * cap_g + gi) * hd;
+    };
     const int c = tid % NCH, kg = tid / NCH;
     bf16x8 kr[VK], vr[VK];
 #pragma unroll
     for (int i = 0; i < VK; ++i) {
         int key = k0 + kg + i * G;
         key = key < k1 ? key : k1 - 1;
-        kr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? knew : kbase + (int64_t)key * hd) + c * 8);
+        kr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? knew : key_row(kbase, kg_, key)) + c * 8);
     }
 #pragma unroll
     for (int i = 0; i < VK; ++i) {
         int key = k0 + kg + i * G;
         key = key < k1 ? key : k1 - 1;
-        vr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? vnew : vbase + (int64_t)key * hd) + c * 8);
+        vr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? vnew : key_row(vbase, vg_, key)) + c * 8);
     }
     const int jt = k0 + tid;  // thread t < KEYS owns key k0 + t for the softmax
-    const bool vis = tid < KEYS && jt < k1 && (jt >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + jt] != 0);
+    const bool vis = tid < KEYS && jt < k1 && (jt >= seq_len || !attn_mask || attn_mask[(int64_t)srow * seq_len + jt] != 0);
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
     if (slot_new >= k0 && slot_new < k1 && tid >= 256 - 2 * NCH) {  // the split that owns the newest slot stores it to the cache
         const int t2 = tid - (256 - 2 * NCH), which = t2 / NCH, cc = t2 - which * NCH;
-        *reinterpret_cast<bf16x8 *>((which ? vbase : kbase) + (int64_t)slot_new * hd + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
+        bf16 *dst = BEAM ? (which ? vg_ : kg_) + (((int64_t)b * heads + h) * cap_g + (slot_new - seq_len)) * hd : (which ? vbase : kbase) + (int64_t)slot_new * hd;
+        *reinterpret_cast<bf16x8 *>(dst + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
     }
     __syncthreads();
     if (kg < G) {
@@ -1121,6 +1137,8 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
+static int g_beam_part = 1;
+extern "C" int eilev_debug_beam_part(int on) { g_beam_part = on; return 0; }  // probe / test switch: 0 = the 256-key split kernel for beam rows too (round 3)
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
     const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
     return sizeof(float) * (size_t)batch * heads * nsplit * (hd + 2);
@@ -1132,6 +1150,19 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
     if (ldq == 0) ldq = 3 * (int64_t)heads * hd;  // q | k | v rows
     if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
     const int cap_all = anc ? seq_len + cap_g : cap;  // beam form: prompt keys (prefill cache) + generated keys (generation cache)
+    if (anc && out && state && fuse_new && !rel_tab && hd == 80 && batch <= 8 && cap_all <= 2048 && g_beam_part) {
+        // (r4) beam search at <= 8 rows: 128-key ranges with up-front loads (attn_decode_part_kernel<.., BEAM>), then the same merge
+        const int ns = (cap_all + 127) / 128;
+        if (scratch && scratch_bytes >= sizeof(float) * (size_t)batch * heads * ns * (hd + 2)) {
+            hipLaunchKernelGGL((attn_decode_part_kernel<10, 6, true>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc),
+                               const_cast<bf16 *>(vc), scratch, attn_mask, state, seq_len, cap, heads, ldq, const_cast<bf16 *>(kg), const_cast<bf16 *>(vg),
+                               anc, beams, cap_g, batch);
+            EILEV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, ns);
+            EILEV_LAUNCH_CHECK();
+            return EILEV_OK;
+        }
+    }
     const int nsplit = (cap_all + DEC_KEYS - 1) / DEC_KEYS;
     if (!scratch || scratch_bytes < attn_decode_scratch_bytes(batch, heads, hd, cap_all)) return EILEV_E_WORKSPACE;
     hipLaunchKernelGGL(attn_decode_split_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, kc, vc, scratch, attn_mask, state,

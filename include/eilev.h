@@ -263,7 +263,8 @@ void eilev_debug_ln_fold_min_rows(int64_t rows);
  *   eilev_debug_fused_patch / eilev_debug_no_fused_patch   select the fused patch-embed + LayerNorm kernel (opt-in since r3)
  *   eilev_debug_decode_rows       0: MFMA weight-streaming kernels at every batch size; 1 (default): row-dot kernels at <= 4 rows; 3: the round-3 row-dot kernels (<= 2 rows) instead of gemv1 / gemvm
  *   eilev_debug_decode_prefetch   the rejected Infinity-Cache touch kernel of DESIGN 3b (off)
- *   eilev_debug_reduce_ln_wave    1: the one-wave-per-row split-K reduce + LayerNorm of round 2 (default: a workgroup per row) */
+ *   eilev_debug_reduce_ln_wave    1: the one-wave-per-row split-K reduce + LayerNorm of round 2 (default: a workgroup per row)
+ *   eilev_debug_beam_part         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.
