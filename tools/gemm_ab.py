@@ -20,15 +20,29 @@ rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 7
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = {"fc1": (6144, 1408, 1, False), "fc1_noact": (6144, 1408, 0, False), "fc2": (1408, 6144, 0, True), "qkv": (4224, 1408, 0, False),
-          "proj": (1408, 1408, 0, True)}
+          "proj": (1408, 1408, 0, True),
+          # what the bench's folded-LayerNorm ViT blocks launch (eilev_linear_lnfold / eilev_linear_stats)
+          "fc1_ln": (6144, 1408, 1, False), "qkv_ln": (4224, 1408, 0, False), "fc2_st": (1408, 6144, 0, True), "proj_st": (1408, 1408, 0, True)}
+only = os.environ.get("AB_SHAPES")
 for name, (n, k, epi, resid) in SHAPES.items():
+    if only and name not in only.split(","):
+        continue
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda").to(torch.bfloat16)
     r = torch.randn(m, n, device="cuda").to(torch.bfloat16) if resid else None
     outs = [torch.empty(m, n, device="cuda", dtype=torch.bfloat16) for _ in libs]
+    if name.endswith("_ln"):
+        cs = torch.randn(n, device="cuda")
+        rows = torch.stack([torch.rand(m, device="cuda") + 0.5, torch.randn(m, device="cuda") * 0.1], 1).contiguous()
+        call = lambda lib, o: lib.eilev_linear_lnfold(P(a), P(w), P(b), P(cs), P(rows), P(o), m, n, k, epi, st())
+    elif name.endswith("_st"):
+        stats = torch.empty(((n + 63) // 64, m, 2), device="cuda")
+        call = lambda lib, o: lib.eilev_linear_stats(P(a), P(w), P(b), P(r), P(o), m, n, k, P(stats), st())
+    else:
+        call = lambda lib, o: lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
     for lib, o in zip(libs, outs):
-        lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+        call(lib, o)
     torch.cuda.synchronize()
     d = (outs[0].float() - outs[1].float()).abs().max().item()
     times = [[] for _ in libs]
@@ -37,7 +51,7 @@ for name, (n, k, epi, resid) in SHAPES.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+                call(lib, o)
             e1.record()
             torch.cuda.synchronize()
             if rd:

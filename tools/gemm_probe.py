@@ -34,7 +34,9 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        "fc1_noact": (34952, 6144, 1408, 0, False), "fc1_relu": (34952, 6144, 1408, 2, False),
        # what the folded-LayerNorm ViT blocks run (eilev_linear_lnfold / eilev_linear_stats): consumer (_ln) and statistics producer (_st)
        "fc1_ln": (34952, 6144, 1408, 1, False), "qkv_ln": (34952, 4224, 1408, 0, False), "proj_st": (34952, 1408, 1408, 0, True),
-       "fc2_st": (34952, 1408, 6144, 0, True)}
+       "fc2_st": (34952, 1408, 6144, 0, True),
+       # round 4 diagnostic: the fc2 K loop without a half tile column (5 / 6 / 8 whole column tiles) — is the 5.5-column drift what costs fc2?
+       "fc2_n1280": (34952, 1280, 6144, 0, True), "fc2_n1536": (34952, 1536, 6144, 0, True), "fc2_n2048": (34952, 2048, 6144, 0, True)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
@@ -75,6 +77,18 @@ for name in names:
         d = (o.float() - ref.float()).abs().max().item()
         if d != 0.0:
             print(f"{name}: flags={flags} MISMATCH vs register-staged kernel: max abs diff {d}")
+    base = None  # every variant against the first one (the LayerNorm-folding shapes have no register-staged reference)
+    for flags in flags_list:
+        raw.eilev_debug_gemm_flags(flags)
+        o.zero_()
+        call(o)
+        torch.cuda.synchronize()
+        if base is None:
+            base = o.float().clone()
+        else:
+            d = (o.float() - base).abs().max().item()
+            print(f"{name}: flags={flags} max abs diff vs flags={flags_list[0]}: {d:.4g} (rms of the output {base.pow(2).mean().sqrt().item():.4g})")
+    del base
     times = {f: [] for f in flags_list}
     for rd in range(rounds + 1):
         for flags in flags_list:
