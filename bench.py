@@ -405,6 +405,50 @@ def strong_scaling_phase(eng, cfg, world, rank, dev, exch_weak, is_t5, global_sa
             "clips_encoded_rank0": plan.n_local, "samples_decoded_rank0": len(mine)}
 
 
+def measure_traffic_pmc(shape: str = "fc1_ln", rows: int = 257 * 1088, kernel: str = "gemm_pp4"):
+    """roofline.traffic measured in THIS run on THIS box: rocprofv3 --pmc around tools/gemm_probe.py launching the roofline kernel at the bench's
+    launch shape (random bf16 operands, 12 launches), one counter per pass with --kernel-trace only (MI355X_MICROARCH.md: separate passes;
+    FETCH_SIZE is doubled on gfx950, both are in KB).  Runs after the timed region, in a subprocess (the profiler attaches at process start).
+    Returns ({"fetch_kb", "write_kb", "launches", "dur_us"}, None) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="eilev_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, PROBE_M=str(rows), TMPDIR="/tmp")
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pm", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "gemm_probe.py"), "0", shape, "1"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            rows_ = sqlite3.connect(dbs[0]).execute(
+                "select dispatch_id, value, duration from counters_collection where counter_name = ? and kernel_name like ?",
+                (counter, f"%{kernel}%")).fetchall()
+            per, dur = {}, {}
+            for did, v, d in rows_:  # summed over the XCDs / channels of a dispatch
+                per[did] = per.get(did, 0.0) + v
+                dur[did] = d
+            if not per:
+                return None, f"no {kernel} dispatch in the {counter} pass"
+            out[counter] = sum(per.values()) / len(per)
+            out["launches"] = len(per)
+            out["dur_us"] = round(sum(dur.values()) / len(dur) / 1e3, 1)
+        except Exception as e:  # noqa: BLE001 — a measurement aid: any failure falls back to the figure in profiles/
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_kb": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"], "launches": out["launches"], "dur_us": out["dur_us"]}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,6 +459,8 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling phase (SURVEY 8(d): 8 samples per GLOBAL step) that "
                     "runs after the headline weak-scaling steps and is reported as `strong_scaling` in the same JSON line")
     ap.add_argument("--strong-samples", type=int, default=8, help="samples per GLOBAL step of the strong-scaling phase")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 --pmc after the timed region (two short "
+                    "profiled launches of the roofline kernel in a subprocess); the figure then comes from profiles/ and is labelled so")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed kernels (outside the timed region)")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 transport of the clip tokens: rccl = eilev_exchange_clip_tokens (direct RCCL send/recv on a side "
@@ -697,10 +743,18 @@ def main():
                     traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
             except OSError:
                 pass
+            live, why = (None, "--no-pmc") if args.no_pmc else (None, "N > 1") if world > 1 else \
+                (None, "not the fc1 roofline kernel / launch shape") if "fc1" not in nm or S * (N_CTX + 1) % 136 else measure_traffic_pmc()
+            src = "profiles/r04_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run: " + str(why) + ")"
+            if live:
+                traffic = int((2 * live["fetch_kb"] + live["write_kb"]) * 1024)
+                src = (f"measured in this run after the timed region: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around "
+                       f"PROBE_M=279616 tools/gemm_probe.py 0 fc1_ln 1 = {live['launches']} launches of this kernel at the bench launch shape "
+                       f"({live['dur_us']} us each under the profiler); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md)")
             res["roofline"] = {"bound": "mfma", "kernel": nm, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "launches": int(n), "avg_launch_ms": round(ms / n, 4), "traffic_measured_in_run": False,
-                               "traffic_source": "profiles/r04_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run)",
+                               "launches": int(n), "avg_launch_ms": round(ms / n, 4), "traffic_measured_in_run": bool(live),
+                               "traffic_source": src, "algorithmic_bytes": int(2 * (257 * 1088 * 1408 + 6144 * 1408 + 257 * 1088 * 6144)) if "fc1" in nm else None,
                                "mfma_busy_frac_pmc": (tr or {}).get("mfma_busy_frac"), "effective_clock_ghz_pmc": (tr or {}).get("eff_clock_ghz"),
                                "vit_gemm_ms_per_step": round(tot_ms / args.steps, 2),
                                "vit_gemm_us_and_tflops": per_kind}

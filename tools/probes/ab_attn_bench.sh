@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 cat > /tmp/run_bench_flag.py <<'PY'
 import ctypes as C, sys, json, io, contextlib, os
 sys.path.insert(0, os.getcwd())
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-strong", "--no-verify"]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-strong", "--no-verify", "--no-pmc"]
 flag = int(os.environ.get("ATTN_FLAG", "0"))
 import torch
 torch.cuda.init(); torch.zeros(1, device="cuda")

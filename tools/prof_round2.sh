@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 # 1) kernel trace + stats of the bench command (no CPU legs: they are not kernels)
-rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify > $O/r02_prof_bench.log 2>&1
+rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-pmc > $O/r02_prof_bench.log 2>&1
 python $R/tools/rocpd_stats.py /tmp/kt/kt_results.db > $O/r02_bench_kernel_stats.md 2>&1
 # 2) PMC counters of the four ViT GEMM shapes at the bench launch shape, one counter group per pass (--kernel-trace only)
 for sh in fc1_ln qkv_ln fc2_st proj_st; do
