@@ -41,6 +41,8 @@ elif name.endswith("_st"):
     run = lambda: lib.eilev_linear_stats(P(a), P(w), P(b), P(r), P(o), m, n, k, P(stats), st())
 else:
     run = lambda: lib.eilev_linear(P(a), P(w), P(b), P(r), P(o), m, n, k, epi, 0, st())
+if os.environ.get("TRACE_FLAGS"):
+    raw.eilev_debug_gemm_flags(int(os.environ["TRACE_FLAGS"]))
 for _ in range(3):
     assert run() == 0
 buf = torch.zeros(WG * 2 * TILES * 8, dtype=torch.int64, device="cuda")
@@ -71,5 +73,11 @@ for grp, gname in ((0, "early waves"), (1, "late waves")):
         for i in idx[:-1]:
             if valid[wg, i + 1]:
                 nxt.append(x[wg, i + 1, 0] - x[wg, i, 0])
+    kl = (sel[:, 2] - sel[:, 1]) * 0.01  # K-loop durations: whole tiles and half (or tall) tiles separate into two modes
+    q = np.percentile(kl, [5, 25, 50, 75, 95])
+    lo = kl[kl < 0.75 * q[2]]
+    hi_ = kl[kl > 1.25 * q[2]]
+    print(f"  {gname}: K loop us  p5 {q[0]:.1f}  p25 {q[1]:.1f}  p50 {q[2]:.1f}  p75 {q[3]:.1f}  p95 {q[4]:.1f} | < 0.75 median: {len(lo)} tiles, mean "
+          f"{lo.mean() if len(lo) else 0:.1f} | > 1.25 median: {len(hi_)} tiles, mean {hi_.mean() if len(hi_) else 0:.1f}")
     print(f"  {gname}: tiles {len(sel)}  top->kloop {us(0, 1):.2f}  kloop {us(1, 2):.2f}  kend->epi {us(2, 3):.2f}  epilogue {us(3, 4):.2f}  "
           f"tile period {np.mean(nxt) * 0.01:.2f} us  shader clock {clk:.0f} MHz")
