@@ -22,7 +22,8 @@ P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = {"fc1": (6144, 1408, 1, False), "fc2": (1408, 6144, 0, True), "qkv": (4224, 1408, 0, False), "proj": (1408, 1408, 0, True),
           "fc1_noact": (6144, 1408, 0, False), "fc1_ln": (6144, 1408, 1, False), "qkv_ln": (4224, 1408, 0, False),
-          "proj_st": (1408, 1408, 0, True), "fc2_st": (1408, 6144, 0, True)}  # _ln: folded-LayerNorm consumer, _st: statistics producer
+          "proj_st": (1408, 1408, 0, True), "fc2_st": (1408, 6144, 0, True),
+          "fc2_n1280": (1280, 6144, 0, True), "fc2_n1536": (1536, 6144, 0, True)}  # fc2 with whole column tiles only (half-tile diagnosis, r4)  # _ln: folded-LayerNorm consumer, _st: statistics producer
 name = sys.argv[1] if len(sys.argv) > 1 else "fc1"
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 139808
 n, k, epi, resid = SHAPES[name]
