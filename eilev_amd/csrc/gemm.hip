@@ -688,7 +688,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         m0 = tm_i * BM;
         n0 = tn_i * BN;
         {
+#ifdef EILEV_PP4_PROBE_A0  /* timing probe only (WRONG results): every tile reads the A rows of tile row 0 — same data statistics, no fabric traffic for A */
+            const uint64_t base = (uint64_t)(g.A);
+#else
             const uint64_t base = (uint64_t)(g.A + (int64_t)m0 * g.lda);
+#endif
             const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);  // provably wave-uniform: no waterfall loop
             ra = __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, 0x7fffffff, 0x00020000);
@@ -708,15 +712,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             }
         }
     };
-    auto stage_step = [&](int st, bool mine = true) {  // mine == false: a late wave whose W rows do not exist in a half tile
+    // part: 0 all 8 pieces, 1 pieces 0..3, 2 pieces 4..7 (EILEV_PP4_SPLIT: a wave's pieces of a K-step are issued in two read phases)
+    auto stage_step = [&](int st, bool mine = true, int part = 0) {  // mine == false: a late wave whose W rows do not exist in a half tile
         char *sd = smem + (st & 1) * STEP + (late ? BM * 128 : 0) + (pw * PC) * 1024;
         if (!mine) return;
+#ifndef EILEV_PP4_PROBE_SKIP
+#define EILEV_PP4_PROBE_SKIP 0  /* timing probe only (WRONG results): 1 / 2 the early / late group issues half of its pieces, 4 / 8 none */
+#endif
+        constexpr int PCE = (EILEV_PP4_PROBE_SKIP & 4) ? 0 : (EILEV_PP4_PROBE_SKIP & 1) ? PC / 2 : PC;
+        constexpr int PCL = (EILEV_PP4_PROBE_SKIP & 8) ? 0 : (EILEV_PP4_PROBE_SKIP & 2) ? PC / 2 : PC;
         if (late) {
 #pragma unroll
-            for (int i = 0; i < PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
+            for (int i = 0; i < PCL; ++i)
+                if (part == 0 || (part == 1) == (i < PC / 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
+            for (int i = 0; i < PCE; ++i)
+                if (part == 0 || (part == 1) == (i < PC / 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
         }
     };
     f32x16 acc[TM][TN];
@@ -938,6 +950,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+// The waits in front of the hand-over barriers are BUILTINS, not inline asm (round 5): hipcc's wait-count pass cannot see into an asm
+// statement, so behind an asm "s_waitcnt lgkmcnt(0)" it still believes the 12 fragment reads are outstanding and puts its own
+// s_waitcnt lgkmcnt(9 / 8 / 7 / 6 / 3 / 2 / 1 / 0) between the 16 MFMAs of the phase — eight instructions that never wait and still take
+// issue slots between back-to-back MFMAs (the trace of tools/gemm_itrace.py: an MFMA phase took 580-650 cycles, 16 x 32 = 512 ideal).
+// simm16 of s_waitcnt on gfx9: vmcnt = [15:14 | 3:0], expcnt = [6:4], lgkmcnt = [11:8].
+#define PP_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0) */
+#define PP_WAIT_LGKM0_VM0() __builtin_amdgcn_s_waitcnt(0x0070)  /* vmcnt(0) lgkmcnt(0) */
+#define PP_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)        /* vmcnt(0) */
 #define PP_BARRIER()                       \
     do {                                   \
         __builtin_amdgcn_sched_barrier(0); \
@@ -1044,26 +1064,43 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             const bool w_mine = !HT || wid < NW / 2 + 2;
             if constexpr (HT) read_half_ht(st, 0); else read_half(st, 0);
 #if EILEV_PP4_DEEP
+            // Round 5: a wave's 8 pieces of a K-step are issued in TWO read phases (whole tiles).  The interval trace (tools/gemm_itrace.py)
+            // shows the read phases that carry a group's 32 pieces as the long ones (the CU's LDS-DMA path takes ~17 cycles per 1-KiB
+            // piece: a 32-piece burst is longer than the other group's 16 MFMAs), the read phases without pieces as the short ones.
+            // Early group: pieces 0..3 of step st + 1 in the read phase of half 0 (as before), pieces 4..7 in the read phase of half 1
+            // (the buffer has been free since the previous barrier; waited for at the end of the second MFMA phase, as before).  Late
+            // group: pieces 0..3 of step st + 2 at the end of its read phase of (st, half 1) (as before), pieces 4..7 one phase pair
+            // later, in its read phase of (st + 1, half 0) — still only rows this wave and its early twin read, both done — waited for
+            // at the end of the read phase of (st + 1, half 1), as before.  Same-box A/B (profiles/r05_dma_split_ab.log): fc2 +2.3 %,
+            // fc2 + statistics +1.9 %, fc1 +0.8...1.4 %, proj +0.9 %, bit-identical; the folded-LayerNorm qkv instance loses 1.1 % and keeps
+            // the unsplit schedule.
+#ifndef EILEV_PP4_SPLIT
+#define EILEV_PP4_SPLIT 3
+#endif
+            constexpr bool SPLIT_OK = !HT && !(LN == 1 && EPI == 0);
+            constexpr bool SPLIT_E = (EILEV_PP4_SPLIT & 1) && SPLIT_OK, SPLIT_L = (EILEV_PP4_SPLIT & 2) && SPLIT_OK;
             if (!late) {
-                if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
+                if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, SPLIT_E ? 1 : 0);
             } else if (FIRST && !pre1 && ns > 1) stage_step(1, w_mine);
+            else if (SPLIT_L && !FIRST && st + 1 < ns) stage_step(st + 1, w_mine, 2);  // its first half: the end of this wave's read phase of (st - 1, half 1)
 #else
             if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine);
 #endif
             if constexpr (FIRST && LN == 1) acc_prep();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_WAIT_LGKM0();
             PP_BARRIER();
             if constexpr (FIRST && LN == 1) acc_init();
             if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();
             if constexpr (HT) read_half_ht(st, 1); else read_half(st, 1);
 #if EILEV_PP4_DEEP
+            PP_WAIT_LGKM0();  // unconditional and in straight-line code: a wait inside the branch below is not credited at the join
             if (late) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                PP_WAIT_VM0();
                 // full tile: the W rows this wave stages are read by itself (done: lgkmcnt(0) above) and by its early twin (done one
                 // barrier ago) only.  Half tile: the reads are re-split 4 x 2, two late waves share W rows -> issue after the barrier.
-                if constexpr (!HT) if (st + 2 < ns) stage_step(st + 2, w_mine);
-            } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (!HT) if (st + 2 < ns) stage_step(st + 2, w_mine, SPLIT_L ? 1 : 0);
+            } else if (SPLIT_E && st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, 2);
             PP_BARRIER();
             if constexpr (HT) {
                 if (late && st + 2 < ns) stage_step(st + 2, w_mine);
@@ -1073,7 +1110,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PP_BARRIER();
 #else
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            PP_WAIT_LGKM0_VM0();
             PP_BARRIER();
             if constexpr (HT) mma_half_ht(); else mma_half();
             PP_BARRIER();

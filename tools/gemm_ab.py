@@ -23,10 +23,16 @@ SHAPES = {"fc1": (6144, 1408, 1, False), "fc1_noact": (6144, 1408, 0, False), "f
           "proj": (1408, 1408, 0, True),
           # what the bench's folded-LayerNorm ViT blocks launch (eilev_linear_lnfold / eilev_linear_stats)
           "fc1_ln": (6144, 1408, 1, False), "qkv_ln": (4224, 1408, 0, False), "fc2_st": (1408, 6144, 0, True), "proj_st": (1408, 1408, 0, True)}
+# the OPT-2.7B prefill linears of a bench step (32 samples x 960 tokens): AB_SHAPES=opt_qkv,... (rows from AB_MOPT, default 30720)
+SHAPES.update({"opt_qkv": (7680, 2560, 0, False), "opt_fc1": (10240, 2560, 2, False), "opt_fc2": (2560, 10240, 0, True), "opt_out": (2560, 2560, 0, True)})
 only = os.environ.get("AB_SHAPES")
 for name, (n, k, epi, resid) in SHAPES.items():
-    if only and name not in only.split(","):
+    if (only and name not in only.split(",")) or (not only and name.startswith("opt_")):
         continue
+    if name.startswith("opt_"):
+        m = int(os.environ.get("AB_MOPT", 30720))
+    elif len(sys.argv) > 3:
+        m = int(sys.argv[3])
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda").to(torch.bfloat16)
