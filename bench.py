@@ -538,18 +538,26 @@ def main():
     plan = ExchangePlan(world * S, N_CTX + 1, world, rank, chunk_clips=max(1, 1088 // FRAMES))
     px, ids, vm, am = build_inputs(cfg, S, dev, seed=1234 + rank)
     assert px.shape[0] == plan.n_local and plan.n_consumed == S * (N_CTX + 1)
-    transport = args.exchange
+    transport = "torch" if args.share_gpu else args.exchange  # --share-gpu: N ranks on one device over gloo — RCCL cannot span them, by definition
     if world > 1 and transport == "rccl":
+        # `--exchange rccl` (the default) means the direct RCCL communicator of csrc/comm.hip or NOTHING: a run that cannot build it must
+        # say why and stop, not quietly time a different transport (VERDICT r4 item 8 — on first contact with N GPUs that fallback would
+        # hide exactly the failure the run exists to find).  `--exchange torch` is the explicit way to time torch.distributed's RCCL.
+        err = None
         try:
             exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport="rccl")
-        except (RuntimeError, OSError) as e:  # no direct communicator: say so in the result and use torch.distributed's RCCL
-            print(f"[rank {rank}] direct RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-            transport = "torch"
-        ok = torch.tensor([1 if transport == "rccl" else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks must agree on the transport
+        except (RuntimeError, OSError) as e:
+            err = f"{type(e).__name__}: {e}"
+            print(f"[rank {rank}] bench.py --exchange rccl: the direct RCCL communicator could not be created: {err}", file=sys.stderr, flush=True)
+        ok = torch.tensor([0 if err else 1], device="cpu" if args.share_gpu else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank learns that some rank failed, so that all of them leave (no hung peer)
         if int(ok.item()) == 0:
-            transport = "torch"
-    if world == 1 or transport != "rccl":
+            if rank == 0:
+                print("bench.py: --exchange rccl failed on at least one rank (messages above); not falling back — rerun with "
+                      "--exchange torch to time torch.distributed's all_to_all_single instead", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
+    else:
         exch = ClipExchange(plan, nq, Dt, torch.bfloat16, dev, transport=transport)
 
     last = {}
@@ -617,6 +625,14 @@ def main():
             return float(t.item())
 
         dt = over_ranks(dt, dist.ReduceOp.MAX)
+        # every rank's own phase times (ms per step): one run locates an imbalance (a slow GPU, an exposed exchange, a rank with more clips)
+        mine_ms = [phases["encode"] / args.steps, phases["prefill"] / args.steps, phases["decode"] / args.steps,
+                   sum(m_[1].elapsed_time(m_[2]) for m_ in (exch.timing or []) if m_[0] == "wait") / args.steps]
+        allp = torch.zeros(world, 4, dtype=torch.float64, device=rdev)
+        allp[rank] = torch.tensor(mine_ms, dtype=torch.float64, device=rdev)
+        dist.all_reduce(allp)
+        per_rank_ms = [{"rank": r, "encode": round(float(allp[r, 0]), 2), "exchange_exposed": round(float(allp[r, 3]), 3),
+                        "prefill": round(float(allp[r, 1]), 2), "decode": round(float(allp[r, 2]), 2)} for r in range(world)]
         if not is_t5 and not args.no_verify:
             # outside the timed region: every rank re-encodes the clips of ITS samples itself (the pixels of a peer are its seed
             # away) and the rows that came through the exchange must be those rows, the ids of its samples the same ids
@@ -693,7 +709,7 @@ def main():
         marks_x = exch.timing or []
         rounds = [m_ for m_ in marks_x if m_[0] == "round"]
         waits = [m_ for m_ in marks_x if m_[0] == "wait"]
-        exchange_info = {"rccl_ranks": world, "transport": exch.transport,
+        exchange_info = {"rccl_ranks": int(getattr(getattr(exch, "comm", None), "world", dist.get_world_size())), "transport": exch.transport,
                          "rounds_per_step": len(rounds) // max(1, args.steps),
                          "sent_MB_per_step": round(sum(m_[3] for m_ in rounds) / args.steps / 1e6, 2),
                          "received_MB_per_step": round(sum(m_[4] for m_ in rounds) / args.steps / 1e6, 2),
@@ -774,6 +790,7 @@ def main():
         if sharded is not None:
             res["sharded_check"] = sharded
         if exchange_info is not None:
+            exchange_info["per_rank_ms_per_step"] = per_rank_ms
             res["exchange"] = exchange_info
         if strong is not None:
             res["strong_scaling"] = strong
@@ -793,8 +810,22 @@ def main():
         if do_cpu:
             res["cpu_baseline"] = cpu_baseline(cfg, host_w)
         print(json.dumps(res), flush=True)
+    bad = None
+    if world > 1 and rank == 0:
+        # the N > 1 line is only valid if the exchange really spanned N ranks on the transport that was asked for and the rows that came
+        # through it are the rows a rank computes itself; otherwise the JSON line above stands as the evidence and the run exits non-zero
+        if exchange_info["rccl_ranks"] != world or exchange_info["transport"] != transport:
+            bad = f"exchange ran on {exchange_info['rccl_ranks']} ranks over '{exchange_info['transport']}', expected {world} over '{transport}'"
+        elif sharded is not None and not sharded["ok"]:
+            bad = "sharded_check failed: " + json.dumps({k: v for k, v in sharded.items() if k != "what"})
+        if bad:
+            print("bench.py: INVALID multi-rank run — " + bad, file=sys.stderr, flush=True)
     if world > 1:
+        flag = torch.tensor([1 if bad else 0], device="cpu" if args.share_gpu else dev)
+        dist.broadcast(flag, 0)
         dist.destroy_process_group()
+        if int(flag.item()):
+            sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -190,7 +190,7 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     and keep their draw order (HF lets only the first K drawn finish); everything else is the same bookkeeping.
 
     ``processors`` (`LogitsProcessorList` / callable): applied to every step's LOG-PROBABILITIES with each beam's own ids, as hf `_beam_search`
-    does (`repetition_penalty`, `no_repeat_ngram_size`, user processors); ``stopping``: the search ends when it flags every row;
+    does (`repetition_penalty`, `no_repeat_ngram_size`, user processors); ``stopping``: a candidate it flags finishes like one that produced EOS (hf step d); the search ends when every candidate is flagged;
     ``prefix`` (batch, P): ids in front of the generated ones (see sampling.sample_loop)."""
     dev = first_logits.device
     B, nb, T = batch, num_beams, max_new_tokens
@@ -202,7 +202,10 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     keep = max(2, 1 + len(eos)) * nb  # hf generation/utils.py:3285-3286 beams_to_keep
     top_mask = torch.arange(keep, device=dev) < nb
 
-    run_seq = torch.full((B, nb, T), pad_id, dtype=torch.int64, device=dev)
+    # hf `_beam_search`: `output_fill_value = pad_token_id or eos_token_id[0] if eos_token_id is not None else -1` — without an EOS id the unused
+    # tail of a hypothesis is -1, whatever the pad id (reachable only through stopping criteria: every hypothesis has full length otherwise)
+    fill = int(pad_id) if eos else -1
+    run_seq = torch.full((B, nb, T), fill, dtype=torch.int64, device=dev)
     fin_seq = run_seq.clone()
     run_len = torch.zeros((B, nb), dtype=torch.int64, device=dev)  # generated length of every finished hypothesis
     fin_len = run_len.clone()
@@ -214,17 +217,14 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
     offs = (torch.arange(B, device=dev) * nb).view(B, 1)
 
     logits = first_logits.float().repeat_interleave(nb, dim=0)  # (B*nb, V): identical rows, like HF's expanded prefill
+    check_every = 4 if (sampler is None and processors is None and stopping is None) else 1
     cur = 0
     while True:
         logp = torch.log_softmax(logits, dim=-1)
-        if processors is not None or stopping is not None:
+        if processors is not None:
             seen = run_seq[:, :, :cur].reshape(B * nb, cur)
             if prefix is not None:
                 seen = torch.cat((prefix.to(dev, torch.int64).repeat_interleave(nb, dim=0), seen), dim=1)
-            if stopping is not None and cur > 0:
-                done_all = stopping(seen, logp)
-                if bool(done_all.all() if torch.is_tensor(done_all) else done_all):
-                    break
             if processors is not None:
                 logp = processors(seen, logp)
         if eos_t is not None and cur < int(min_new_tokens):  # MinNewTokensLengthLogitsProcessor acts on the log-probabilities here
@@ -244,6 +244,17 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
         cand = _take(run_seq, src)
         cand[:, :, cur] = tok
         hit = torch.isin(tok, eos_t) if eos_t is not None else torch.zeros_like(tok, dtype=torch.bool)
+        if stopping is not None:
+            # hf `_beam_search` step d (generation/utils.py:3438-3444): the criteria see every CANDIDATE (prompt ids + the ids generated so
+            # far + the candidate token) and a flagged candidate finishes exactly like one that produced EOS — it enters the finished set with
+            # its length-penalised score and cannot keep running.  (breaking out of the loop instead lost those hypotheses.)
+            cs = cand[:, :, : cur + 1].reshape(B * keep, cur + 1)
+            if prefix is not None:
+                cs = torch.cat((prefix.to(dev, torch.int64).repeat_interleave(keep, dim=0), cs), dim=1)
+            flagged = stopping(cs, None)
+            if not torch.is_tensor(flagged):
+                flagged = torch.full((B * keep,), bool(flagged), dtype=torch.bool, device=dev)
+            hit = hit | flagged.to(dev).view(B, keep)
         if cur + 1 >= T:
             hit = torch.ones_like(hit)
 
@@ -275,11 +286,15 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
         can_improve = can_improve & torch.any(best_running > worst_done, dim=1, keepdim=True)
         if cur >= T:  # the budget: every candidate of this step was forced to finish (hit is all ones) — known on the host, no read-back
             break
+        if stopping is not None and bool(hit.all()):  # hf: `valid_continuations` — every candidate was stopped, nothing can continue
+            break
         # The early exits (nothing can improve any more; early_stopping=True and every beam finished) read device values back: a host
         # synchronisation per step, during which the GPU idles behind the ~20 small selection kernels above.  They are looked at every 4th
         # step only: once an exit condition holds it keeps holding and the finished set is frozen (done_lp is masked by ~can_improve /
-        # all-finished), so up to three extra steps change nothing that is returned.
-        if cur % 4 == 0:
+        # all-finished), so up to three extra steps change nothing that is returned.  With a sampler, logits processors or stopping criteria
+        # the test runs EVERY step: extra iterations would draw from the torch generator and call the user's (possibly stateful)
+        # callbacks more often than hf does.
+        if cur % check_every == 0:
             open_beam = not (bool(torch.all(finished)) and early_stopping is True)
             if not (bool(torch.any(can_improve)) and open_beam):
                 break

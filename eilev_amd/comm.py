@@ -6,7 +6,8 @@ Two transports behind one interface:
   RCCL directly (grouped ncclSend / ncclRecv, ncclAllGather) on a SIDE stream; the communicator is created from a
   ncclUniqueId that rank 0 draws and `torch.distributed` only carries to the other ranks (bootstrap, not data path).
 * ``"torch"`` — `torch.distributed.all_to_all_single` on the default process group: what the world-size-2 gloo tests run on
-  the CPU, and the fallback `bench.py` reports (field `exchange`) if the direct communicator cannot be created.
+  the CPU and what `bench.py --exchange torch` / `--share-gpu` time.  (`bench.py --exchange rccl` exits non-zero when the direct
+  communicator cannot be created: no silent fallback.)
 
 Both follow :class:`eilev_amd.sharding.ExchangePlan`: per encode round every rank sends contiguous blocks of its chunk and
 receives into a staging buffer; `finish()` returns the consumed clips in global clip order.

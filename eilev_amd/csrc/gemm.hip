@@ -997,7 +997,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     ln_fetch(m0, n0);
     int trace_i = 0;
     const bool tracer = g.trace != nullptr && (wid == 0 || wid == NW / 2) && lane == 0;
+    // EILEV_PP4_ITRACE (probe build only, tools/gemm_itrace.py): instead of the per-tile phase stamps, the 8 slots of a (workgroup, wave group,
+    // tile) record hold s_memtime at the 8 phase edges of ONE K-step (st == EILEV_PP4_ITRACE) of that tile: start of the read phase of half
+    // 0 / its reads landed (before the barrier) / barrier released = first MFMA phase starts / its MFMAs issued / barrier released = read
+    // phase of half 1 starts / reads (+ the late group's DMA wait and issue) done / barrier released / second MFMA phase issued.  The stamps
+    // go through the wave's (idle) epilogue staging bytes and are copied out at the tile's end.
+#ifdef EILEV_PP4_ITRACE
+#define ITR(k)                                                                                                              \
+    do {                                                                                                                    \
+        if (st == EILEV_PP4_ITRACE && tracer) *reinterpret_cast<volatile unsigned long long *>(stg + (k) * 8) = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ITR(k) do { } while (0)
+#endif
     auto stamp = [&](int k, bool core = false) {
+#ifdef EILEV_PP4_ITRACE
+        return;
+#endif
         if (tracer && trace_i < g.trace_tiles)
             g.trace[(((size_t)blockIdx.x * 2 + (late ? 1 : 0)) * g.trace_tiles + trace_i) * 8 + k] =
                 core ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
@@ -1062,6 +1078,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             constexpr bool FIRST = decltype(first_c)::value;
             constexpr bool HT = decltype(ht_c)::value;
             const bool w_mine = !HT || wid < NW / 2 + 2;
+            ITR(0);
             if constexpr (HT) read_half_ht(st, 0); else read_half(st, 0);
 #if EILEV_PP4_DEEP
             // Round 5: a wave's 8 pieces of a K-step are issued in TWO read phases (whole tiles).  The interval trace (tools/gemm_itrace.py)
@@ -1088,10 +1105,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #endif
             if constexpr (FIRST && LN == 1) acc_prep();
             PP_WAIT_LGKM0();
+            ITR(1);
             PP_BARRIER();
+            ITR(2);
             if constexpr (FIRST && LN == 1) acc_init();
             if constexpr (HT) mma_half_ht(); else mma_half();
+            ITR(3);
             PP_BARRIER();
+            ITR(4);
             if constexpr (HT) read_half_ht(st, 1); else read_half(st, 1);
 #if EILEV_PP4_DEEP
             PP_WAIT_LGKM0();  // unconditional and in straight-line code: a wait inside the branch below is not credited at the join
@@ -1101,13 +1122,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 // barrier ago) only.  Half tile: the reads are re-split 4 x 2, two late waves share W rows -> issue after the barrier.
                 if constexpr (!HT) if (st + 2 < ns) stage_step(st + 2, w_mine, SPLIT_L ? 1 : 0);
             } else if (SPLIT_E && st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, 2);
+            ITR(5);
             PP_BARRIER();
+            ITR(6);
             if constexpr (HT) {
                 if (late && st + 2 < ns) stage_step(st + 2, w_mine);
                 mma_half_ht();
             } else mma_half();
             __builtin_amdgcn_sched_barrier(0);
             if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ITR(7);
             PP_BARRIER();
 #else
             PP_WAIT_LGKM0_VM0();
@@ -1124,6 +1148,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::false_type{});
         }
         stamp(2);
+#ifdef EILEV_PP4_ITRACE
+        if (tracer && trace_i < g.trace_tiles) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                g.trace[(((size_t)blockIdx.x * 2 + (late ? 1 : 0)) * g.trace_tiles + trace_i) * 8 + k] = *reinterpret_cast<volatile unsigned long long *>(stg + k * 8);
+        }
+#endif  // (before the epilogue reuses the staging bytes)
         if (!late) PP_BARRIER();
         if constexpr (LN == 1) {  // rstd of the lane's rows for the epilogue: issued BEFORE the next tile's DMA (retire in order)
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);

@@ -866,7 +866,11 @@ __global__ __launch_bounds__(256) void beam_advance_kernel(const BeamAdvanceArgs
     __shared__ uint8_t nfd[32];
     __shared__ int32_t acol[32 * 64];  // gen_cap <= 64 ancestor rows of the sample's columns (larger tables: scratch-free second pass below)
     const int b = blockIdx.x, tid = threadIdx.x, K = a.beams, keep = a.keep, T = a.T, C = K * keep, R = a.batch * K;
+    // state[0] counts the generated tokens including this step's: 1 .. T (include/eilev.h).  It is a device value the host entry cannot
+    // check, so a caller that forgot `state[0] = 1` or advanced past max_new gets NO update instead of out-of-range reads of len_pow,
+    // the candidate column and the ancestor row (attn_decode_split_kernel guards the same counter the same way).
     const int cur = a.state[0] - 1;
+    if (cur < 0 || cur >= T) return;
     for (int c = tid; c < C; c += 256) cv[c] = cv0[c] = a.row_lp[(int64_t)(b * K + c / keep) * keep + c % keep];
     __syncthreads();
     beam_topk_lds(cv, C, keep, order, red_v, red_i);

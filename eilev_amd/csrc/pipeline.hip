@@ -655,7 +655,7 @@ bool opt_rows1_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M, i
     return gemv1_ok(3 * D, D, 1) && gemv1_ok(D, D, 0) && gemv1_ok(d->t_ffn, D, 1) && gemv1_ok(D, d->t_ffn, 0) && gemv1_ok(d->vocab, D, 1) &&
            attn_decode1_ok(1, (int)cap, D / d->t_heads);
 }
-// 2..8 rows (beam search, a few samples per GPU): gemvm_kernel for every K = t_hidden linear, the one-pass attention where it applies
+// 2..4 rows (beam search, a few samples per GPU): gemvm_kernel for every K = t_hidden linear, the one-pass attention where it applies
 bool opt_rowsm_usable(const EilevDims *d, const EilevOptWeights *w, int64_t M) {
     // measured (OPT-2.7B, L = 960, ms per token): 2 rows 2.06 (row-dot kernels of round 3: 2.67), 4 rows 2.51, 5 rows 3.20 against 2.87 for the MFMA
     // weight-streaming kernels, whose cost is flat up to 16 rows: every extra row costs this kernel a pass of LDS reads + dot products
@@ -914,7 +914,7 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
                         D, 0, 1.0f, 0, s));
         return launch_select(logits, 1, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
     }
-    if (opt_rowsm_usable(d, w, batch)) {  // 2..8 rows (round 4)
+    if (opt_rowsm_usable(d, w, batch)) {  // 2..4 rows (round 4)
         const bool one_pass = attn_decode1_ok((int)batch, (int)kv_capacity, hd);
         for (int l = 0; l < d->t_layers; ++l) {
             bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
@@ -995,7 +995,7 @@ extern "C" int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeig
     RC(launch_decode_embed((const bf16 *)w->embed_tokens, (const bf16 *)w->embed_positions, tokens, n_valid, state, d->vocab, d->max_pos + 1, b.h,
                            (int)rows, D, s));
     const size_t per_p = (size_t)2 * samples * H * seq_len * hd, per_g = (size_t)2 * rows * H * gen_capacity * hd;
-    if (opt_rowsm_usable(d, w, rows)) {  // 2..8 rows (the sample script: 5 beams of one sample), round 4: gemvm_kernel around the beam attention
+    if (opt_rowsm_usable(d, w, rows)) {  // 2..4 rows (e.g. 4 beams of one sample; 5 beams take the MFMA row kernels), round 4: gemvm_kernel around the beam attention
         for (int l = 0; l < d->t_layers; ++l) {
             const bf16 *kc = (const bf16 *)kv_prompt + l * per_p, *vc = kc + per_p / 2;
             bf16 *kg = (bf16 *)kv_gen + l * per_g, *vg = kg + per_g / 2;
@@ -1207,7 +1207,7 @@ extern "C" int eilev_linear_rows(const void *x, const void *ln_gamma, const void
                                  const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream) {
     if (!x || !w || !c || m <= 0 || n <= 0 || k <= 0 || n > 0x7fffffff || k > 0x7fffffff || (ln_gamma != nullptr) != (ln_beta != nullptr)) return EILEV_E_BADARG;
     if (m > 8 || !gemv_rows_ok((int)m, (int)n, (int)k) || (epilogue != 0 && epilogue != 2)) return EILEV_E_UNSUPPORTED;
-    if (m == 1 && g_decode_rows != 3 && gemv1_ok((int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3))  // round 4: one row
+    if (m == 1 && g_decode_rows != 3 && gemv1_ok((int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3) && !(n & 1))  // round 4: one row (bias / residual are fetched as 32-bit pairs: even n only)
         return launch_gemv1(ln_gamma ? 1 : 0, (const bf16 *)x, (const bf16 *)ln_gamma, (const bf16 *)ln_beta, eps, (const bf16 *)w, (const bf16 *)bias,
                             (const bf16 *)residual, c, out_f32, (int)n, (int)k, epilogue, 1.0f, 0, (hipStream_t)stream);
     if (m >= 2 && g_decode_rows != 3 && gemvm_ok((int)m, (int)n, (int)k, ln_gamma ? 1 : 0) && !(((uintptr_t)bias | (uintptr_t)residual) & 3) && !(n & 1))

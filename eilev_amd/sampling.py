@@ -77,7 +77,8 @@ def sample_loop(step, first_logits: torch.Tensor, max_new_tokens: int, eos_id=-1
         else:
             probs = warp_logits(logits, temperature, top_k, top_p).softmax(dim=-1)
             nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
-        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, int(pad_id)))
+        if eos_t is not None:  # hf `_sample` pads finished rows only when an EOS criterion exists (`has_eos_stopping_criteria`); rows finished
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, int(pad_id)))  # by a custom criterion alone keep their real tokens
         out.append(nxt)
         prev = torch.cat((prev, nxt.view(R, 1)), dim=1)
         if eos_t is not None:

@@ -430,7 +430,8 @@ int eilev_topk_logprob(const float *logits, const float *row_score, int64_t rows
  * (x / scalar is x * (1 / scalar) in torch's GPU kernel, a true division on the CPU: eilev_amd/beam.py keeps either bit for bit).
  * early_stopping: 0 False / "never" with length_penalty <= 0, 1 True, 2 "never" with length_penalty > 0.  eos_ids: host array (n_eos <= 8).
  * Sequences (batch, beams, max_new) int64, scores f32, fin_len int64, finished / can_improve uint8, all updated in place.  Equal scores: the
- * lower candidate index wins.  HIP: beams <= 32, keep <= 64, beams * keep <= 2048, gen_cap * beams <= 2048. */
+ * lower candidate index wins.  HIP: beams <= 32, keep <= 64, beams * keep <= 2048, gen_cap * beams <= 2048.
+ * Precondition 1 <= state[0] <= max_new (a device value the entry cannot validate): outside it the call changes nothing. */
 size_t eilev_beam_scratch_bytes(int64_t batch, int64_t beams, int64_t keep, int64_t max_new);
 int eilev_beam_advance(const float *row_lp, const int32_t *row_tok, int64_t batch, int64_t beams, int64_t keep, int64_t max_new,
                        const int32_t *state, const int64_t *eos_ids, int64_t n_eos, const float *len_pow, int len_pow_reciprocal,

@@ -148,3 +148,58 @@ def test_greedy_with_stopping_criteria_equals_transformers(tiny_opt):
     hf = _hf(tiny_opt, prompt, max_new_tokens=12, do_sample=False, num_beams=1, eos_token_id=None, stopping_criteria=StoppingCriteriaList([_StopOnLength(5 + 4)]))
     assert ours.shape[1] == 4
     _eq(ours, hf)
+
+
+# ---- round 5: stopping criteria inside BEAM search: a flagged candidate finishes like an EOS one (hf `_beam_search` step d) ----
+class _StopOnToken:
+    """a user StoppingCriteria: a row is done once its last id is in `ids` (per-row, unlike _StopOnLength)"""
+
+    def __init__(self, ids):
+        self.ids = torch.tensor(ids)
+
+    def __call__(self, input_ids, scores, **kw):
+        return torch.isin(input_ids[:, -1], self.ids.to(input_ids.device))
+
+
+@pytest.mark.parametrize("nb,lp,crit_kind", [(3, 1.0, "len"), (4, -1.0, "len"), (3, 1.0, "tok"), (5, -1.0, "tok")])
+def test_beam_with_stopping_criteria_equals_transformers(tiny_opt, nb, lp, crit_kind):
+    from transformers import StoppingCriteriaList
+
+    torch.manual_seed(6)
+    prompt = torch.randint(4, 40, (2, 6))
+    mk = (lambda: _StopOnLength(6 + 4)) if crit_kind == "len" else (lambda: _StopOnToken([7, 12, 25, 30, 31]))
+    step, first = _stepper(tiny_opt, prompt, 2 * nb)
+    ours = beam_search(step, first, 2, nb, 9, lp, -1, 1, False, 1, stopping=StoppingCriteriaList([mk()]), prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=9, do_sample=False, num_beams=nb, length_penalty=lp, eos_token_id=None, early_stopping=False,
+             stopping_criteria=StoppingCriteriaList([mk()]))
+    if crit_kind == "len":
+        assert ours.shape[1] == 4
+    _eq(ours, hf, pad=-1)  # hf fills the unused tail of a hypothesis with -1 when there is no EOS id; so does beam_search
+
+
+def test_beam_with_max_time_returns_finished_hypotheses(tiny_opt):
+    """generate(num_beams > 1, max_time=...): hf's MaxTimeCriteria flags every candidate once the budget is spent; the candidates of that
+    step must come back as hypotheses (not an empty / stale finished set)."""
+    from transformers import MaxTimeCriteria, StoppingCriteriaList
+
+    torch.manual_seed(7)
+    prompt = torch.randint(4, 40, (2, 6))
+    step, first = _stepper(tiny_opt, prompt, 6)
+    ours = beam_search(step, first, 2, 3, 9, 1.0, -1, 1, False, 1, stopping=StoppingCriteriaList([MaxTimeCriteria(max_time=0.0)]), prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=9, do_sample=False, num_beams=3, eos_token_id=None, early_stopping=False, max_time=0.0)
+    assert ours.shape[1] == 1
+    _eq(ours, hf, pad=-1)
+
+
+def test_greedy_custom_criterion_without_eos_keeps_real_tokens(tiny_opt):
+    """hf `_sample` pads finished rows only when an EOS criterion exists: with eos_token_id=None and a per-row criterion the rows that
+    stopped early keep receiving real tokens until every row is done."""
+    from transformers import StoppingCriteriaList
+
+    torch.manual_seed(8)
+    prompt = torch.randint(4, 40, (3, 5))
+    ids = [7, 12, 25, 30, 31, 9, 14]
+    step, first = _stepper(tiny_opt, prompt, 3)
+    ours = sample_loop(step, first, 12, eos_id=-1, pad_id=1, greedy=True, stopping=StoppingCriteriaList([_StopOnToken(ids)]), prefix=prompt)
+    hf = _hf(tiny_opt, prompt, max_new_tokens=12, do_sample=False, num_beams=1, eos_token_id=None, stopping_criteria=StoppingCriteriaList([_StopOnToken(ids)]))
+    _eq(ours, hf)
