@@ -604,11 +604,12 @@ def main():
     phases = {"encode": 0.0, "prefill": 0.0, "decode": 0.0}
     marks = eng.timing
     eng.timing = None
-    per = 3 if is_t5 else 4
+    per = 5 if is_t5 else 4
+    t5_enc_ms = 0.0
     for i in range(0, len(marks), per):
-        if is_t5:
-            (_, b0), (_, e1), (_, s1) = marks[i:i + 3]
-            p1 = e1  # no separate prefill stamp: encoder + cross K/V + decode are reported together as "decode"
+        if is_t5:  # T5: "prefill" = text encoder (24 blocks over L = 960) + cross K/V of the 24 decoder blocks
+            (_, b0), (_, e1), (_, te), (_, p1), (_, s1) = marks[i:i + 5]
+            t5_enc_ms += e1.elapsed_time(te)
         else:
             (_, b0), (_, e1), (_, p1), (_, s1) = marks[i:i + 4]
         phases["encode"] += b0.elapsed_time(e1)
@@ -745,7 +746,8 @@ def main():
             "phases_rank0": {"encode_ms_per_step": round(phases["encode"] / args.steps, 2),
                              "encode_only_clips_per_s": round(S * (N_CTX + 1) * args.steps / (phases["encode"] * 1e-3), 1),
                              "prefill_ms_per_step": round(phases["prefill"] / args.steps, 2),
-                             "decode_ms_per_token": round(phases["decode"] / args.steps / (NEW_TOKENS - 1), 3),
+                             # (OPT: the first token comes out of the prefill, 31 decode steps follow; T5: all 32 tokens are decoder steps)
+                             "decode_ms_per_token": round(phases["decode"] / args.steps / (NEW_TOKENS if is_t5 else NEW_TOKENS - 1), 3),
                              "samples_per_s": round(world * S * args.steps / dt, 3)},
         }
         if best is not None:
@@ -787,6 +789,44 @@ def main():
             ach = (w_bytes + kv_bytes) / (ms_tok * 1e-3) / 1e12
             res["decode"] = {"bound": "hbm", "rows": S, "ms_per_token": round(ms_tok, 3), "weight_bytes_per_token": int(w_bytes),
                              "kv_bytes_per_token": int(kv_bytes), "achieved": round(ach, 3), "peak": 8.0, "unit": "TB/s", "frac": round(ach / 8.0, 4)}
+        # the language-model phase of THIS run against its rooflines (configs[3] / configs[4] need their own blocks):
+        # prefill-like work (OPT prefill; T5 text encoder + cross K/V) = dense contractions -> MFMA peak of the operand type;
+        # decode = weight + K/V streaming -> HBM
+        t = cfg.text_config
+        if is_t5:
+            D_, I_, F_, Le, Ld = t.d_model, t.num_heads * t.d_kv, t.d_ff, t.num_layers, t.num_decoder_layers
+            enc_tf = Le * (2 * seq_len * D_ * 3 * I_ + 2 * seq_len * I_ * D_ + 3 * 2 * seq_len * D_ * F_ + 4 * seq_len * seq_len * I_) / 1e12
+            ckv_tf = Ld * 2 * 2 * seq_len * D_ * I_ / 1e12
+            enc_ms, pre_ms = t5_enc_ms / args.steps, phases["prefill"] / args.steps
+            ms_tok = phases["decode"] / args.steps / NEW_TOKENS
+            w_bytes = 2 * (Ld * (6 * D_ * I_ + 3 * D_ * F_) + t.vocab_size * D_)
+            kv_bytes = 2 * 2 * Ld * I_ * S * (seq_len + NEW_TOKENS / 2.0)  # cross K/V of the 960 encoder positions + the self-attention cache so far
+            res["lm_phase"] = {
+                "text_encoder": {"bound": "mfma", "tflop_per_sample": round(enc_tf, 3), "ms_per_step": round(enc_ms, 2),
+                                 "achieved": round(enc_tf * S / (enc_ms * 1e-3), 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(enc_tf * S / (enc_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4)},
+                "cross_kv": {"tflop_per_sample": round(ckv_tf, 3), "ms_per_step": round(pre_ms - enc_ms, 2)},
+                "decode": {"bound": "hbm", "rows": S, "ms_per_token": round(ms_tok, 3), "weight_bytes_per_token": int(w_bytes), "kv_bytes_per_token": int(kv_bytes),
+                           "achieved": round((w_bytes + kv_bytes) / (ms_tok * 1e-3) / 1e12, 3), "peak": 8.0, "unit": "TB/s",
+                           "frac": round((w_bytes + kv_bytes) / (ms_tok * 1e-3) / 1e12 / 8.0, 4),
+                           "floor_ms_per_token_at_6.3TBs": round((w_bytes + kv_bytes) / 6.3e12 * 1e3, 3)}}
+        else:
+            Dt_, Ft_, Ll_ = t.hidden_size, t.ffn_dim, t.num_hidden_layers
+            pre_tf = (Ll_ * (2 * seq_len * Dt_ * (4 * Dt_ + 2 * Ft_) + 2 * seq_len * seq_len * Dt_) + 2 * Dt_ * t.vocab_size) / 1e12  # causal attention halved; lm_head on the last row
+            pre_ms = phases["prefill"] / args.steps
+            peak = 5000.0 if args.lm_weights == "fp8_mfma" else MFMA_BF16_PEAK_TFLOPS
+            res["lm_phase"] = {"prefill": {"bound": "mfma", "operands": "fp8 e4m3 x e4m3 (fp32 accumulate)" if args.lm_weights == "fp8_mfma" else "bf16",
+                                           "tflop_per_sample": round(pre_tf, 3), "ms_per_step": round(pre_ms, 2),
+                                           "achieved": round(pre_tf * S / (pre_ms * 1e-3), 1), "peak": peak, "unit": "TFLOP/s",
+                                           "frac": round(pre_tf * S / (pre_ms * 1e-3) / peak, 4)}}
+            if args.lm_weights != "bf16":  # (the bf16 decode block is `decode` above)
+                wb = 1 if args.lm_weights in ("fp8", "fp8_mfma") else 2
+                w_bytes = wb * Ll_ * (4 * Dt_ * Dt_ + 2 * Dt_ * Ft_) + 2 * t.vocab_size * Dt_
+                kv_bytes = 2 * 2 * Ll_ * Dt_ * S * (seq_len + NEW_TOKENS / 2.0)
+                ms_tok = phases["decode"] / args.steps / (NEW_TOKENS - 1)
+                res["lm_phase"]["decode"] = {"bound": "hbm", "rows": S, "ms_per_token": round(ms_tok, 3), "weight_bytes_per_token": int(w_bytes),
+                                             "kv_bytes_per_token": int(kv_bytes), "achieved": round((w_bytes + kv_bytes) / (ms_tok * 1e-3) / 1e12, 3),
+                                             "peak": 8.0, "unit": "TB/s", "frac": round((w_bytes + kv_bytes) / (ms_tok * 1e-3) / 1e12 / 8.0, 4)}
         if sharded is not None:
             res["sharded_check"] = sharded
         if exchange_info is not None:

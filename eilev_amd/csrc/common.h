@@ -18,6 +18,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
         if (_e != hipSuccess) return (int)_e;          \
     } while (0)
 
+// CUs of the current device (cached; 256 when the query fails).  hipDeviceGetAttribute, not hipGetDeviceProperties: the property STRUCT
+// differs between the HIP runtime this library was built against and the one the process mapped first (PyTorch ships its own copy), and
+// a failed query must not leave its error behind for the next launch check's hipGetLastError().
+static inline int eilev_num_cu() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) n = cu;
+        else {
+            (void)hipGetLastError();
+            n = 256;
+        }
+    }
+    return n;
+}
+
 #define EILEV_LAUNCH_CHECK()                           \
     do {                                               \
         hipError_t _e = hipGetLastError();             \

@@ -2025,16 +2025,7 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
     }
 }
 
-static int skinny_n_cu() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-        else n = 256;
-    }
-    return n;
-}
+static int skinny_n_cu() { return eilev_num_cu(); }
 
 // K split of gemm_rows32_kernel: the 8-wave K slice must be 5 or 10 k-steps of 32; more splits when the matrix has fewer blocks than CUs
 static bool rows32_plan(const GemmArgs &g, int nb, int n_cu, SkinnyArgs &a, int &ks, int &ksteps) {
@@ -2476,8 +2467,15 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     // one-wave-per-SIMD continuous-stream kernel (256 x 128 tiles): its smaller tiles balance better when there are fewer than
     // 4 rounds of 256 x 256 tiles (M = 7680 prefill GEMMs: +28 %); with more tiles the ping-pong kernel with the lean epilogue wins
     // (qkv +5 %, OPT out_proj +3 %)
+    // Round 5 (profiles/r05_w6_vs_pp4_rows.log: rows swept 3840 .. 30 720 at N = 2048 / 2560 / 6144 / 7680 / 10 240): which of the two wins is
+    // the wave quantisation of its tile count over the CUs — 256 x 256 tiles fill ceil(t / CUs) rounds, the 256 x 128 tiles of w6 twice as
+    // many half-sized ones — times the ping-pong kernel's ~6 % higher rate at equal fill (e.g. flan-t5-xl wo / o at 30 720 rows: 960 tiles =
+    // 3.75 rounds, ping-pong 1144 / 995 TFLOP/s against 1071 / 864; OPT qkv at 15 360 rows: 1800 tiles = 7.03 rounds, w6 1166 against 1101).
+    // The old rule (w6 below 1024 tiles) stays for N that is not a whole number of 256-column tiles.
     const int64_t tiles256 = tm256 * ceil_div64(g.N, 256);
-    const bool w6_pick = cfg == 1 && tiles256 < 1024;
+    const int n_cu_q = skinny_n_cu() / 8 * 8;
+    auto fill = [&](int64_t t) { return (double)t / (double)(ceil_div64(t, n_cu_q) * n_cu_q); };
+    const bool w6_pick = cfg == 1 && (g.N % 256 == 0 ? 1.06 * fill(tiles256) < fill(tm256 * ceil_div64(g.N, 128)) : tiles256 < 1024);
     if ((force == 12 || (force == 0 && w6_pick && !(g.dbg & (2097152 | 4)))) && w6_ok)
         rc = launch_w6(g, s);
     else if (cfg == 1 && !(wide_tiles && (g.dbg & 1048576)) && (force == 0 || force == 9) && !(g.dbg & 4) && g.K % BK == 0 && (int64_t)g.N * g.ldw * 2 < 0x7fff0000ll)

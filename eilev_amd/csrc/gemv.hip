@@ -686,14 +686,7 @@ int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, fl
         if (!part || heads * hd != K || (hd & 7) || (K >> 9) != 5 || K % 512 || !W || !out || ((uintptr_t)W & 15) || ((uintptr_t)part & 7)) return EILEV_E_UNSUPPORTED;
     } else if (!gemv1_ok(N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
     if ((bias && ((uintptr_t)bias & 3)) || (resid && ((uintptr_t)resid & 3)) || (pro == PRO_LN && (!gamma || !beta))) return EILEV_E_BADARG;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        EILEV_HIP_CHECK(hipGetDevice(&dev));
-        EILEV_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = eilev_num_cu();
     GemvArgs a = {};
     a.x = x; a.ldx = K; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.out = out; a.ldo = N;
     a.out_f32 = out_f32; a.M = 1; a.N = N; a.K = K; a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;
@@ -723,14 +716,7 @@ int launch_gemvm(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const b
                  int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N, int K, int epi, float scale, int scale_cols, hipStream_t s) {
     if (!gemvm_ok(M, N, K, pro) || !x || !W || !out || ((uintptr_t)x & 15) || (ldx & 7) || ((uintptr_t)W & 15)) return EILEV_E_UNSUPPORTED;
     if ((bias && ((uintptr_t)bias & 3)) || (resid && (((uintptr_t)resid & 3) || (ldr & 1))) || (pro == PRO_LN && (!gamma || !beta))) return EILEV_E_BADARG;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        EILEV_HIP_CHECK(hipGetDevice(&dev));
-        EILEV_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = eilev_num_cu();
     GemvArgs a = {};
     a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
     a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K; a.epi = epi; a.scale = scale; a.scale_cols = scale_cols;

@@ -888,8 +888,17 @@ class HipEngine:
         (B, 1 + n) INCLUDING the start token, like HF does for encoder-decoder models.  One decoder step + token selection
         (position and bookkeeping read from a device `state` word) is captured into a hipGraph and replayed."""
         d = self.t5dims
+
+        def stamp(name):  # optional phase stamps for bench.py (events on the launch stream, no sync)
+            if self.timing is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.timing.append((name, ev))
+
         enc = self.t5_encode(inputs_embeds, attention_mask)
+        stamp("t5_encoder_done")
         ckv = self.t5_cross_kv(enc)
+        stamp("prefill_done")  # encoder + cross K/V = what the prefill is for the decoder-only model
         B, L, _ = enc.shape
         if max_new_tokens <= 0:
             return torch.full((B, 1), int(start_id), dtype=torch.int64, device=self.device)

@@ -36,6 +36,9 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        "fc1_ln": (34952, 6144, 1408, 1, False), "qkv_ln": (34952, 4224, 1408, 0, False), "proj_st": (34952, 1408, 1408, 0, True),
        "fc2_st": (34952, 1408, 6144, 0, True),
        # round 4 diagnostic: the fc2 K loop without a half tile column (5 / 6 / 8 whole column tiles) — is the 5.5-column drift what costs fc2?
+       # round 5: the flan-t5-xl encoder linears of a bench step (32 samples x 960 tokens; no biases: PROBE_NOBIAS=1)
+       "t5_qkv": (30720, 6144, 2048, 0, False), "t5_o": (30720, 2048, 2048, 0, True), "t5_wi": (30720, 10240, 2048, 0, False),
+       "t5_wo": (30720, 2048, 5120, 0, True),
        "fc2_n1280": (34952, 1280, 6144, 0, True), "fc2_n1536": (34952, 1536, 6144, 0, True), "fc2_n2048": (34952, 2048, 6144, 0, True)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
@@ -46,6 +49,8 @@ for name in names:
         m = int(os.environ["PROBE_M"])
     if os.environ.get("PROBE_MOPT") and m == 7680:
         m = int(os.environ["PROBE_MOPT"])
+    if os.environ.get("PROBE_MT5") and name.startswith("t5_"):
+        m = int(os.environ["PROBE_MT5"])
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda").to(torch.bfloat16)
