@@ -203,14 +203,29 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
-template <int NWQ>
+// Round 5: DB = 2 is the hd = 64 form (flan-t5: 32 heads x 64; no padded d block).  Its rows are 128 bytes — a power-of-two stride, so the
+// 16-byte chunks of a row are XOR-swizzled (chunk c of key row r sits at chunk c ^ ((r >> 1) & 7), the GEMM kernels' swz()): the LDS-DMA
+// applies it on the SOURCE side (lane p of a piece fetches the global chunk that belongs at LDS chunk p), the K fragment reads and the
+// transposing V reads on their addresses.  REL: T5's relative position bias, bias(h, key - query) — the head's table (2 L - 1 floats for
+// the encoder, <= 4096) is copied to LDS once per workgroup with 64 zeros of slack on both sides (rows / keys past the ends index there),
+// added to the raw scores before masking.  (The v1 kernel this replaces for the T5 encoder ran at ~120 TFLOP/s: 41 % of the encoder's time.)
+constexpr int ATTN_V2_REL_MAX = 4096, ATTN_V2_REL_SLACK = 64;
+// bytes of the K / V stages + key-mask words, or of the O staging that overlays them at the end, whichever is larger (16-byte multiple):
+// the relative-position table sits behind both
+__host__ __device__ inline int attn_v2_rel_offset(int nwq, int hd) {
+    int b = 4 * 64 * hd * 2 + 256 + (2 * 64 + 2) * (int)sizeof(int);
+    if (b < nwq * 32 * 200) b = nwq * 32 * 200;
+    return (b + 15) & ~15;
+}
+template <int NWQ, int DB = 3, bool REL = false>
 __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArgs a) {
-    constexpr int DB = 3;              // 32-wide d blocks (DP = 96)
-    constexpr int KD = 6;              // k = 16 MFMA steps over DP
+    constexpr int KD = 2 * DB;         // k = 16 MFMA steps over DP = 32 DB (96: hd 72 / 80 / 88; 64: hd 64)
+    constexpr bool SWZ = DB == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int RS = a.hd * 2, CH = a.hd >> 3;  // LDS row stride (bytes), 16-byte chunks per row
     const int T = 64 * RS;                     // bytes per K (or V) tile
     int *msk = reinterpret_cast<int *>(smem + 4 * T + 256);
+    float *rel_lds = reinterpret_cast<float *>(smem + attn_v2_rel_offset(NWQ, a.hd));  // behind everything else (incl. the O staging)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,7 +253,8 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
         for (int i = wid; i < 2 * CH; i += NWQ) {  // pieces [0, CH) = K, [CH, 2CH) = V
             const bool isv = i >= CH;
             const int pi = isv ? i - CH : i;
-            const int pch = pi * 64 + lane, key = pch / CH, c = pch - key * CH;
+            const int pch = pi * 64 + lane, key = pch / CH, cl = pch - key * CH;
+            const int c = SWZ ? (cl ^ ((key >> 1) & 7)) : cl;  // the global chunk that lives at LDS chunk cl of this row
             int gk = kv0 + key;
             gk = gk < a.skv ? gk : a.skv - 1;
             const bf16 *src = isv ? vp + (int64_t)gk * a.ldv + c * 8 : kp + (int64_t)gk * a.ldk + c * 8;
@@ -269,11 +285,26 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
         for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
 
     if (ntiles > 0) stage_in(0, 0);
+    if constexpr (REL) {
+        const float *rt = a.rel_tab + (int64_t)h * a.rel_hs;
+        for (int i = tid; i < a.rel_n + 2 * ATTN_V2_REL_SLACK; i += 64 * NWQ) {
+            const int j = i - ATTN_V2_REL_SLACK;
+            rel_lds[i] = (j >= 0 && j < a.rel_n) ? rt[j] : 0.0f;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const bool active = q0 < a.sq;
     const int g16 = lane >> 4, i16 = lane & 15;
+    const float inv_scale = 1.0f / a.scale;
+    // SWZ: per-lane chunk offsets of the K fragment reads (row & 7 pattern of the lane's key row is the same in every 32-key block)
+    int kswz[SWZ ? KD : 1];
+    if constexpr (SWZ) {
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) kswz[kd] = ((kd * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    }
+    const int khi = hi * 16;
     // one KV tile = NB (1 or 2) blocks of 32 keys, processed together: independent MFMA chains, one softmax
     // update and one rescale of O per tile
     auto tile_body = [&](auto nb_tag, auto masked_tag, int cur, int kv0) {
@@ -286,16 +317,23 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.0f;
         const int toff = kv0 & 63;  // 0, or 32 when the second half of a tile is processed on its own
-        const char *krow = kt_ + (toff + l31) * RS + hi * 16;
+        const char *krow = kt_ + (toff + l31) * RS;
 #pragma unroll
         for (int kd = 0; kd < KD; ++kd) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + kb * 32 * RS + kd * 32);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + kb * 32 * RS + (SWZ ? kswz[SWZ ? kd : 0] : kd * 32 + khi));
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], st[kb], 0, 0, 0);
             }
         }
         // st[kb][r] = S[q = l31][key = kv0 + 32 kb + (r&3) + 8*(r>>2) + 4*hi]   (raw q.k, scale folded below)
+        if constexpr (REL) {  // + bias(h, key - query) / scale (the scale is folded into the exponent below; T5: scale = 1)
+            const float *rl = rel_lds + ATTN_V2_REL_SLACK + (kv0 - qrow - off + a.rel_off + 4 * hi);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = fmaf(rl[kb * 32 + (r & 3) + 8 * (r >> 2)], inv_scale, st[kb][r]);
+        }
         if (MASKED) {
             const int *mk = msk + cur * 64;
 #pragma unroll
@@ -338,7 +376,11 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
         rs += __shfl_xor(rs, 32, 64);
         l_run += rs;
         // O^T += V^T P^T.  k-slot (hi, j) of step s of block kb <-> key kv0 + 32 kb + 16 s + (j < 4 ? 4 hi + j : 8 + 4 hi + j - 4)
-        const char *vbase = vt_ + (toff + 4 * (g16 >> 1) + (i16 >> 2)) * RS + (16 * (g16 & 1) + (i16 & 3) * 4) * 2;
+        // SWZ: the lane's 8 bytes are half of global chunk gb + 4 db of row R = toff + 4 (g16 >> 1) + (i16 >> 2) (+ 8 for the second read, + 16 s2
+        // + 32 kb); (R >> 1) & 7 = x0 (+ 4 for the second read), x0 = 2 (g16 >> 1) + (i16 >> 3) < 4, gb < 4: chunk = (gb ^ x0) + 4 (db ^ second)
+        const int v_gb = 2 * (g16 & 1) + ((i16 & 3) >> 1), v_x0 = 2 * (g16 >> 1) + (i16 >> 3);
+        const char *vrow = vt_ + (toff + 4 * (g16 >> 1) + (i16 >> 2)) * RS;
+        const char *vbase = SWZ ? vrow + ((v_gb ^ v_x0) << 4) + 8 * (i16 & 1) : vrow + (16 * (g16 & 1) + (i16 & 3) * 4) * 2;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
@@ -348,9 +390,9 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
                 for (int j = 0; j < 8; ++j) pb[j] = (bf16)st[kb][8 * s2 + j];
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const char *va = vbase + (kb * 32 + 16 * s2) * RS + db * 64;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)va);
-                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(va + 8 * RS));
+                    const char *va = vbase + (kb * 32 + 16 * s2) * RS + (SWZ ? 0 : db * 64);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(va + (SWZ ? db * 64 : 0)));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(va + 8 * RS + (SWZ ? (db ^ 1) * 64 : 0)));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
                 }
@@ -755,12 +797,18 @@ int launch_attn_frame(const AttnArgs &a, hipStream_t s) {
 
 #include "attn_frame3.h"
 
-template <int NWQ>
+template <int NWQ, int DB = 3, bool REL = false>
 int launch_attn_v2(const AttnArgs &a, hipStream_t s) {
-    size_t smem = (size_t)4 * 64 * a.hd * 2 + 256 + (2 * 64 + 2) * sizeof(int);
-    if (smem < (size_t)NWQ * 32 * 200) smem = (size_t)NWQ * 32 * 200;
+    size_t smem = attn_v2_rel_offset(NWQ, a.hd) + (REL ? (size_t)(a.rel_n + 2 * ATTN_V2_REL_SLACK) * sizeof(float) : 0);
     const dim3 grid((a.sq + 32 * NWQ - 1) / (32 * NWQ), a.heads, a.batch), block(64 * NWQ);
-    hipLaunchKernelGGL(attn_prefill_v2_kernel<NWQ>, grid, block, smem, s, a);
+    if (smem > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_prefill_v2_kernel<NWQ, DB, REL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_prefill_v2_kernel<NWQ, DB, REL>), grid, block, smem, s, a);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }
@@ -783,6 +831,14 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         // of a workgroup's walk).  Probe flag 16 forces it, 32 forbids it.
         if (a.sq == 257 && !(a.dbg & 32) && ((a.dbg & (16 | 512)) || a.batch >= 512)) return launch_attn_frame3<88, 17>(a, s);
         return launch_attn_frame<88, 17>(a, s);
+    }
+    // hd = 64 with >= 128 query rows (the flan-t5 encoder: L = 960, relative position bias; also its bias-free long forms): round 5
+    // (its bias lookup does not clamp: the table must cover every distance of the launch, key - query - (skv - sq) in [-(skv - 1), sq - 1])
+    if (!g_attn_force_v1 && !a.drop_thr && a.hd == 64 && a.sq >= 128 && a.skv >= 64 && a.scale > 0.0f &&
+        (!a.rel_tab || (a.rel_n <= ATTN_V2_REL_MAX && a.rel_off >= a.skv - 1 && a.rel_off + a.sq <= a.rel_n))) {
+        const int qt = (a.sq + 31) / 32;
+        if (a.rel_tab) return qt >= 5 ? launch_attn_v2<8, 2, true>(a, s) : launch_attn_v2<4, 2, true>(a, s);
+        return qt >= 5 ? launch_attn_v2<8, 2, false>(a, s) : launch_attn_v2<4, 2, false>(a, s);
     }
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
         const int qt = (a.sq + 31) / 32;

@@ -7,8 +7,8 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "patch.hip", "gemv.hip"]
-HEADERS = ["common.h", "gemm_a4.h", "gemm_a4_loop.inc", "attn_frame3.h", os.path.join("..", "..", "include", "eilev.h")]
+SOURCES = ["gemm.hip", "gemm_pp4_ext.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "patch.hip", "gemv.hip"]
+HEADERS = ["common.h", "gemm_common.h", "gemm_tiled.h", "gemm_pp4.h", "gemm_w6.h", "gemm_skinny.h", "attn_frame3.h", os.path.join("..", "..", "include", "eilev.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 LIB = os.path.join(HERE, "libeilev_hip.so")
@@ -28,47 +28,17 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _generate_a4_loop() -> None:
-    """gemm_a4_loop.inc = the hand-scheduled K loop of gemm_a4_kernel as inline-asm text, written by gen_a4_loop.py.  The committed copy
-    is used as is unless its CONTENT differs from what the generator prints now (mtimes mean nothing after a checkout); the new text
-    goes to a temporary file first, so a failing generator or a read-only tree leaves the committed file alone."""
-    gen, inc = os.path.join(HERE, "gen_a4_loop.py"), os.path.join(HERE, "gemm_a4_loop.inc")
-    try:
-        text = subprocess.run([sys.executable, gen], check=True, capture_output=True, text=True).stdout
-    except (OSError, subprocess.CalledProcessError) as e:
-        if os.path.exists(inc):
-            print(f"warning: gen_a4_loop.py failed ({e}); keeping the committed gemm_a4_loop.inc", file=sys.stderr)
-            return
-        raise
-    try:
-        with open(inc) as f:
-            if f.read() == text:
-                return
-    except OSError:
-        pass
-    tmp = inc + f".tmp{os.getpid()}"
-    try:
-        with open(tmp, "w") as f:
-            f.write(text)
-        os.replace(tmp, inc)
-    except OSError as e:  # read-only install: the committed file stays
-        print(f"warning: cannot refresh gemm_a4_loop.inc ({e})", file=sys.stderr)
-
-
 def build_hip(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
     """``variant`` / ``extra_flags``: an A/B build of the same sources with extra -D flags into build/<variant>/ and
     libeilev_hip_<variant>.so (tools/gemm_ab.py compares two libraries in one process on one box)."""
-    _generate_a4_loop()
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build", variant) if variant else os.path.join(HERE, "build")
     lib = os.path.join(HERE, f"libeilev_hip_{variant}.so") if variant else LIB
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
-    # gemm.hip is by far the longest compile (the persistent kernel's instances): two objects, built side by side
-    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES if src != "gemm.hip"]
-    units += [("gemm.hip", "gemm.o", ["-DEILEV_GEMM_PART=1"]), ("gemm.hip", "gemm_ext.o", ["-DEILEV_GEMM_PART=2"]),
-              ("gemm.hip", "gemm_a4.o", ["-DEILEV_GEMM_PART=3"])]
+    # (gemm.hip and gemm_pp4_ext.hip are by far the longest compiles — the persistent kernel's instances — and run side by side)
+    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
     for src, obj, extra in units:
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, obj)

@@ -91,7 +91,7 @@ __device__ __forceinline__ float wave_max(float v) {
 //  * gelu_erf / gelu_erf_pk (everything but the two persistent kernels: Q-Former, training forward, small-tile launches, decode): Phi(-u) on
 //    [0, 5] as a degree-12 polynomial in t = 0.4 u - 1 (weighted minimax fit): max abs error of the GELU 1.5e-6, i.e. below the bf16
 //    rounding of the stored activation everywhere; r < 1.5e-6 beyond u = 5 (x < -5 returns -0.0-ish, approaching 0 like the exact form).
-//  * gelu_erf_n<NP> = the FAST form of the persistent kernels' epilogues (gemm_pp4_kernel, gemm_w6_kernel, gemm_a4_kernel: with a GELU only
+//  * gelu_erf_n<NP> = the FAST form of the persistent kernels' epilogues (gemm_pp4_kernel, gemm_w6_kernel: with a GELU only
 //    the ViT fc1 reaches them — >= 192 tiles of 256 x 128): r itself on [0, 4] as a degree-8
 //    polynomial in t = u / 2 - 1: max abs error 1.1e-4 (relative 2.2e-3 where |y| > 0.05; a constant -1.3e-4 for x < -4).  The stored
 //    activation is bf16 (2^-9 relative) and the reference's own bf16 run evaluates GELU on a pre-activation that was itself rounded
@@ -217,13 +217,12 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
-int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm.hip, object 2 (see EILEV_GEMM_PART)
-int launch_a4(const GemmArgs &g, hipStream_t s);
+int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm_pp4_ext.hip
 // gemv.hip: nn.Linear on M <= 8 rows as row dot products with the LayerNorm / flash-decoding merge in its prologue
 bool gemv_rows_ok(int M, int N, int K);
 int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const float *part, int heads, int hd,
                      int nsplit, const bf16 *W, const bf16 *bias, const bf16 *resid, int64_t ldr, void *out, int64_t ldo, int out_f32, int M, int N,
-                     int K, int epi, float scale, int scale_cols, hipStream_t s);                    // gemm.hip, object 3: gemm_a4.h
+                     int K, int epi, float scale, int scale_cols, hipStream_t s);
 // gemv.hip, M = 1: activations in registers, a 4-deep ring of weight sub-blocks, one workgroup per CU (round 4)
 bool gemv1_ok(int N, int K, int pro);
 int launch_gemv1(int pro, const bf16 *x, const bf16 *gamma, const bf16 *beta, float eps, const bf16 *W, const bf16 *bias, const bf16 *resid, void *out,

@@ -538,9 +538,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             eos_ids = []  # EOS can never fire before the budget is exhausted
             min_new = 0
         kw.pop("use_cache", None)
-        for k in ("return_dict_in_generate", "output_scores", "output_logits"):  # a tensor of ids is all this path returns: say so instead of ignoring
-            if kw.pop(k, None):
-                raise NotImplementedError(f"generate({k}=True) is not built on the HIP path (it returns the generated ids, as the reference's callers use it)")
+        # hf forwards these to GenerationMixin (ref:eilev/model/v2.py:318-322): the result becomes a ModelOutput with `sequences` (+ `scores` /
+        # `logits`: one (rows, vocab) fp32 tensor per generated token).  Scores are served for greedy search on the decoder-only LM — the
+        # per-step logits of the eager decode loop (`return_step_logits`), which for greedy search without processors ARE hf's processed scores;
+        # like hf, output_scores / output_logits without return_dict_in_generate change nothing.
+        want_dict = bool(kw.pop("return_dict_in_generate", False))
+        want_scores, want_logits = bool(kw.pop("output_scores", False)) and want_dict, bool(kw.pop("output_logits", False)) and want_dict
         # hf hands every other kwarg to GenerationMixin (ref:eilev/model/v2.py:318-322).  Logits processors and stopping criteria run in the
         # host loops over the same HIP decode step, with transformers' own processor classes (exactly hf's arithmetic and order).
         from transformers import (LogitsProcessorList, MaxTimeCriteria, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
@@ -565,6 +568,12 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
             rules = dict(processors=procs if len(procs) else None, stopping=crit if len(crit) else None)
         if kw:
             raise NotImplementedError(f"unsupported generate() arguments on the HIP path: {sorted(kw)}")
+        if want_dict and not (want_scores or want_logits):  # sequences only: any decoding mode, wrapped like hf wraps it
+            from transformers.generation.utils import GenerateDecoderOnlyOutput, GenerateEncoderDecoderOutput
+
+            plain = {k: v for k, v in generate_kwargs.items() if k not in ("return_dict_in_generate", "output_scores", "output_logits")}
+            seq = self.generate(input_ids, pixel_values=pixel_values, video_input_mask=video_input_mask, attention_mask=attention_mask, **plain)
+            return (GenerateEncoderDecoderOutput if self._is_t5 else GenerateDecoderOnlyOutput)(sequences=seq)
         if num_beams == 1 and not do_sample and int(num_return) != 1:
             raise ValueError("Greedy methods without beam search do not support `num_return_sequences` different than 1")
         if num_beams > 1 and int(num_return) > num_beams:
@@ -581,6 +590,17 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         eos1 = eos_ids[0] if eos_ids else -1
         host_rules = len(eos_ids) > 1 or min_new > 0 or rules is not None
         eng = self.engine()
+        if want_dict:
+            plain_greedy = num_beams == 1 and sampler is None and not host_rules
+            if (want_scores or want_logits) and not (plain_greedy and not self._is_t5):
+                raise NotImplementedError("generate(output_scores / output_logits) is served for greedy search on the decoder-only language model only")
+            from transformers.generation.utils import GenerateDecoderOnlyOutput
+
+            if plain_greedy and not self._is_t5 and (want_scores or want_logits):
+                ids, steps = eng.greedy_decode(emb, attention_mask, int(max_new), eos_id=int(eos1), pad_id=int(pad), use_graph=False, return_step_logits=True)
+                steps = tuple(st_[:, : self.config.text_config.vocab_size].float() for st_ in steps[: ids.shape[1]])
+                return GenerateDecoderOnlyOutput(sequences=ids, scores=steps if want_scores else None, logits=steps if want_logits else None)
+            raise AssertionError("unreachable: the sequences-only form returned before the encode")
         if self._is_t5:
             t = self.config.text_config
             start = t.decoder_start_token_id if t.decoder_start_token_id is not None else t.pad_token_id

@@ -267,3 +267,50 @@ def test_attention_frame_default_route_from_512_frames(hip):
         qf, kf, vf = (t.float().view(sq, heads, hd).transpose(0, 1) for t in qkv[b].split(D, dim=-1))
         ref = (torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf).transpose(0, 1).reshape(sq, D)
         assert (outs[0][b].float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("batch,heads,sq,skv,causal,masked,rel", [
+    (2, 4, 960, 960, 0, False, True),    # flan-t5-xl encoder: L = 960, relative position bias (round 5: the hd = 64 form of the v2 kernel)
+    (2, 3, 333, 333, 0, True, True),     # ragged length (partial last key tile and last query tile), left padding through the key mask
+    (1, 2, 200, 200, 1, False, True),    # causal + bias (decoder self-attention, teacher-forced)
+    (2, 2, 130, 300, 1, True, True),     # causal with offset (sq < skv) + bias + mask
+    (2, 4, 256, 512, 0, False, False),   # hd = 64 without a bias (long cross-attention)
+    (1, 2, 128, 64, 0, True, False),     # the smallest shapes the route takes
+])
+def test_attention_hd64_v2_route(hip, batch, heads, sq, skv, causal, masked, rel):
+    """hd = 64, >= 128 query rows: attn_prefill_v2_kernel<*, 2, REL> (128-byte LDS rows, XOR-swizzled through the LDS-DMA's source side;
+    the head's relative-position table in LDS) against the oracle's eilev_attention_rel (hf T5Attention: no 1 / sqrt(d) factor)."""
+    hd = 64
+    D = heads * hd
+    q = round_bf16(0.35 * det_normal("q64", (batch, sq, D)))
+    k = round_bf16(det_normal("k64", (batch, skv, D)))
+    v = round_bf16(det_normal("v64", (batch, skv, D)))
+    km = None
+    if masked:
+        km = np.ones((batch, skv), np.int32)
+        km[0, :7] = 0
+        if batch > 1:
+            km[1, :1] = 0
+            km[1, skv - 3:] = 0 if not causal else 1
+    n = sq + skv - 1
+    tab = (0.5 * det_normal("rel64", (heads, n))).astype(np.float32) if rel else None
+    ref = np.empty((batch, sq, D), np.float32)
+    pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    assert orc.lib().eilev_attention_rel(pp(q), pp(k), pp(v), pp(ref), batch, heads, sq, skv, hd, D, D, D, 1.0, causal, pp(km), pp(tab), n, skv - 1, n, None) == 0
+    dq, dk, dv = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    dkm = torch.from_numpy(km).cuda() if masked else None
+    dtab = torch.from_numpy(tab).cuda() if rel else None
+    out = torch.empty((batch, sq, D), dtype=torch.bfloat16, device="cuda")
+    rc = hip.eilev_attention_rel(P(dq), P(dk), P(dv), P(out), batch, heads, sq, skv, hd, D, D, D, 1.0, causal, P(dkm), P(dtab), n, skv - 1, n, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = host(out)
+    valid = np.ones((batch, sq), bool)
+    if masked and causal:
+        for b in range(batch):
+            first = int(np.argmax(km[b] != 0))
+            for i in range(sq):
+                if i + (skv - sq) < first:
+                    valid[b, i] = False
+    err = np.abs(got - ref)[valid].max()
+    assert err <= 2e-2 * np.abs(ref).max(), err

@@ -354,3 +354,43 @@ def test_output_attentions_of_the_qformer_and_the_language_model(golden_dir, dty
     # logits unchanged by the debug outputs
     plain = m(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), pixel_values=t(px).to(dtype), video_input_mask=t(g["video_input_mask"]))
     assert torch.equal(plain.logits, o.logits)
+
+
+def test_generate_return_dict_with_scores_like_the_reference(golden_dir):
+    """`generate(return_dict_in_generate=True, output_scores=True)` — hf hands the kwargs to GenerationMixin (ref:eilev/model/v2.py:318-322):
+    a ModelOutput with `sequences` and one (rows, vocab) fp32 score tensor per generated token.  tests/golden/mid_v2.npz holds exactly what
+    the REFERENCE returns for that call (tools/make_goldens.py::_greedy_with_scores: ids + every step's scores, two rows, left padding)."""
+    g, meta, px = load_case(golden_dir, "mid_v2")
+    from eilev_amd.configs import blip2_config
+    from oracle.runner import synth_state_dict
+
+    cfg = blip2_config(meta["config"])
+    sd = synth_state_dict(cfg, meta["weight_mode"], meta["weight_seed"])
+    from eilev_amd.model.v2 import VideoBlipForConditionalGeneration
+
+    m = VideoBlipForConditionalGeneration(cfg).eval()
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    sd["language_model.lm_head.weight"] = sd["language_model.model.decoder.embed_tokens.weight"]
+    m.load_state_dict(sd)
+    m = m.to(torch.bfloat16).to("cuda")
+    t = lambda a: torch.from_numpy(a).cuda()
+    kw = dict(input_ids=t(g["input_ids"]), pixel_values=t(px).to(torch.bfloat16), video_input_mask=t(g["video_input_mask"]),
+              attention_mask=t(g["attention_mask"]))
+    n = meta["new_tokens"]
+    out = m.generate(**kw, max_new_tokens=n, eos_token_id=meta["never_id"], return_dict_in_generate=True, output_scores=True, output_logits=True)
+    assert np.array_equal(out.sequences.cpu().numpy(), g["fp32_greedy_free"])
+    assert len(out.scores) == n == len(out.logits) and all(s_.dtype == torch.float32 and tuple(s_.shape) == g["fp32_step_logits"].shape[1:] for s_ in out.scores)
+    ref, ref16 = g["fp32_step_logits"], g["bf16_step_logits"]
+    for k in range(n):
+        err, dev = rel_rms(host(out.scores[k]), ref[k]), rel_rms(ref16[k], ref[k])
+        assert err <= 1.5 * dev + 2e-3, (k, err, dev)
+        assert torch.equal(out.scores[k], out.logits[k])
+    # sequences only: any decoding mode; scores without the dict flag change nothing (hf semantics)
+    seq = m.generate(**kw, max_new_tokens=n, eos_token_id=meta["never_id"], return_dict_in_generate=True)
+    assert np.array_equal(seq.sequences.cpu().numpy(), g["fp32_greedy_free"]) and seq.scores is None
+    plain = m.generate(**kw, max_new_tokens=n, eos_token_id=meta["never_id"], output_scores=True)
+    assert torch.is_tensor(plain) and np.array_equal(plain.cpu().numpy(), g["fp32_greedy_free"])
+    beams = m.generate(**kw, max_new_tokens=6, num_beams=3, eos_token_id=meta["never_id"], return_dict_in_generate=True)
+    assert beams.sequences.shape[0] == g["input_ids"].shape[0]
+    with pytest.raises(NotImplementedError):
+        m.generate(**kw, max_new_tokens=4, num_beams=3, return_dict_in_generate=True, output_scores=True)
