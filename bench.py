@@ -443,7 +443,7 @@ def measure_traffic_pmc(shape: str = "fc1_ln", rows: int = 257 * 1088, kernel: s
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="eilev_pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, PROBE_M=str(rows), TMPDIR="/tmp")
+            env = dict(os.environ, PROBE_M=str(rows), TMPDIR="/tmp", EILEV_PROBE_ON_PRODUCT_LIB="1")  # the PRODUCT library's kernel, no switches
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pm", "--", sys.executable,
                                 os.path.join(ROOT, "tools", "gemm_probe.py"), "0", shape, "1"],
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)

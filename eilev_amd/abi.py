@@ -450,6 +450,30 @@ def load_hip() -> C.CDLL:
     return _hip
 
 
+PROBES_LIB_PATH = os.path.join(_HERE, "csrc", "libeilev_hip_probes.so")
+_probes = None
+
+
+def load_probes():
+    """The PROBE build of the same sources (-DEILEV_PROBES: the product entry points + the process-global `eilev_debug_*` switches of
+    include/eilev.h's last comment) — tools/ and the few tests that compare an alternative kernel.  None when it has not been built
+    (`python eilev_amd/csrc/build.py --variant probes -DEILEV_PROBES`; __graft_entry__.build() builds it next to the product library).
+    Never loaded by the product path."""
+    global _probes
+    if _probes is None and os.path.exists(PROBES_LIB_PATH):
+        _probes = load_library(PROBES_LIB_PATH)
+    return _probes
+
+
+def use_probes() -> None:
+    """tools/ only: make this process run on the probe build (load_hip() and HIP_LIB_PATH then refer to libeilev_hip_probes.so)."""
+    global _hip, HIP_LIB_PATH
+    lib = load_probes()
+    if lib is None:
+        raise RuntimeError(f"{PROBES_LIB_PATH} not found: python eilev_amd/csrc/build.py --variant probes -DEILEV_PROBES")
+    _hip, HIP_LIB_PATH = lib, PROBES_LIB_PATH
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         names = {-1: "EILEV_E_BADARG", -2: "EILEV_E_UNSUPPORTED", -3: "EILEV_E_WORKSPACE"}

@@ -18,7 +18,9 @@
 #include <utility>
 
 int g_attn_force_v1 = 0, g_attn_dbg = 0;
+#ifdef EILEV_PROBES
 extern "C" int eilev_debug_attn_v1(int on) { g_attn_force_v1 = on & 1; g_attn_dbg = on >> 1; return 0; }
+#endif
 
 namespace {
 
@@ -483,9 +485,11 @@ __device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void
 }
 
 __device__ unsigned long long g_attn_ts[9 * 8 * 16];  // probe: [wave][pair < 8][event < 16] s_memtime stamps of workgroup 0
+#ifdef EILEV_PROBES
 extern "C" int eilev_debug_attn_ts(void *host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_ts), sizeof(g_attn_ts));
 }
+#endif
 typedef __attribute__((address_space(3))) char lds_char_t;
 typedef __attribute__((address_space(3))) const bf16x4 lds_cbf16x4_t;
 

@@ -7,7 +7,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm_pp4_ext.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "patch.hip", "gemv.hip"]
+SOURCES = ["gemm.hip", "gemm_pp4_ext.hip", "norm.hip", "attention.hip", "misc.hip", "pipeline.hip", "backward.hip", "comm.hip", "gemv.hip"]
 HEADERS = ["common.h", "gemm_common.h", "gemm_tiled.h", "gemm_pp4.h", "gemm_w6.h", "gemm_skinny.h", "attn_frame3.h", os.path.join("..", "..", "include", "eilev.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]

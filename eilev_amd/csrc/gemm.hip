@@ -24,11 +24,15 @@
 #include "gemm_skinny.h"
 
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
+#ifdef EILEV_PROBES  // the probe build only (build.py --variant probes -DEILEV_PROBES): the product library exports no switch
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
+#endif
 int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
 unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
 int g_gemm_trace_tiles = 0;
+#ifdef EILEV_PROBES
 extern "C" int eilev_debug_gemm_trace(void *buf, int tiles) { g_gemm_trace = (unsigned long long *)buf; g_gemm_trace_tiles = tiles; return 0; }
+#endif
 
 namespace {
 

@@ -1142,7 +1142,9 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
     return EILEV_OK;
 }
 static int g_beam_part = 1;
+#ifdef EILEV_PROBES
 extern "C" int eilev_debug_beam_part(int on) { g_beam_part = on; return 0; }  // probe / test switch: 0 = the 256-key split kernel for beam rows too (round 3)
+#endif
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
     const int nsplit = (cap + DEC_KEYS - 1) / DEC_KEYS;
     return sizeof(float) * (size_t)batch * heads * nsplit * (hd + 2);

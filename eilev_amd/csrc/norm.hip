@@ -172,81 +172,11 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restric
     *reinterpret_cast<float2 *>(out + r * 2) = make_float2(rstd, -mean);
 }
 
-// ---- decode: split-K partial sums -> output row -> its LayerNorm, one wave per row ------------------------------------------------
+// ---- decode: split-K partial sums -> output row -> its LayerNorm ------------------------------------------------------------------------
 // Replaces skinny_reduce_kernel + layernorm_kernel for the two residual GEMVs of an OPT block (hf modeling_opt.py:226-253: out_proj /
-// fc2, + residual, then the next LayerNorm).  Same arithmetic in the same order as those two kernels (partials summed s = 0 .. ks - 1
-// from 0, x wscale, + bias, + residual, one bf16 rounding; statistics over the rounded row with the lane / chunk assignment of
-// layernorm_kernel), so the results are bit-identical to the two launches.
-template <int MAXC, int KS>  // KS > 0: compile-time split count (all partial loads of a lane in flight at once); 0: run-time `ks`
-__global__ __launch_bounds__(64) void reduce_ln_kernel(const float *__restrict__ part, int ks, int mr, int N, const float *__restrict__ wscale,
-                                                      const bf16 *__restrict__ bias, const bf16 *__restrict__ resid, int64_t ldr,
-                                                      bf16 *__restrict__ C, int64_t ldc, const bf16 *__restrict__ gamma,
-                                                      const bf16 *__restrict__ beta, bf16 *__restrict__ y, float eps) {
-    const int lane = threadIdx.x, row = blockIdx.x;
-    const int nch = N >> 3;
-    float v[MAXC][8];
-    float sum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-            float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            auto add = [&](int s) {
-                const float4 *pp = reinterpret_cast<const float4 *>(part + ((int64_t)s * mr + row) * N + c * 8);
-                const float4 a = pp[0], b = pp[1];
-                t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
-            };
-            if constexpr (KS > 0) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) add(s);
-            } else {
-                for (int s = 0; s < ks; ++s) add(s);
-            }
-            float bv[8], rv[8];
-            if (bias) unpack8(*reinterpret_cast<const bf16x8 *>(bias + c * 8), bv);
-            if (resid) unpack8(*reinterpret_cast<const bf16x8 *>(resid + (int64_t)row * ldr + c * 8), rv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = t[e];
-                if (wscale) x *= wscale[c * 8 + e];
-                if (bias) x += bv[e];
-                if (resid) x += rv[e];
-                t[e] = x;
-            }
-            const bf16x8 o = pack8(t);
-            *reinterpret_cast<bf16x8 *>(C + (int64_t)row * ldc + c * 8) = o;
-            unpack8(o, v[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[i][e];
-        }
-    }
-    const float mean = wave_sum(sum) / (float)N;
-    float sq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)N + eps);
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-            float gv[8], bv[8], o[8];
-            unpack8(*reinterpret_cast<const bf16x8 *>(gamma + c * 8), gv);
-            unpack8(*reinterpret_cast<const bf16x8 *>(beta + c * 8), bv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gv[e] + bv[e];
-            *reinterpret_cast<bf16x8 *>(y + (int64_t)row * N + c * 8) = pack8(o);
-        }
-    }
-}
+// fc2, + residual, then the next LayerNorm): partials summed s = 0 .. ks - 1 from 0, x wscale, + bias, + residual, one bf16 rounding, then
+// the statistics over the rounded row — bit-identical to the two launches.  (Round 2 ran one WAVE per row; the workgroup-per-row form below
+// replaced it in round 4: profiles/r04_reduce_ln_ab.log.)
 
 // Round 4: the same reduction with ONE 16-byte chunk per thread — a workgroup of N / 8 threads per row (N = 2560: 5 waves) instead of one
 // wave walking 5 chunks: a fifth of the loads per lane, gamma / beta requested with the partials (not after the statistics), the row
@@ -318,13 +248,10 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
     }
 }
 
-int g_reduce_ln_wave = 0;  // probe (eilev_debug_reduce_ln_wave): 1 = the one-wave-per-row kernel of round 2
-extern "C" int eilev_debug_reduce_ln_wave(int on) { g_reduce_ln_wave = on; return 0; }
-
 int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
                      int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s) {
     if (!part || !C || !gamma || !beta || !ln_out || M <= 0 || (N & 7) || N > 8 * 512) return EILEV_E_UNSUPPORTED;
-    if (!g_reduce_ln_wave) {
+    {
         const int threads = (((N >> 3) + 63) / 64) * 64;
 #define EILEV_RLW(KS_) hipLaunchKernelGGL((reduce_ln_wg_kernel<KS_>), dim3(M), dim3(threads), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)
         if (ks == 2) EILEV_RLW(2); else if (ks == 4) EILEV_RLW(4); else EILEV_RLW(0);
@@ -332,13 +259,6 @@ int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const floa
         EILEV_LAUNCH_CHECK();
         return EILEV_OK;
     }
-#define EILEV_RLN(MC, KS_) hipLaunchKernelGGL((reduce_ln_kernel<MC, KS_>), dim3(M), dim3(64), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)
-    if (N <= 3 * 512) { if (ks == 2) EILEV_RLN(3, 2); else if (ks == 4) EILEV_RLN(3, 4); else EILEV_RLN(3, 0); }
-    else if (N <= 5 * 512) { if (ks == 2) EILEV_RLN(5, 2); else if (ks == 4) EILEV_RLN(5, 4); else EILEV_RLN(5, 0); }
-    else { if (ks == 2) EILEV_RLN(8, 2); else if (ks == 4) EILEV_RLN(8, 4); else EILEV_RLN(8, 0); }
-#undef EILEV_RLN
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
 }
 
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,

@@ -10,9 +10,6 @@ int launch_im2col(const void *pix, int dtype, bf16 *out, int64_t rows, int frame
 int launch_pad_rows(const bf16 *w, bf16 *out, int rows, int k, int kp, hipStream_t s);
 int launch_cls_rows(const bf16 *cls, const bf16 *pos, bf16 *x, int64_t frames_total, int tok, int d, hipStream_t s);
 int launch_quant_rows_e4m3(const bf16 *x, int64_t ldx, uint8_t *q, float *scale, int64_t rows, int cols, hipStream_t s);
-int launch_patch_embed_ln(const void *pix, int pix_dtype, const bf16 *wpad, const bf16 *bias, const bf16 *pos, const bf16 *cls,
-                          const bf16 *gamma, const bf16 *beta, bf16 *x, bf16 *ln, int64_t frames_total, int frames_per_clip, int img,
-                          int patch, int D, int KP, float eps, hipStream_t s);
 int launch_broadcast_rows(const bf16 *src, bf16 *dst, int64_t copies, int64_t n, hipStream_t s);
 int launch_embed_scatter(const bf16 *embed, const int64_t *ids, const uint8_t *mask, const bf16 *feats, int64_t n_rows,
                          int64_t total, int vocab, bf16 *out, int d, hipStream_t s);
@@ -96,18 +93,13 @@ extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms,
 }
 
 extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
-// probe / test switch: 1 = take the unfused patch path (im2col -> GEMM -> CLS rows -> LayerNorm) even where the fused kernel applies
 // (r4) 24 576: tools/vit_small_launch.py — the fold wins from 96 frames per launch (53.3 vs 55.7 ms; 136 frames 69.3 vs 71.5), ties at 32-64
 // frames and loses below (8 frames 11.2 vs 8.9 ms: too few 256 x 256 tiles for the persistent kernel)
 static int64_t g_ln_fold_min_rows = 24576;
-extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }
-// Round 3: the UNFUSED patch path is the default — im2col_strip_kernel reads the frame tensor with coalesced 16-byte loads at 3.9 TB/s
-// (168 us per 1088 frames) and im2col + GEMM + CLS rows + LayerNorm take 0.93 ms per launch, while the fused patch_embed_ln_kernel takes
-// 2.74 ms (0.69 TB/s on the pixels: 50 spilled VGPRs in its K loop, W re-streamed from L2 by every workgroup).  The fused kernel
-// stays selectable (eilev_debug_fused_patch(1)) and parity-tested against this path.
-static int g_fused_patch = 0;
-extern "C" int eilev_debug_fused_patch(int on) { g_fused_patch = on; return 0; }
-extern "C" int eilev_debug_no_fused_patch(int on) { g_fused_patch = on ? 0 : g_fused_patch; return 0; }  // (kept for older probes: 1 = unfused)
+extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }  // (part of the ABI: tests/test_ln_fold.py runs both routes)
+// The patch path: im2col_strip_kernel reads the frame tensor with coalesced 16-byte loads at 3.9 TB/s (168 us per 1088 frames) and im2col +
+// GEMM + CLS rows take 0.93 ms per launch; the fused patch-embed + LayerNorm kernel of rounds 1-2 took 2.74 ms (0.69 TB/s on the pixels:
+// 50 spilled VGPRs in its K loop, W re-streamed from L2 by every workgroup) and was retired to tools/probes/patch_fused.hip in round 5.
 extern "C" const char *eilev_backend(void) { return "hip-gfx950"; }
 
 namespace {
@@ -262,31 +254,21 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     const bool fold = w->layers_fold && M >= g_ln_fold_min_rows && !hidden_states && !attentions && D % 64 == 0 && Fi % 64 == 0 &&
                       (int64_t)M * D * 2 < 0x7fff0000ll && (int64_t)Fi * D * 2 < 0x7fff0000ll;
 
-    // patch embedding (+ bias + position, CLS rows) fused with layer_norm1 of block 0: hf modeling_blip_2.py:243-255, :390.
-    // One kernel (patch.hip); shapes it does not take fall back to im2col -> GEMM -> CLS rows (+ the separate LayerNorm below).
+    // patch embedding (+ bias + position, CLS rows): hf modeling_blip_2.py:243-255 as im2col (coalesced strip reads of the frame tensor) ->
+    // GEMM with the position rows as its "residual" -> CLS rows; layer_norm1 of block 0 is the folded LayerNorm of its qkv GEMM (or the
+    // LayerNorm kernel below).  (The ONE-kernel form — patch embedding + LayerNorm1 fused, rounds 1-2 — measured slower end to end in
+    // round 3 and lives on as tools/probes/patch_fused.hip.)
     RC(launch_pad_rows((const bf16 *)w->patch_w, wpad, D, PK, KP, s));
-    bool ln0_done = false;
+    const bool ln0_done = false;
     {
-        const EilevVitLayer *L0 = d->v_layers > 0 ? &w->layers[0] : nullptr;
-        const int rc_ = !g_fused_patch ? EILEV_E_UNSUPPORTED
-                                         : launch_patch_embed_ln(pixels, pixels_dtype, wpad, (const bf16 *)w->patch_b, (const bf16 *)w->pos,
-                                                                 (const bf16 *)w->cls, L0 ? (const bf16 *)L0->ln1_w : nullptr,
-                                                                 L0 ? (const bf16 *)L0->ln1_b : nullptr, x, L0 ? ln : nullptr, F, (int)frames,
-                                                                 d->image_size, d->patch_size, D, KP, d->v_eps, s);
-        if (rc_ == EILEV_OK) {
-            ln0_done = L0 != nullptr;
-        } else if (rc_ == EILEV_E_UNSUPPORTED) {
-            // prof kind 6: the pixel read of the frame tensor ("flops" carries the BYTES of pixels read: bench.py reports GB/s)
-            prof_begin(6, (double)F * 3.0 * d->image_size * d->image_size * (pixels_dtype == 0 ? 4.0 : 2.0), s);
-            RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
-            prof_end(s);
-            GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
-            g.patch_group = (int)G2;
-            RC(launch_gemm(g, 5, s));
-            RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
-        } else {
-            return rc_;
-        }
+        // prof kind 6: the pixel read of the frame tensor ("flops" carries the BYTES of pixels read: bench.py reports GB/s)
+        prof_begin(6, (double)F * 3.0 * d->image_size * d->image_size * (pixels_dtype == 0 ? 4.0 : 2.0), s);
+        RC(launch_im2col(pixels, pixels_dtype, mlp, F * G2, (int)frames, d->image_size, d->patch_size, KP, s));
+        prof_end(s);
+        GemmArgs g = mk_gemm(mlp, KP, wpad, KP, w->patch_b, (const bf16 *)w->pos, D, x, D, F * G2, D, KP, 0);
+        g.patch_group = (int)G2;
+        RC(launch_gemm(g, 5, s));
+        RC(launch_cls_rows((const bf16 *)w->cls, (const bf16 *)w->pos, x, F, (int)tok, D, s));
     }
     const size_t hs_bytes = (size_t)M * D * sizeof(bf16);
     if (hidden_states) RC((int)hipMemcpyAsync(hidden_states, x, hs_bytes, hipMemcpyDeviceToDevice, s));
@@ -583,51 +565,6 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     return launch_gemm(g, 5, s);
 }
 
-// ---- decode: weight prefetch into the Infinity Cache on a parallel branch (probe: eilev_debug_decode_prefetch) --------------------------
-// The GEMVs of a decode step are latency-bound (2.2 TB/s at 32 rows) while the attention before them is HBM-bound on the KV cache; the
-// weights do not depend on activations, so block l's out_proj / fc1 / fc2 (+ block l + 1's q|k|v) can be pulled towards the 256-MB
-// memory-side cache by a touch kernel on a second stream while block l's attention runs.  One 16-byte load per 64-byte segment.
-int g_decode_prefetch = 0;
-hipStream_t g_pf_stream = nullptr;
-hipEvent_t g_pf_fork = nullptr, g_pf_join = nullptr;
-unsigned *g_pf_sink = nullptr;
-struct TouchArgs {
-    const void *p[4];
-    size_t bytes[4];
-};
-__global__ __launch_bounds__(256) void weight_touch_kernel(const TouchArgs a, unsigned *sink) {
-    unsigned acc = 0;
-    for (int sgm = 0; sgm < 4; ++sgm) {
-        const char *base = (const char *)a.p[sgm];
-        const size_t n = a.bytes[sgm] / 64;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + i * 64);
-            acc ^= v.x;
-        }
-    }
-    if (acc == 0x5ca1ab1eu && sink) *sink = acc;  // keeps the loads alive; practically never taken
-}
-int pf_init() {
-    if (g_pf_stream) return EILEV_OK;
-    EILEV_HIP_CHECK(hipStreamCreateWithFlags(&g_pf_stream, hipStreamNonBlocking));
-    EILEV_HIP_CHECK(hipEventCreateWithFlags(&g_pf_fork, hipEventDisableTiming));
-    EILEV_HIP_CHECK(hipEventCreateWithFlags(&g_pf_join, hipEventDisableTiming));
-    EILEV_HIP_CHECK(hipMalloc(&g_pf_sink, 64));
-    return EILEV_OK;
-}
-int pf_launch(const TouchArgs &t, hipStream_t s) {  // fork from s, touch on the side stream (joined once at the end of the step)
-    EILEV_HIP_CHECK(hipEventRecord(g_pf_fork, s));
-    EILEV_HIP_CHECK(hipStreamWaitEvent(g_pf_stream, g_pf_fork, 0));
-    hipLaunchKernelGGL(weight_touch_kernel, dim3(g_decode_prefetch > 1 ? g_decode_prefetch : 128), dim3(256), 0, g_pf_stream, t, g_pf_sink);
-    EILEV_LAUNCH_CHECK();
-    return EILEV_OK;
-}
-int pf_join(hipStream_t s) {
-    EILEV_HIP_CHECK(hipEventRecord(g_pf_join, g_pf_stream));
-    EILEV_HIP_CHECK(hipStreamWaitEvent(s, g_pf_join, 0));
-    return EILEV_OK;
-}
-
 // ---- small-batch decode (M <= 8 rows): the block as 5 launches of gemv.hip + the attention split ---------------------------------------
 int g_decode_rows = 1;  // probe / test switch (eilev_debug_decode_rows): 0 = the MFMA weight-streaming kernels at every batch size
 constexpr int kDecodeKeys = 256;  // keys per flash-decoding split (misc.hip DEC_KEYS)
@@ -726,13 +663,9 @@ int opt_rows_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b
 
 }  // namespace
 
+#ifdef EILEV_PROBES
 extern "C" int eilev_debug_decode_rows(int on) { g_decode_rows = on; return 0; }
-// 0 off, 1 = 128 workgroups, n > 1 = n.  Creates the side stream / events here: not inside a graph capture.
-extern "C" int eilev_debug_decode_prefetch(int workgroups) {
-    g_decode_prefetch = workgroups;
-    return workgroups ? pf_init() : 0;
-}
-
+#endif
 namespace {
 int opt_prefill_impl(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask, int64_t batch,
                      int64_t seq_len, void *kv_cache, int64_t kv_capacity, float *logits_last, float *logits_all, bf16 *hidden,
@@ -946,15 +879,6 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         if (l == 0) RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
         RC(opt_qkv(d, w, l, b, batch, s));
-        if (g_decode_prefetch && g_pf_stream && !w->layers_w8) {  // probe: this block's remaining weights (+ the next block's q|k|v) under its attention
-            TouchArgs t = {};
-            const size_t DD = (size_t)D * D * sizeof(bf16), DF = (size_t)D * d->t_ffn * sizeof(bf16);
-            t.p[0] = L->o_w; t.bytes[0] = DD;
-            t.p[1] = L->fc1_w; t.bytes[1] = DF;
-            t.p[2] = L->fc2_w; t.bytes[2] = DF;
-            if (l + 1 < d->t_layers) { t.p[3] = w->layers[l + 1].q_w; t.bytes[3] = 3 * DD; }
-            RC(pf_launch(t, s));
-        }
         // the new token's K / V go into the cache inside the attention kernel (fuse_new): one launch less per layer
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
                               b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
@@ -962,7 +886,6 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         const bool last = l + 1 == d->t_layers;
         RC(opt_tail(d, w, l, b, batch, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b));
     }
-    if (g_decode_prefetch && g_pf_stream && !w->layers_w8) RC(pf_join(s));
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     RC(launch_gemm(g, 5, s));

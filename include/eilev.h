@@ -19,10 +19,11 @@
  * Conventions: the caller owns every buffer (weights, activations, workspace, KV cache); the
  * library never allocates device memory and never synchronises the stream.  Returns 0 on
  * success, a negative EILEV_E_* for bad arguments / unsupported dimensions, a positive value
- * = passthrough hipError_t.  Global mutable state: none on the product path.  The library also exports a handful of
- * process-global PROBE switches (`eilev_debug_*`, listed at the end of this header): they all default to "off", nothing in
- * eilev_amd/ sets them outside tests / tools/, and a caller that never touches them gets a stateless library.  They are not
- * thread-safe (plain ints read at launch time) and not part of the drop-in contract.
+ * = passthrough hipError_t.  Global mutable state: none — the product library exports ONE tuning knob
+ * (`eilev_debug_ln_fold_min_rows`, a row threshold read at launch time; tests run both of its routes) and no probe switch.  The
+ * `eilev_debug_*` switches of the tools (tile-configuration overrides, phase stamps, alternative kernels for A/B runs) exist only in the
+ * PROBE build of the same sources (`python eilev_amd/csrc/build.py --variant probes -DEILEV_PROBES` -> libeilev_hip_probes.so, loaded by
+ * tools/ and by the few tests that compare an alternative kernel): listed at the end of this header.
  * Linear weights are in the checkpoint's layout: [out_features, in_features] row-major.
  */
 #ifndef EILEV_H
@@ -254,17 +255,13 @@ int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, cons
                         int64_t n, int64_t k, int epilogue, void *stream);
 /* probe / test knob: minimum token rows of a launch for the folded ViT path (default 24 576; 0 = always when layers_fold is set) */
 void eilev_debug_ln_fold_min_rows(int64_t rows);
-/* The other process-global probe switches (all default 0 = the product path; tools/ and tests/ only; see the header comment):
- *   eilev_debug_gemm_flags        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
- *   eilev_debug_gemm_trace per-tile time stamps of the persistent GEMM (tools/gemm_trace.py)
- *   eilev_debug_patch_trace       phase stamps of the fused patch kernel (tools/patch_trace.py)
- *   eilev_debug_attn_v1           route attention to the round-1 kernels (A/B in tests/test_hip_kernels.py)
- *   eilev_debug_attn_ts           phase stamps of the frame attention kernel (tools/attn_ts.py)
- *   eilev_debug_fused_patch / eilev_debug_no_fused_patch   select the fused patch-embed + LayerNorm kernel (opt-in since r3)
- *   eilev_debug_decode_rows       0: MFMA weight-streaming kernels at every batch size; 1 (default): row-dot kernels at <= 4 rows; 3: the round-3 row-dot kernels (<= 2 rows) instead of gemv1 / gemvm
- *   eilev_debug_decode_prefetch   the rejected Infinity-Cache touch kernel of DESIGN 3b (off)
- *   eilev_debug_reduce_ln_wave    1: the one-wave-per-row split-K reduce + LayerNorm of round 2 (default: a workgroup per row)
- *   eilev_debug_beam_part         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges */
+/* PROBE build only (-DEILEV_PROBES; not exported by libeilev_hip.so): process-global switches, all default 0 = the product path
+ *   eilev_debug_gemm_flags : int (int)        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
+ *   eilev_debug_gemm_trace : int (void*, int) per-tile time stamps of the persistent GEMM (tools/gemm_trace.py, tools/gemm_itrace.py)
+ *   eilev_debug_attn_v1 : int (int)           route attention to the round-1 kernels / select frame-attention variants (A/B tests)
+ *   eilev_debug_attn_ts : int (void*)         phase stamps of the frame attention kernel (tools/attn_ts.py)
+ *   eilev_debug_decode_rows : int (int)       0: MFMA weight-streaming kernels at every batch size; 1 (default): row-dot kernels at <= 4 rows; 3: the round-3 row-dot kernels
+ *   eilev_debug_beam_part : int (int)         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.

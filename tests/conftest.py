@@ -30,3 +30,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture()
+def probes():
+    """The probe build of the HIP library (alternative kernels behind `eilev_debug_*` switches, for A/B tests); while the fixture is
+    active it also stands in for the product library inside eilev_amd (engines built in the test run on it), restored afterwards."""
+    from eilev_amd import abi
+
+    lib = abi.load_probes()
+    if lib is None:
+        pytest.skip("libeilev_hip_probes.so not built (python eilev_amd/csrc/build.py --variant probes -DEILEV_PROBES)")
+    saved = abi._hip
+    abi._hip = lib
+    try:
+        yield lib
+    finally:
+        abi._hip = saved

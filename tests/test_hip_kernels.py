@@ -178,20 +178,19 @@ def test_attention_online_softmax_rescale_branch(hip):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(1000, 1408, 1408, 0), (700, 1408, 640, 1), (520, 1536, 128, 0), (300, 128, 256, 2)])
-def test_linear_256x256_half_column_tile(hip, m, n, k, epi):
+def test_linear_256x256_half_column_tile(probes, m, n, k, epi):
     """N % 256 <= 128 with the 256x256 kernel forced: the last column tile runs the 8-waves-as-4x2 half-tile path."""
-    raw = C.CDLL(abi.HIP_LIB_PATH)
-    raw.eilev_debug_gemm_flags(1 << 4)
+    probes.eilev_debug_gemm_flags(1 << 4)
     try:
-        _lin_case(hip, m, n, k, epi, bias=True, resid=(epi == 0))
+        _lin_case(probes, m, n, k, epi, bias=True, resid=(epi == 0))
     finally:
-        raw.eilev_debug_gemm_flags(0)
+        probes.eilev_debug_gemm_flags(0)
 
 
-def test_linear_operand_over_2gib(hip):
+def test_linear_operand_over_2gib(probes):
     """An A operand beyond the 32-bit buffer-offset range of the LDS-DMA kernels (Q-Former k|v projection of a whole bench
     step) is processed in row chunks: same result as the register-staged kernel, which addresses with 64-bit pointers."""
-    raw = C.CDLL(abi.HIP_LIB_PATH)
+    hip = raw = probes
     m, n, k = 800_000, 256, 1408  # 2.25 GB of A
     torch.manual_seed(0)
     a = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
@@ -212,12 +211,12 @@ def test_linear_operand_over_2gib(hip):
 
 
 @pytest.mark.parametrize("batch", [1, 3, 18, 41])
-def test_attention_frame_two_group_kernel(hip, batch):
+def test_attention_frame_two_group_kernel(probes, batch):
     """`attn_frame3_kernel` (two wave groups one phase apart: two query tiles per wave share every K / V fragment, the CLS row split over
     the keys and merged from eight partial softmaxes; the default from 256 frames, forced here by probe flag 16) against the oracle and
     the single-tile kernel.  1 / 3 frames: workgroups with one pair (no next pair to prefetch); 18: 288 pairs > 256 CUs, the buffer
     ring and the deferred CLS merge run over two pairs; 41: the XCD-aware walk with a ragged last round."""
-    raw = C.CDLL(abi.HIP_LIB_PATH)
+    hip = raw = probes
     heads, sq, hd = 16, 257, 88
     D = heads * hd
     q, k, v = (round_bf16(det_normal(n, (batch, sq, D))) for n in ("qj", "kj", "vj"))
@@ -241,10 +240,10 @@ def test_attention_frame_two_group_kernel(hip, batch):
     assert np.abs(outs[0][:, 256] - outs[1][:, 256]).max() <= 2.0 ** -7 * np.abs(ref[:, 256]).max()  # CLS row: another summation order
 
 
-def test_attention_frame_default_route_from_512_frames(hip):
+def test_attention_frame_default_route_from_512_frames(probes):
     """From 512 frames `eilev_attention` takes the two-group kernel on its own: the same bits as forcing it, the patch rows the same bits
     as the single-tile kernel, and a sample of frames against fp32 softmax attention."""
-    raw = C.CDLL(abi.HIP_LIB_PATH)
+    hip = raw = probes
     batch, heads, sq, hd = 520, 16, 257, 88  # 32-33 pairs per workgroup
     D = heads * hd
     g = torch.Generator(device="cuda")

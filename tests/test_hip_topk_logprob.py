@@ -94,7 +94,7 @@ def test_beam_advance_vs_oracle_step_by_step(B, nb, n_eos, T, early, recip):
 
 
 @pytest.mark.parametrize("L,B,nb", [(700, 1, 5), (530, 2, 3), (300, 4, 2), (130, 1, 8)])
-def test_beam_attention_128_key_ranges_vs_split_kernel(L, B, nb):
+def test_beam_attention_128_key_ranges_vs_split_kernel(probes, L, B, nb):
     """Beam-search decode step at <= 8 rows: attn_decode_part_kernel<.., BEAM> (128-key ranges, loads up front) against the 256-key split
     kernel it replaces there — every step's logits equal to summation-order rounding of the bf16 attention rows, with left padding, through a
     real search (rows get re-parented: the ancestor table is read by both).  The parity test proper of the beam step is
@@ -109,7 +109,7 @@ def test_beam_attention_128_key_ranges_vs_split_kernel(L, B, nb):
     named = {k: torch.from_numpy(synth_param(k, shp, "varied")).to(torch.bfloat16).cuda()
              for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
     eng = HipEngine(cfg, named, device="cuda", parts=("opt",))
-    raw = C.CDLL(abi.HIP_LIB_PATH)
+    raw = probes  # (the engine above was built while the fixture stands in for the product library)
     torch.manual_seed(L)
     emb = (0.5 * torch.randn(B, L, eng.dims.t_hidden, device="cuda")).to(torch.bfloat16)
     am = torch.ones(B, L, dtype=torch.int32, device="cuda")

@@ -143,6 +143,10 @@ def test_c_abi_library_exports_every_declared_symbol():
         lib = ctypes.CDLL(abi.HIP_LIB_PATH)  # loads without a GPU
         for sym in declared:
             assert hasattr(lib, sym), sym
+        # round 5: the product library carries no probe switch (they exist in the -DEILEV_PROBES build only)
+        for sw in ("eilev_debug_gemm_flags", "eilev_debug_gemm_trace", "eilev_debug_attn_v1", "eilev_debug_attn_ts", "eilev_debug_decode_rows",
+                   "eilev_debug_beam_part", "eilev_debug_fused_patch", "eilev_debug_decode_prefetch", "eilev_debug_reduce_ln_wave"):
+            assert not hasattr(lib, sw), sw
     from oracle.runner import lib as oracle_lib
 
     for sym in declared:

@@ -9,6 +9,8 @@ import torch
 
 from eilev_amd import abi
 
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
+
 lib = abi.load_hip()
 raw = C.CDLL(abi.HIP_LIB_PATH)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)

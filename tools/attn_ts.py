@@ -10,6 +10,8 @@ import torch
 
 from eilev_amd import abi
 
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
+
 lib = abi.load_hip()
 raw = C.CDLL(abi.HIP_LIB_PATH)
 b, h, sq, hd = 544, 16, 257, 88

@@ -19,6 +19,8 @@ emb = (torch.randn(B, L, cfg.text_config.hidden_size, device=dev) * 0.02).to(tor
 am = torch.ones(B, L, dtype=torch.int32, device=dev)
 import ctypes as C
 from eilev_amd import abi
+
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 raw = C.CDLL(abi.HIP_LIB_PATH)
 for rd in range(6):
     flag = int(os.environ.get("PROBE_FLAG", "536870912")) if rd % 2 else 0  # odd rounds: the probe flag (default: split-K reduce and LayerNorm as two launches)

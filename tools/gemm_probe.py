@@ -21,8 +21,19 @@ import torch
 
 from eilev_amd import abi
 
+_flags_req = [x for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]) if int(x)]
+if os.environ.get("EILEV_PROBE_ON_PRODUCT_LIB") and not _flags_req:
+    pass  # flags 0 only on libeilev_hip.so itself: what bench.py's live traffic measurement profiles
+else:
+    abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
+
 lib = abi.load_hip()
 raw = C.CDLL(abi.HIP_LIB_PATH)
+if not hasattr(raw, "eilev_debug_gemm_flags"):  # product library: no switches (flags 0 only, see above)
+    class _NoSwitch:
+        def eilev_debug_gemm_flags(self, f):
+            assert f in (0, 4)
+    raw = _NoSwitch()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 NOBIAS = bool(os.environ.get("PROBE_NOBIAS"))
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)

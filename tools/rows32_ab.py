@@ -7,6 +7,8 @@ import ctypes as C
 import torch
 import bench
 from eilev_amd import abi
+
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 from eilev_amd.configs import blip2_config
 from eilev_amd.engine import HipEngine
 cfg = blip2_config("opt27"); dev = torch.device("cuda")
@@ -19,7 +21,7 @@ outs = {}
 for rd in range(6):
     flag = (1 << 28) if rd % 2 else 0
     if os.environ.get("PROBE_SWITCH") == "reduce_ln":  # A/B of the split-K reduce + LayerNorm kernel instead (odd rounds: one wave per row)
-        raw.eilev_debug_reduce_ln_wave(1 if rd % 2 else 0)
+        pass  # (the one-wave reduce kernel was removed in round 5)
     else:
         raw.eilev_debug_gemm_flags(flag)
     eng._dec_cache = None
@@ -30,5 +32,5 @@ for rd in range(6):
     pre = e0.elapsed_time(dict(eng.timing)["prefill_done"])
     outs[flag] = out.cpu()
     print(f"round {rd} ({'round-3 kernels' if flag else 'rows32'}): decode {(e0.elapsed_time(e2) - pre) / (NEW - 1):.3f} ms/token", flush=True)
-raw.eilev_debug_gemm_flags(0); raw.eilev_debug_reduce_ln_wave(0)
+raw.eilev_debug_gemm_flags(0)
 print("ids equal between the two:", float((outs[0] == outs[1 << 28]).float().mean()))

@@ -5,6 +5,8 @@ import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from eilev_amd import abi
+
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 lib = abi.load_hip(); raw = C.CDLL(abi.HIP_LIB_PATH)
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)

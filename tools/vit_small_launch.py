@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from eilev_amd import abi
+
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 from eilev_amd.configs import blip2_config
 from eilev_amd.engine import HipEngine
 
