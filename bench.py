@@ -775,7 +775,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             traffic = tr = None
             try:  # PMC-measured HBM/fabric bytes per launch of this kernel (profiles/, collected with rocprofv3 --pmc)
-                with open(os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r05_gemm_traffic.json")) as fh:
                     tr = json.load(fh).get(nm.split(" [")[0].replace("gemm_nt ViT ", ""))
                 if tr:  # measured on the bench's launch shape (1088 frames x 257 tokens per launch)
                     traffic = int((2 * tr["fetch_kb"] + tr["write_kb"]) * 1024)
@@ -783,7 +783,7 @@ def main():
                 pass
             live, why = (None, "--no-pmc") if args.no_pmc else (None, "N > 1") if world > 1 else \
                 (None, "not the fc1 roofline kernel / launch shape") if "fc1" not in nm or S * (N_CTX + 1) % 136 else measure_traffic_pmc()
-            src = "profiles/r04_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run: " + str(why) + ")"
+            src = "profiles/r05_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel at this launch shape; not re-measured in this run: " + str(why) + ")"
             if live:
                 traffic = int((2 * live["fetch_kb"] + live["write_kb"]) * 1024)
                 src = (f"measured in this run after the timed region: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around "

@@ -657,7 +657,8 @@ int launch_attn_frame3(const AttnArgs &a, hipStream_t s) {
         attr_set = true;
     }
     const int npairs = a.batch * a.heads;
-    const int grid = npairs < num_cu ? npairs : num_cu;
+    const int ncu = eilev_grid_cus() < num_cu ? eilev_grid_cus() : num_cu;
+    const int grid = npairs < ncu ? npairs : ncu;
     hipLaunchKernelGGL((attn_frame3_kernel<HD, NT>), dim3(grid), dim3(512), smem, s, a);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;

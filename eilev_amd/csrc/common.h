@@ -34,6 +34,11 @@ static inline int eilev_num_cu() {
     return n;
 }
 
+// CUs the persistent kernels (one workgroup per CU: GEMM, frame attention) size their grids for: all of them, or fewer when the caller runs
+// them on a CU-masked stream next to another stream (probe switch eilev_debug_grid_cus; tools/overlap_probe.py).
+extern int g_eilev_grid_cus;
+static inline int eilev_grid_cus() { return g_eilev_grid_cus > 0 ? g_eilev_grid_cus : eilev_num_cu(); }
+
 #define EILEV_LAUNCH_CHECK()                           \
     do {                                               \
         hipError_t _e = hipGetLastError();             \

@@ -24,8 +24,10 @@
 #include "gemm_skinny.h"
 
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
+int g_eilev_grid_cus = 0;  // 0 = every CU (common.h: eilev_grid_cus)
 #ifdef EILEV_PROBES  // the probe build only (build.py --variant probes -DEILEV_PROBES): the product library exports no switch
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
+extern "C" int eilev_debug_grid_cus(int n) { g_eilev_grid_cus = n; return 0; }
 #endif
 int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
 unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
@@ -50,7 +52,8 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    const int ncu = eilev_grid_cus() < num_cu ? eilev_grid_cus() : num_cu;
+    const int grid = tiles < ncu ? tiles : ncu / 8 * 8;
     if (g.A8 || g.ln_rows || g.stat_out) return launch_pp4_ext(g, grid, s);  // fp8 MFMA / LayerNorm-folding instances (the other object)
     if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);

@@ -331,7 +331,8 @@ int launch_w6(const GemmArgs &g, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    const int grid = tiles < num_cu ? tiles : num_cu / 8 * 8;
+    const int ncu = eilev_grid_cus() < num_cu ? eilev_grid_cus() : num_cu;
+    const int grid = tiles < ncu ? tiles : ncu / 8 * 8;
     if (g.epi == 1) hipLaunchKernelGGL(gemm_w6_kernel<1>, dim3(grid), dim3(256), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_w6_kernel<2>, dim3(grid), dim3(256), smem, s, g);
     else hipLaunchKernelGGL(gemm_w6_kernel<0>, dim3(grid), dim3(256), smem, s, g);

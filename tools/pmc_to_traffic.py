@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn the text tools/prof_round3.sh writes (gpurun_out/r03_gemm_pmc.txt: one rocpd_pmc.py table per shape and counter group) into
-profiles/r03_gemm_traffic.json, the file bench.py reads `roofline.traffic` from.
+profiles/r03_gemm_traffic.json, the file bench.py reads `roofline.traffic` from (the newest profiles/rNN_gemm_traffic.json).
 
     python tools/pmc_to_traffic.py gpurun_out/r03_gemm_pmc.txt > profiles/r03_gemm_traffic.json
 """
