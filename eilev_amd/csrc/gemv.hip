@@ -10,7 +10,7 @@
 //   fc2 + residual                       -> gemv_rows_kernel<PRO_X>
 //   final_layer_norm + lm_head           -> gemv_rows_kernel<PRO_LN>, fp32 logits
 // Round 2 measured the batch-1 step at 2.64 ms per token: per block 43.6 us of weight streaming and 40 us in seven small kernels, each
-// at its 4.5-6 us launch floor.  The MFMA weight-streaming kernels (gemm.hip) stay for 9 <= M <= 32.
+// at its 4.5-6 us launch floor (profiles/HISTORY.md §5 item 3).  The MFMA weight-streaming kernels (gemm.hip) stay for 9 <= M <= 32.
 //
 // Arithmetic: weights [N, K] row-major bf16; a wave owns output rows; lane l reads 16-byte chunks l, l + 64, ... of the row (1 KiB per
 // load instruction, fully coalesced) and the matching chunks of the M activation rows from LDS (staged once per workgroup, bf16 — the

@@ -48,7 +48,7 @@ class HipEngine:
         self._load(named_tensors)
         if lm_weights != "bf16":
             self._quantize_opt(act_fp8=lm_weights == "fp8_mfma")
-        # LayerNorm folding of the ViT blocks: the folded qkv / fc1 copies (+1.1 GB at ViT-g) are built lazily by the first
+        # LayerNorm folding of the ViT blocks (profiles/HISTORY.md §3f): the folded qkv / fc1 copies (+1.1 GB at ViT-g) are built lazily by the first
         # launch large enough to use them (>= 24576 token rows); vit_ln_fold=False keeps the LayerNorm kernels for every launch
         self.vit_ln_fold = bool(vit_ln_fold)
         self._vit_folded = False

@@ -11,7 +11,7 @@ Everything after the ViT is composed from the autograd-wrapped HIP kernels of ei
 `loss.backward()` runs the gradient kernels of eilev_amd/csrc/backward.hip and leaves `.grad` on the trainable
 parameters exactly as the reference's `accelerator.backward(loss)` does.  Dropout (0.1 in the Q-Former / OPT / T5 configs
 while `model.train()`) is applied at the reference's sites when `TrainGraph(dropout=True)` (the model class does so in train()
-mode), with counter-based masks recomputed in the backward; dropout=False is the deterministic function.
+mode), with counter-based masks recomputed in the backward (profiles/HISTORY.md §5h); dropout=False is the deterministic function.
 """
 from __future__ import annotations
 
