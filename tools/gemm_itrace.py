@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU probe: the eight phase edges of ONE K-step inside the persistent ping-pong GEMM (gemm_pp4_kernel), from a library built with
--DEILEV_PP4_ITRACE=<k-step> (eilev_amd/csrc/build.py --variant itrace -DEILEV_PP4_ITRACE=8).
+-DEILEV_PROBES -DEILEV_PP4_ITRACE=<k-step> (eilev_amd/csrc/build.py --variant itrace -DEILEV_PROBES -DEILEV_PP4_ITRACE=8).
 
     python tools/gemm_itrace.py <lib.so> [fc1_ln|fc2_st|qkv_ln|proj_st|fc2|fc1_noact] [rows]
 
