@@ -55,6 +55,19 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
     const int ncu = eilev_grid_cus() < num_cu ? eilev_grid_cus() : num_cu;
     const int grid = tiles < ncu ? tiles : ncu / 8 * 8;
     if (g.A8 || g.ln_rows || g.stat_out) return launch_pp4_ext(g, grid, s);  // fp8 MFMA / LayerNorm-folding instances (the other object)
+    // 16 x 16 x 32 MFMAs where every tile of the launch is a whole lean tile (gemm_pp4.h: M16)
+    if (pp4_all_lean(g) && g.epi != 1) {
+        static bool attr16 = false;
+        if (!attr16) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr16 = true;
+        }
+        if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, false, 0, 2>), dim3(grid), dim3(512), smem, s, g);
+        else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 0, 2>), dim3(grid), dim3(512), smem, s, g);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     if (g.epi == 1) hipLaunchKernelGGL(gemm_pp4_kernel<1>, dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 2) hipLaunchKernelGGL(gemm_pp4_kernel<2>, dim3(grid), dim3(512), smem, s, g);
     else hipLaunchKernelGGL(gemm_pp4_kernel<0>, dim3(grid), dim3(512), smem, s, g);

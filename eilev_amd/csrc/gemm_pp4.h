@@ -21,8 +21,22 @@ namespace {
 #ifndef EILEV_PP4_DEEP
 #define EILEV_PP4_DEEP 1
 #endif
-template <int EPI, bool F8 = false, int LN = 0>
+// M16 (round 5): the K loop on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 — same fragment bytes, same 128 accumulator registers per
+// lane, 32 MFMAs of 16 cycles per phase instead of 16 of 32.  The chip is POWER-limited under this kernel (~1.0 "MFMA-GHz" whatever the
+// schedule), and on random operands the 16 x 16 form costs less energy per flop: tools/probes/mfma_lds_ceiling.hip, the same ping-pong loop
+// fed from LDS: 1818 vs 1684 TFLOP/s (profiles/r05_mfma_ceiling.log) — it is also what the vendor's kernel uses.  A lane then owns row
+// l15 of every 16-row block and 4 consecutive columns (4 g4 ..) of every 16-column block: acc16[i][j][e] = C[16 i + l15][16 j + 4 g4 + e].
+// Launches whose every tile can take the lean epilogue (the launcher checks: bf16 output, N % 128 == 0, ...): there is no general epilogue
+// in this layout.  A last column tile with only 128 valid columns (N = 1408, 4224): see M16K below (profiles/r05_m16_ab_all_shapes.log,
+// r05_m16_ht_ab.log).
+template <int EPI, bool F8 = false, int LN = 0, int M16K = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
+    // M16K: 0 = 32 x 32 x 16 MFMAs; 1 = 16 x 16 x 32, a half-valid last column tile runs as a WHOLE tile (its W rows past N are not staged:
+    // stale, finite LDS bytes; the waves that own columns >= N skip the epilogue) — no half-tile code in the instance: the folded-LayerNorm
+    // consumers, whose registers are tightest (qkv, N = 4224: 3 % padding, +2.1 %); 2 = 16 x 16 x 32 with the half-tile path (N = 1408: a
+    // whole tile for the half column costs fc2 6 %)
+    constexpr bool M16 = M16K != 0, HT16 = M16K == 2;
+    static_assert(!M16 || !F8, "16 x 16 form: bf16 instances");
     constexpr int BM = 256, BN = 256, NWM = 2, NWN = 4, NW = 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
     constexpr int STEP = (BM + BN) * 128;
@@ -34,6 +48,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / NWN, wn = wid % NWN;
     const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    constexpr int TM16 = WM / 16, TN16 = WN / 16;
     const int ns = g.K / 64;
     const bool late = wid >= NW / 2;
     const int prow = lane >> 3, pslot = lane & 7;
@@ -99,11 +115,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 if (part == 0 || (part == 1) == (i < PC / 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void *)(sd + i * 1024), 16, po[i], st * 128, 0, 0);
         }
     };
-    f32x16 acc[TM][TN];
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
     bf16x8 af[2][TM], bfr[2][TN];
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    f32x4_t acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
     auto read_half = [&](int st, int h) {
         const char *sa = smem + (st & 1) * STEP + (wm * WM) * 128;
         const char *sb = smem + (st & 1) * STEP + BM * 128 + (wn * WN) * 128;
+        if constexpr (M16) {  // one k-slice of 32 per half step: chunk h * 4 + g4 of rows 16 i + l15 (af / bfr reused as flat arrays of 8 / 4)
+            const int kc = h * 4 + g4;
+#pragma unroll
+            for (int j = 0; j < TN16; ++j) {
+                const int row = j * 16 + l15;
+                bfr[j >> 1][j & 1] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < TM16; ++i) {
+                const int row = i * 16 + l15;
+                af[i >> 2][i & 3] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+            }
+            return;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int kc = h * 4 + k2 * 2 + hi;
@@ -135,6 +167,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat32(bfr[0][j], bfr[1][j]), cat32(af[0][i], af[1][i]), acc[i][j],
                                                                                0, 0, 0, 0, 0, 0);
+        } else if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                for (int j = 0; j < TN16; ++j)
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j >> 1][j & 1], af[i >> 2][i & 3], acc16[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
@@ -153,6 +191,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     auto read_half_ht = [&](int st, int h) {
         const char *sa = smem + (st & 1) * STEP + (hm * 64) * 128;
         const char *sb = smem + (st & 1) * STEP + BM * 128 + (hn * 64) * 128;
+        if constexpr (M16) {  // 64 x 64 per wave: 4 + 4 fragments of the one 32-wide k-slice
+            const int kc = h * 4 + g4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 16 + l15;
+                bfr[j >> 1][j & 1] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + swz(row, kc));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + l15;
+                af[0][i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + swz(row, kc));
+            }
+            return;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int kc = h * 4 + k2 * 2 + hi;
@@ -177,6 +229,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat32(bfr[0][j], bfr[1][j]), cat32(af[0][i], af[1][i]), acc[i][j],
                                                                                0, 0, 0, 0, 0, 0);
+        } else if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j >> 1][j & 1], af[0][i], acc16[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
@@ -200,6 +258,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // arithmetic here — was built and makes hipcc spill 200-600 VGPRs in this 256-register kernel: not adopted.)
     char *const stg = smem + 2 * STEP + wid * 4096;
     const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
+    // 16 x 16 layout: the lane's 4 values of block (ib, j) of a unit = row 16 ib + l15, columns 16 j + 4 g4 ..: chunk 2 j + (g4 >> 1), bytes 8 (g4 & 1)
+    const unsigned stg_sw16 = (unsigned)(2 * STEP + wid * 4096 + l15 * 128 + (g4 & 1) * 8) ^ (unsigned)((((g4 >> 1) ^ (l15 & 7)) << 4));
     const int srow = lane >> 3, schunk = lane & 7;
     auto is_lean = [&](int n0_) {
         return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale &&
@@ -207,21 +267,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     };
     // LN == 2 (proj / fc2, residual): the unit also emits the row statistics of what it writes (g.stat_out); LN == 1 (qkv / fc1, no residual):
     // (qkv / fc1) it finishes a folded LayerNorm (g.ln_rows / g.ln_csum): see GemmArgs.
-    float ln_rs[LN == 1 ? TM : 1];  // LN == 1: rstd of the lane's row in each of its units, fetched at the end of the K loop
-    auto lean_epilogue = [&](int cm0, int cn0, auto res_c) {
+    float ln_rs[LN == 1 ? (M16 ? TM16 : TM) : 1];  // LN == 1: rstd of the lane's row in each of its units (M16: 16-row blocks), fetched at the end of the K loop
+    auto lean_epilogue = [&](int cm0, int cn0, auto res_c, auto ht_c) {
         constexpr bool RES = decltype(res_c)::value;
+        constexpr bool HTE = decltype(ht_c)::value;  // M16 only: the half tile's 64 x 64 block of this wave (rows 64 hm .., columns 64 hn ..)
+        constexpr int NU = HTE ? 2 : TM;              // units of 32 rows
+        const int roff = HTE ? hm * 64 : wm * WM, coff = HTE ? hn * 64 : wn * WN;
+        if constexpr (M16K == 1) {
+            if (cn0 + coff >= g.N) return;  // (wave-uniform) this wave's 64 columns do not exist: the half-valid last column tile run whole
+        }
         constexpr bool LNC = LN == 1 && !RES, LNP = LN == 2 && RES;
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-        const int r0 = cm0 + wm * WM;
-        const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < WM ? g.M - r0 : WM);
+        const int r0 = cm0 + roff;
+        const int rows = g.M - r0 < 0 ? 0 : (g.M - r0 < NU * 32 ? g.M - r0 : NU * 32);
         auto uniform_rsrc = [&](const void *ptr, int bytes) {
             const uint64_t base = (uint64_t)ptr;
             const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);  // provably wave-uniform: no waterfall loops
             return __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
         };
-        const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + wn * WN, rows * (int)(g.ldc * 2));
-        const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + cn0 + wn * WN : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
+        const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + coff, rows * (int)(g.ldc * 2));
+        const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + cn0 + coff : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
         const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
         u32x4_t rv[4];
         auto res_load = [&](int u) {
@@ -229,7 +295,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             for (int it = 0; it < 4; ++it) rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, rs_voff, (u * 32 + it * 8) * (int)(g.ldr * 2), 0);
         };
         if constexpr (RES) res_load(0);
-        bf16x4 biasr[TN][4];  // columns j*32 + q*8 + hi*4 + (0..3) of the wave's 64: the accumulator layout
+        bf16x4 biasr[M16 ? 1 : TN][4];  // columns j*32 + q*8 + hi*4 + (0..3) of the wave's 64: the accumulator layout
+        bf16x4 biasr16[M16 ? TN16 : 1];  // M16: columns 16 j + 4 g4 + (0..3)
+        if constexpr (M16) {
+#pragma unroll
+            for (int j = 0; j < TN16; ++j) {
+                if (g.bias) biasr16[j] = *reinterpret_cast<const bf16x4 *>(g.bias + cn0 + coff + j * 16 + g4 * 4);
+                else biasr16[j] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -237,20 +311,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 if (g.bias) biasr[j][q] = *reinterpret_cast<const bf16x4 *>(g.bias + cn0 + wn * WN + j * 32 + q * 8 + hi * 4);
                 else biasr[j][q] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             }
+        }
         typedef __attribute__((ext_vector_type(2))) float f32x2_t;
         __amdgpu_buffer_rsrc_t rst = rr;
-        if constexpr (LNP) rst = uniform_rsrc(g.stat_out + ((int64_t)((cn0 + wn * WN) >> 6) * g.stat_ld + r0) * 2, rows * 8);
-        static_for<TM>([&](auto u_c) {
+        if constexpr (LNP) rst = uniform_rsrc(g.stat_out + ((int64_t)((cn0 + coff) >> 6) * g.stat_ld + r0) * 2, rows * 8);
+        static_for<NU>([&](auto u_c) {
             constexpr int U = decltype(u_c)::value;
             float st1 = 0.0f, st2 = 0.0f;
-            bf16x4 rcell[TN][4];
+            bf16x4 rcell[M16 ? 2 : TN][4];  // (M16: [ib][j])
             if constexpr (RES) {  // the unit's residual rows -> staging (coalesced); every lane then fetches its 8 cells in one batch
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + srow;
                     *reinterpret_cast<u32x4_t *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4)) = rv[it];
                 }
-                if constexpr (U + 1 < TM) res_load(U + 1);  // the next unit's rows arrive under this unit's arithmetic
+                if constexpr (U + 1 < NU) res_load(U + 1);  // the next unit's rows arrive under this unit's arithmetic
+                if constexpr (M16) {
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                        for (int j = 0; j < TN16; ++j) {
+                            unsigned ca;
+                            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(((j * 2) << 4) | (ib << 11)), "v"(stg_sw16));
+                            rcell[ib][j] = *reinterpret_cast<const bf16x4 *>(smem + ca);
+                        }
+                } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -259,7 +344,43 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
                         rcell[j][q] = *reinterpret_cast<const bf16x4 *>(smem + ca);
                     }
+                }
             }
+            float st16[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};  // M16 + LNP: (sum, sum of squares) of the lane's 16 values of row 16 ib + l15
+            if constexpr (M16) {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) {
+                        float v[4];
+                        if constexpr (LNC) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc16[2 * U + ib][j][e], ln_rs[2 * U + ib], (float)biasr16[j][e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc16[2 * U + ib][j][e] + (float)biasr16[j][e];
+                        }
+                        if constexpr (EPI == 2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                        }
+                        if constexpr (EPI == 1) gelu_erf_n<4>(v);
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rcell[ib][j][e];
+                        }
+                        if constexpr (LNP) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                st16[ib][0] += v[e];
+                                st16[ib][1] = fmaf(v[e], v[e], st16[ib][1]);
+                            }
+                        }
+                        unsigned ca;
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"(((j * 2) << 4) | (ib << 11)), "v"(stg_sw16));
+                        *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    }
+            } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -292,7 +413,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ca) : "n"((j * 4 + q) << 4), "v"(stg_sw));
                     *reinterpret_cast<bf16x4 *>(smem + ca) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 }
-            if constexpr (LNP) {  // the two lane halves hold the two column halves of a row
+            }
+            if constexpr (LNP && M16) {  // the four lane quarters (g4) hold the four column quarters of a row: fixed summation order
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    float a1 = st16[ib][0], a2 = st16[ib][1];
+                    a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+                    a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                    const f32x2_t t = (f32x2_t){a1, a2};
+                    if (g4 == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, t), rst, (U * 32 + ib * 16 + l15) * 8, 0, 0);
+                }
+            } else if constexpr (LNP) {  // the two lane halves hold the two column halves of a row
                 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                 const f32x2_t t = (f32x2_t){st1 + __shfl_xor(st1, 32), st2 + __shfl_xor(st2, 32)};
                 if (hi == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, t), rst, (U * 32 + l31) * 8, 0, 0);
@@ -341,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     stage_step(0, w_piece_mine(n0));
     bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
-    bool lean_cur = is_lean(n0);  // this tile runs the lean epilogue: its accumulators start from the bias
+    bool lean_cur = M16 || is_lean(n0);  // this tile runs the lean epilogue (M16: every tile does)
     // folded LayerNorm (LN == 1): C = rstd * (A . W^T - mean * csum) + bias.  The rank-1 term -mean[m] * csum[n] is one more K-slice on
     // the matrix cores: the tile's first MFMA of every 32 x 32 block multiplies (csum_hi, csum_lo, csum_hi, 0 ...) by (nm_hi, nm_hi,
     // nm_lo, 0 ...) with nm = -mean (v_mfma_f32_32x32x8_bf16_1k: half the cost of the K = 16 form) — two bf16 pieces each, the product is good to 2^-16 of |mean * csum|, far inside the bf16 output —
@@ -349,9 +481,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // VALU operations, 6 four-byte loads per lane fetched one tile AHEAD next to the next tile's first DMA (rows past M / columns past N
     // read 0).  (Built and measured before this: accumulators initialised with v_mul from 32 csum registers per lane — 36 loads per
     // lane and tile through the texture addresser and 128 VALU operations in a read phase: fc1 +4.5 %.)
-    float ln_nm[LN == 1 ? TM : 1], ln_cl[LN == 1 ? TN : 1];
+    float ln_nm[LN == 1 ? (M16 ? TM16 : TM) : 1], ln_cl[LN == 1 ? (M16 ? TN16 : TN) : 1];
     auto ln_fetch = [&](int m0_, int n0_) {
-        if constexpr (LN == 1) {
+        if constexpr (LN == 1 && M16) {  // the lane's rows 16 i + l15 and columns 16 j + l15 (the operand layout of the 16 x 16 MFMA)
+            const bool ht = HT16 && n0_ + 128 >= g.N;
+            const int mb = m0_ + (ht ? hm * 64 : wm * WM) + l15, nb = n0_ + (ht ? hn * 64 : wn * WN) + l15;
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rcs = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_csum, 0, g.N * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM16; ++i) ln_nm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (mb + i * 16) * 8 + 4, 0, 0));
+#pragma unroll
+            for (int j = 0; j < TN16; ++j) ln_cl[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rcs, (nb + j * 16) * 4, 0, 0));
+        } else if constexpr (LN == 1) {
             const bool ht = n0_ + 128 >= g.N && !(g.dbg & 524288);
             const int mb = m0_ + (ht ? hm * 64 : wm * WM) + l31, nb = n0_ + (ht ? hn * 64 : wn * WN) + l31;
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);
@@ -390,9 +531,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         stamp(0);
         stamp(5, true);
         typedef __attribute__((ext_vector_type(4))) short s16x4_t;  // operand type of the K = 8 bf16 MFMA
-        s16x4_t ln_a1[LN == 1 ? TM : 1], ln_w1[LN == 1 ? TN : 1];
+        s16x4_t ln_a1[LN == 1 ? (M16 ? TM16 : TM) : 1], ln_w1[LN == 1 ? (M16 ? TN16 : TN) : 1];
         auto acc_prep = [&]() {  // the two fragments of the rank-1 K-slice (in a read phase)
-            if constexpr (LN == 1) {
+            if constexpr (LN == 1 && M16) {  // v_mfma_f32_16x16x16_bf16: k-slots 4 g4 .. 4 g4 + 3; the values sit in the lanes g4 == 0
+                const bf16 z = (bf16)0.0f;
+#pragma unroll
+                for (int i = 0; i < TM16; ++i) {
+                    const float m = g4 ? 0.0f : ln_nm[i];
+                    const bf16 mh = (bf16)m, ml = (bf16)(m - (float)mh);
+                    ln_a1[i] = __builtin_bit_cast(s16x4_t, (bf16x4){mh, mh, ml, z});
+                }
+#pragma unroll
+                for (int j = 0; j < TN16; ++j) {
+                    const float c = g4 ? 0.0f : ln_cl[j];
+                    const bf16 ch = (bf16)c, cl = (bf16)(c - (float)ch);
+                    ln_w1[j] = __builtin_bit_cast(s16x4_t, (bf16x4){ch, cl, ch, z});
+                }
+            } else if constexpr (LN == 1) {
                 const bf16 z = (bf16)0.0f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -409,7 +564,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             }
         };
         auto acc_init = [&]() {
-            if constexpr (LN == 1) {
+            if constexpr (M16) {
+                const f32x4_t zero4 = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) {
+                        if constexpr (LN == 1) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ln_w1[j], ln_a1[i], zero4, 0, 0, 0);
+                        else acc16[i][j] = zero4;
+                    }
+            } else if constexpr (LN == 1) {
                 f32x16 zero;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
@@ -508,9 +672,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             PP_BARRIER();
 #endif
         };
-        if (half_tile) {
-            kstep(0, std::true_type{}, std::true_type{});
-            for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::true_type{});
+        if (half_tile && M16K != 1) {
+            if constexpr (M16K != 1) {
+                kstep(0, std::true_type{}, std::true_type{});
+                for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::true_type{});
+            }
         } else {
             kstep(0, std::true_type{}, std::false_type{});
             for (int st = 1; st < nsd; ++st) kstep(st, std::false_type{}, std::false_type{});
@@ -526,8 +692,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         if (!late) PP_BARRIER();
         if constexpr (LN == 1) {  // rstd of the lane's rows for the epilogue: issued BEFORE the next tile's DMA (retire in order)
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)g.ln_rows, 0, g.M * 8, 0x00020000);
+            if constexpr (M16) {
+#pragma unroll
+                for (int i = 0; i < TM16; ++i) ln_rs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (m0 + ((HT16 && half_tile) ? hm * 64 : wm * WM) + i * 16 + l15) * 8, 0, 0));
+            } else {
 #pragma unroll
             for (int u = 0; u < TM; ++u) ln_rs[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (m0 + wm * WM + u * 32 + l31) * 8, 0, 0));
+            }
         }
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
@@ -540,20 +711,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             stage_step(0, w_piece_mine(n0));
             pre1 = lean && ns > 1;
             if (pre1) stage_step(1, w_piece_mine(n0));
-            lean_cur = is_lean(n0);
+            lean_cur = M16 || is_lean(n0);
             ln_fetch(m0, n0);
         }
         stamp(3);
-        if (lean) {  // LN kernels: the launcher guarantees ln_rows and no residual (1), stat_out and a residual (2)
-            if constexpr (LN == 1) lean_epilogue(cm0, cn0, std::false_type{});
-            else if constexpr (LN == 2) lean_epilogue(cm0, cn0, std::true_type{});
-            else if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{});
-            else lean_epilogue(cm0, cn0, std::false_type{});
-        } else if (half_tile) {
-            gemm_epilogue<64, 64, EPI, 0, 2, LN, true>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
-        } else {
-            gemm_epilogue<WM, WN, EPI, 0, TM / 2, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
-            gemm_epilogue<WM, WN, EPI, TM / 2, TM, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+        if (HT16 && half_tile) {  // the wave's 64 x 64 block of the half tile, same lean epilogue
+            if constexpr (HT16) {
+                if constexpr (LN == 1) lean_epilogue(cm0, cn0, std::false_type{}, std::true_type{});
+                else if constexpr (LN == 2) lean_epilogue(cm0, cn0, std::true_type{}, std::true_type{});
+                else if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{}, std::true_type{});
+                else lean_epilogue(cm0, cn0, std::false_type{}, std::true_type{});
+            }
+        } else if (lean || M16) {  // LN kernels: the launcher guarantees ln_rows and no residual (1), stat_out and a residual (2); M16: lean tiles only
+            if constexpr (LN == 1) lean_epilogue(cm0, cn0, std::false_type{}, std::false_type{});
+            else if constexpr (LN == 2) lean_epilogue(cm0, cn0, std::true_type{}, std::false_type{});
+            else if (g.resid != nullptr) lean_epilogue(cm0, cn0, std::true_type{}, std::false_type{});
+            else lean_epilogue(cm0, cn0, std::false_type{}, std::false_type{});
+        } else if constexpr (!M16) {
+            if (half_tile) {
+                gemm_epilogue<64, 64, EPI, 0, 2, LN, true>(g, reinterpret_cast<f32x16(&)[2][2]>(acc), smem + STEP, cm0, cn0, hm, hn, wid, lane);
+            } else {
+                gemm_epilogue<WM, WN, EPI, 0, TM / 2, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+                gemm_epilogue<WM, WN, EPI, TM / 2, TM, LN, true>(g, acc, smem + STEP, cm0, cn0, wm, wn, wid, lane);
+            }
         }
         stamp(4);
         stamp(6, true);

@@ -33,6 +33,28 @@ int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s) {
     if (g.epi == 2 || g.out_f32 || (g.ln_rows && (g.resid || g.stat_out || !g.ln_csum || ((uintptr_t)g.ln_csum & 15) || ((uintptr_t)g.ln_rows & 7))) ||
         (g.stat_out && (!g.resid || g.epi != 0 || g.stat_ld < g.M || ((uintptr_t)g.stat_out & 7))))
         return EILEV_E_UNSUPPORTED;
+    if (g.stat_out && pp4_all_lean(g)) {  // statistics producers (ViT proj / fc2)
+        static bool attr16s = false;
+        if (!attr16s) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr16s = true;
+        }
+        hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 2, 2>), dim3(grid), dim3(512), smem, s, g);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
+    if (g.ln_rows && pp4_all_lean(g)) {  // folded-LayerNorm consumers (ViT qkv / fc1)
+        static bool attr16 = false;
+        if (!attr16) {
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<1, false, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr16 = true;
+        }
+        if (g.epi == 1) hipLaunchKernelGGL((gemm_pp4_kernel<1, false, 1, 1>), dim3(grid), dim3(512), smem, s, g);
+        else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 1, 1>), dim3(grid), dim3(512), smem, s, g);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     if (g.stat_out) hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 2>), dim3(grid), dim3(512), smem, s, g);
     else if (g.epi == 1) hipLaunchKernelGGL((gemm_pp4_kernel<1, false, 1>), dim3(grid), dim3(512), smem, s, g);
     else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 1>), dim3(grid), dim3(512), smem, s, g);

@@ -53,6 +53,41 @@ __global__ __launch_bounds__(512, 2) void k8(const char *src, float *out, int it
   out[blockIdx.x * 512 + tid] = s;
 }
 
+// round 5: the same 8-wave ping-pong loop (same LDS bytes, same flops, same 128 accumulator registers) on v_mfma_f32_16x16x32_bf16:
+// 32 MFMAs of 16 cycles per phase instead of 16 of 32 cycles — is the power-limited rate different?
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ __launch_bounds__(512, 2) void k8b(const char *src, float *out, int iters, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  fill(smem, src, tid, 512);
+  f32x4 c[8][4];
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) c[i][j][e] = 0.f;
+  const bool late = wid >= 4;
+  if ((mode & 1) && late) __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < iters; ++it) {
+    const char *base = smem + (it & 3) * 32768 + (wid & 1) * 8192;
+    bf16x8 a[8], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int row = j * 16 + l15; b[j] = *reinterpret_cast<const bf16x8 *>(base + 16384 + row * 64 + ((g4 ^ ((row >> 2) & 3)) << 4)); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int row = i * 16 + l15; a[i] = *reinterpret_cast<const bf16x8 *>(base + row * 64 + ((g4 ^ ((row >> 2) & 3)) << 4)); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (mode & 1) { SB(); __builtin_amdgcn_s_barrier(); SB(); }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], c[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (mode & 1) { SB(); __builtin_amdgcn_s_barrier(); SB(); }
+  }
+  if ((mode & 1) && !late) __builtin_amdgcn_s_barrier();
+  float s = 0;
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) s += c[i][j][1];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
 __global__ __launch_bounds__(256, 1) void k4(const char *src, float *out, int iters, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,6 +125,7 @@ int main() {
   static unsigned short h[65536];
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8b), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   for (int dist = 0; dist < 3; ++dist) {
     for (int i = 0; i < 65536; ++i) {
       float f;
@@ -101,19 +137,21 @@ int main() {
     (void)hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
     const char *dn = dist == 0 ? "zeros" : (dist == 1 ? "uniform[-1,1]" : "normal(0,1)");
     for (int mode = 0; mode < 2; ++mode) {
-      for (int which = 0; which < 2; ++which) {
+      for (int which = 0; which < 3; ++which) {
         const int iters = 20000, blocks = 256;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         if (which == 0) hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 131072, 0, d, o, 200, mode);
+        else if (which == 2) hipLaunchKernelGGL(k8b, dim3(blocks), dim3(512), 131072, 0, d, o, 200, mode);
         else hipLaunchKernelGGL(k4, dim3(blocks), dim3(256), 131072, 0, d, o, 100, mode);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 131072, 0, d, o, iters, mode);
+        else if (which == 2) hipLaunchKernelGGL(k8b, dim3(blocks), dim3(512), 131072, 0, d, o, iters, mode);
         else hipLaunchKernelGGL(k4, dim3(blocks), dim3(256), 131072, 0, d, o, iters / 2, mode);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        const double fl = which == 0 ? (double)blocks * 8 * iters * 16 * 32768.0 : (double)blocks * 4 * (iters / 2) * 64 * 32768.0;
-        printf("%-14s %s %s: %.0f TFLOP/s\n", dn, which == 0 ? "8 waves x 128x64 " : "4 waves x 128x128", mode ? (which == 0 ? "ping-pong barriers" : "barrier per K-step ") : "free-running      ", fl / ms / 1e9);
+        const double fl = which != 1 ? (double)blocks * 8 * iters * 16 * 32768.0 : (double)blocks * 4 * (iters / 2) * 64 * 32768.0;
+        printf("%-14s %s %s: %.0f TFLOP/s\n", dn, which == 0 ? "8 waves x 128x64 (32x32x16)" : which == 2 ? "8 waves x 128x64 (16x16x32)" : "4 waves x 128x128 (32x32x16)", mode ? (which != 1 ? "ping-pong barriers" : "barrier per K-step ") : "free-running      ", fl / ms / 1e9);
       }
     }
   }
