@@ -626,7 +626,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #ifndef EILEV_PP4_SPLIT
 #define EILEV_PP4_SPLIT 3
 #endif
-            constexpr bool SPLIT_OK = !HT && !(LN == 1 && EPI == 0);
+#ifndef EILEV_PP4_SPLIT_QKV
+#define EILEV_PP4_SPLIT_QKV 0
+#endif
+            constexpr bool SPLIT_OK = !HT && (EILEV_PP4_SPLIT_QKV || !(LN == 1 && EPI == 0));
             constexpr bool SPLIT_E = (EILEV_PP4_SPLIT & 1) && SPLIT_OK, SPLIT_L = (EILEV_PP4_SPLIT & 2) && SPLIT_OK;
             if (!late) {
                 if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, SPLIT_E ? 1 : 0);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512, 2) void k8(const char *src, float *out, int it
 // round 5: the same 8-wave ping-pong loop (same LDS bytes, same flops, same 128 accumulator registers) on v_mfma_f32_16x16x32_bf16:
 // 32 MFMAs of 16 cycles per phase instead of 16 of 32 cycles — is the power-limited rate different?
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int ORD>
 __global__ __launch_bounds__(512, 2) void k8b(const char *src, float *out, int iters, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,10 +76,22 @@ __global__ __launch_bounds__(512, 2) void k8b(const char *src, float *out, int i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (mode & 1) { SB(); __builtin_amdgcn_s_barrier(); SB(); }
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (ORD == 1) {  // W fragment stationary across 8 consecutive MFMAs
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], c[i][j], 0, 0, 0);
+    } else if constexpr (ORD == 2) {  // operands swapped (A first)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], c[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], c[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     if (mode & 1) { SB(); __builtin_amdgcn_s_barrier(); SB(); }
   }
@@ -125,7 +138,7 @@ int main() {
   static unsigned short h[65536];
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8b), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8b<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   for (int dist = 0; dist < 3; ++dist) {
     for (int i = 0; i < 65536; ++i) {
       float f;
@@ -141,12 +154,12 @@ int main() {
         const int iters = 20000, blocks = 256;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         if (which == 0) hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 131072, 0, d, o, 200, mode);
-        else if (which == 2) hipLaunchKernelGGL(k8b, dim3(blocks), dim3(512), 131072, 0, d, o, 200, mode);
+        else if (which == 2) hipLaunchKernelGGL(k8b<0>, dim3(blocks), dim3(512), 131072, 0, d, o, 200, mode);
         else hipLaunchKernelGGL(k4, dim3(blocks), dim3(256), 131072, 0, d, o, 100, mode);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 131072, 0, d, o, iters, mode);
-        else if (which == 2) hipLaunchKernelGGL(k8b, dim3(blocks), dim3(512), 131072, 0, d, o, iters, mode);
+        else if (which == 2) hipLaunchKernelGGL(k8b<0>, dim3(blocks), dim3(512), 131072, 0, d, o, iters, mode);
         else hipLaunchKernelGGL(k4, dim3(blocks), dim3(256), 131072, 0, d, o, iters / 2, mode);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -154,6 +167,25 @@ int main() {
         printf("%-14s %s %s: %.0f TFLOP/s\n", dn, which == 0 ? "8 waves x 128x64 (32x32x16)" : which == 2 ? "8 waves x 128x64 (16x16x32)" : "4 waves x 128x128 (32x32x16)", mode ? (which != 1 ? "ping-pong barriers" : "barrier per K-step ") : "free-running      ", fl / ms / 1e9);
       }
     }
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8b<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k8b<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (int ord = 0; ord < 3; ++ord) {
+    const int iters = 20000, blocks = 256;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto go = [&](int it) {
+      if (ord == 0) hipLaunchKernelGGL(k8b<0>, dim3(blocks), dim3(512), 131072, 0, d, o, it, 1);
+      else if (ord == 1) hipLaunchKernelGGL(k8b<1>, dim3(blocks), dim3(512), 131072, 0, d, o, it, 1);
+      else hipLaunchKernelGGL(k8b<2>, dim3(blocks), dim3(512), 131072, 0, d, o, it, 1);
+    };
+    go(200);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    go(iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("normal(0,1) 16x16x32 ping-pong, MFMA order %d (0: A-fragment outer, 1: W-fragment outer, 2: operands swapped): %.0f TFLOP/s\n", ord,
+           (double)blocks * 8 * iters * 16 * 32768.0 / ms / 1e9);
   }
   return 0;
 }
