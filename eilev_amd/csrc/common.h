@@ -225,7 +225,9 @@ int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm_pp4_ext.hip
 // every tile of a persistent-kernel launch can take the lean epilogue (what the 16 x 16 MFMA instances need: gemm_pp4.h M16)
 static inline bool pp4_all_lean(const GemmArgs &g) {
-    return g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale && !g.dbg && !g.trace;
+    // (column scaling — the q part of a fused q|k|v projection — only on plain bias-only launches, in whole 16-column blocks)
+    const bool scale_ok = g.scale_cols == 0 || (g.scale_cols % 16 == 0 && g.epi == 0 && !g.resid && !g.ln_rows && !g.stat_out);
+    return g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && scale_ok && !g.wscale && !g.ascale && !g.dbg && !g.trace;
 }
 // gemv.hip: nn.Linear on M <= 8 rows as row dot products with the LayerNorm / flash-decoding merge in its prologue
 bool gemv_rows_ok(int M, int N, int K);

@@ -360,6 +360,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = acc16[2 * U + ib][j][e] + (float)biasr16[j][e];
                         }
+                        if constexpr (LN == 0 && EPI == 0 && !RES) {  // q pre-scaling of the fused q|k|v projection: (x W^T + b) * scale on the first
+                            if (cn0 + coff + j * 16 < g.scale_cols) {   // scale_cols columns (a multiple of 16: whole blocks, wave-uniform)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] *= g.scale;
+                            }
+                        }
                         if constexpr (EPI == 2) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
