@@ -127,6 +127,30 @@ def test_vit_bench_launch_equals_small_launches():
     assert worst <= 4e-3
 
 
+def test_prefill_bench_launch_equals_small_launches():
+    """The OPT prefill at the bench's launch shape (32 samples x 960 tokens = 30 720 rows: every linear on the persistent 16 x 16 MFMA kernel,
+    the fused q|k|v with its q pre-scaling in the lean epilogue, relu, residuals) against the same rows prefilled alone (960 rows: the
+    one-wave-per-SIMD kernel with the general epilogue), one block at the real widths; rows 1 and 17 are left-padded.  Both are bf16 paths
+    of the same arithmetic: logits agree to bf16 rounding, the argmax exactly where the margin allows."""
+    cfg, _, eng = models("real_1l")
+    B, L, D = 32, 960, cfg.text_config.hidden_size
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    emb = (0.5 * torch.randn((B, L, D), device="cuda", generator=g)).to(torch.bfloat16)
+    am = torch.ones((B, L), dtype=torch.int64, device="cuda")
+    am[1, :300] = 0
+    am[17, :7] = 0
+    big, _, _ = eng.prefill(emb, am)
+    worst = 0.0
+    for b in (0, 1, 17, 31):
+        small, _, _ = eng.prefill(emb[b:b + 1], am[b:b + 1])
+        x, y = host(big[b:b + 1]), host(small)
+        worst = max(worst, rel_rms(x, y))
+        assert np.abs(x - y).max() <= 2.0 ** -6 * max(1.0, float(np.abs(y).max())), b
+    record_parity("prefill_bench_launch", relrms_vs_single_sample=worst)
+    assert worst <= 4e-3
+
+
 def test_real_width_t5_path(golden_dir):
     """BASELINE configs[3] at its real widths (flan-t5-xl, one block per stack): encoder output and logits vs the reference fixture,
     judged like the OPT path; greedy ids equal to the reference's fp32 or bf16 run."""
