@@ -696,7 +696,7 @@ def main():
                              sharded["first_logits_rel_rms_max"] < 2e-2 and sharded["first_token_equal_or_near_tie_min"] == 1.0)
 
     # dominant kernel: the ViT GEMM family, timed with hipEvents on the launch stream during the timed region
-    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [gemm_pp4_kernel<1>, M x 6144 x 1408, M = 257 tokens x 1088 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
+    kinds = {1: "gemm_nt ViT fc1 (+bias+GELU) [gemm_pp4_kernel<1, false, 1, 1>: folded LayerNorm, 16x16x32 MFMAs; M x 6144 x 1408, M = 257 tokens x 1088 frames]", 2: "gemm_nt ViT fc2 (+bias+residual) [M x 1408 x 6144]",
              3: "gemm_nt ViT qkv (+bias) [M x 4224 x 1408]", 4: "gemm_nt ViT proj (+bias+residual) [M x 1408 x 1408]"}
     best = None
     tot_ms = 0.0
