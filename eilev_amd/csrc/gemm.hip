@@ -87,6 +87,7 @@ int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
     const int rc = launch_gemm_core(g, prof_kind, s, &ln_done);
     if (rc != EILEV_OK || !g.ln_out || ln_done || g.M <= 0) return rc;
     if (g.out_f32 || g.patch_group) return EILEV_E_UNSUPPORTED;
+    if (!g.ln_beta) return launch_rmsnorm(reinterpret_cast<const bf16 *>(g.C), g.ldc, g.ln_gamma, g.ln_out, g.N, g.M, g.N, g.ln_eps, s);  // T5: RMS
     return launch_layernorm(reinterpret_cast<const bf16 *>(g.C), g.ldc, g.ln_gamma, g.ln_beta, g.ln_out, g.N, g.M, g.N, g.ln_eps, s);
 }
 

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
         if (bias) unpack8(*reinterpret_cast<const bf16x8 *>(bias + c * 8), bv);
         if (resid) unpack8(*reinterpret_cast<const bf16x8 *>(resid + (int64_t)row * ldr + c * 8), rv);
         unpack8(*reinterpret_cast<const bf16x8 *>(gamma + c * 8), gv);
-        unpack8(*reinterpret_cast<const bf16x8 *>(beta + c * 8), bt);
+        if (beta) unpack8(*reinterpret_cast<const bf16x8 *>(beta + c * 8), bt);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float x = t[e];
@@ -219,6 +219,26 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
         const bf16x8 o = pack8(t);
         *reinterpret_cast<bf16x8 *>(C + (int64_t)row * ldc + c * 8) = o;
         unpack8(o, t);  // statistics over the ROUNDED row, like the LayerNorm kernel that read it back
+    }
+    if (beta == nullptr) {  // RMS form (T5LayerNorm, hf modeling_t5.py:50-72): y = gamma * bf16(x * rsqrt(mean(x^2) + eps)), no mean, no beta —
+        float ss = 0.0f;    // round 5: the three RMSNorms of a flan-t5 decoder block ride on the split-K reduces in front of them
+        if (on) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(t[e], t[e], ss);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[0][wid] = ss;
+        __syncthreads();
+        float tot2 = 0.0f;
+        for (int w = 0; w < nw; ++w) tot2 += red[0][w];
+        const float rs = rsqrtf(tot2 / (float)N + eps);
+        if (on) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gv[e] * (float)(bf16)(t[e] * rs);
+            *reinterpret_cast<bf16x8 *>(y + (int64_t)row * N + c * 8) = pack8(o);
+        }
+        return;
     }
     float s1 = 0.0f;
 #pragma unroll
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
 
 int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
                      int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s) {
-    if (!part || !C || !gamma || !beta || !ln_out || M <= 0 || (N & 7) || N > 8 * 512) return EILEV_E_UNSUPPORTED;
+    if (!part || !C || !gamma || !ln_out || M <= 0 || (N & 7) || N > 8 * 512) return EILEV_E_UNSUPPORTED;  // beta == nullptr: the RMS form
     {
         const int threads = (((N >> 3) + 63) / 64) * 64;
 #define EILEV_RLW(KS_) hipLaunchKernelGGL((reduce_ln_wg_kernel<KS_>), dim3(M), dim3(threads), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)

@@ -1205,12 +1205,16 @@ int t5_proj(const T5Bufs &b, const bf16 *x, int D, const void *w0, const void *w
     return EILEV_OK;
 }
 // h += wo(gelu_new(wi_0 x) * wi_1 x) with x = rmsnorm(h)   [T5LayerFF :126-141, T5DenseGatedActDense :97-124]
-int t5_ff(const EilevT5Dims *d, const EilevT5Layer *L, const T5Bufs &b, int64_t M, hipStream_t s) {
+// normed_in: b.x already holds RMSNorm_ff(h) (written by the reduce of the GEMV before); next_ln: the RMSNorm weight whose output of the new h
+// the wo GEMV's reduce should leave in b.x (decode steps: see t5_decode_impl)
+int t5_ff(const EilevT5Dims *d, const EilevT5Layer *L, const T5Bufs &b, int64_t M, hipStream_t s, bool normed_in = false, const void *next_ln = nullptr) {
     const int D = d->d_model, F = d->d_ff;
-    RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ff, b.x, D, M, D, d->eps, s));
+    if (!normed_in) RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ff, b.x, D, M, D, d->eps, s));
     RC(t5_proj(b, b.x, D, L->wi0_w, L->wi1_w, nullptr, F, b.ff, 2 * F, M, s));
     RC(launch_gated_gelu(b.ff, 2 * F, b.gate, M, F, s));
-    return launch_gemm(t5_gemm(b, b.gate, F, L->wo_w, F, b.h, D, b.h, D, M, D, F), 5, s);
+    GemmArgs g = t5_gemm(b, b.gate, F, L->wo_w, F, b.h, D, b.h, D, M, D, F);
+    if (next_ln) { g.ln_gamma = (const bf16 *)next_ln; g.ln_beta = nullptr; g.ln_out = b.x; g.ln_eps = d->eps; }
+    return launch_gemm(g, 5, s);
 }
 }  // namespace
 
@@ -1328,13 +1332,16 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
     const bool single = new_len == 1 && attn_decode_scratch_bytes((int)batch, H, hd, (int)kmax) <= kSkinnyScratch / 2;
     if (state && !single) return EILEV_E_UNSUPPORTED;
     const size_t hid_bytes = (size_t)M * D * sizeof(bf16);
+    const bool fuse_norm = single && M <= 32 && !hidden_out;  // the weight-streaming GEMVs of a decode step (their reduce can carry a norm)
     for (int l = 0; l < d->dec_layers; ++l) {
         const EilevT5Layer *L = &w->dec_layers[l];
         bf16 *kc = (bf16 *)self_kv + 2 * (size_t)l * splane, *vc = kc + splane;
         const bf16 *ck = (const bf16 *)cross_kv + 2 * (size_t)l * cplane, *cv = ck + cplane;
         if (hidden_out) EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + l * hid_bytes, b.h, hid_bytes, hipMemcpyDeviceToDevice, s));
         // ---- self-attention against the cache (T5LayerSelfAttention :372-401)
-        RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
+        // (decode steps, round 5: the RMSNorm in front of every projection is produced by the residual GEMV before it — its split-K reduce
+        //  writes h and RMSNorm(h) in one launch (GemmArgs::ln_out with ln_beta == nullptr) — so only block 0 normalises here)
+        if (!fuse_norm || l == 0) RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
         RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
         RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
@@ -1358,9 +1365,13 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
             a.rel_tab = b.rel; a.rel_hs = total; a.rel_off = (int)total - 1; a.rel_n = (int)total;
             RC(launch_attention(a, s));
         }
-        RC(launch_gemm(t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I), 5, s));
+        {
+            GemmArgs go = t5_gemm(b, b.att, I, L->o_w, I, b.h, D, b.h, D, M, D, I);
+            if (fuse_norm) { go.ln_gamma = (const bf16 *)L->ln_ca; go.ln_beta = nullptr; go.ln_out = b.x; go.ln_eps = d->eps; }
+            RC(launch_gemm(go, 5, s));
+        }
         // ---- cross-attention over the encoder output (T5LayerCrossAttention :404-432): no position bias, padding mask
-        RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ca, b.x, D, M, D, d->eps, s));
+        if (!fuse_norm) RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_ca, b.x, D, M, D, d->eps, s));
         RC(launch_gemm(t5_gemm(b, b.x, D, L->cq_w, D, nullptr, 0, b.qkv, I, M, I, D), 5, s));
         if (single) {
             RC(launch_attn_decode(b.qkv, ck, cv, b.att, enc_mask, nullptr, (int)batch, (int)enc_len, (int)enc_len, H, hd, b.scratch + skinny_f,
@@ -1376,10 +1387,14 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
             c.key_mask = enc_mask; c.mask_ld = enc_len; c.dbg = 0;
             RC(launch_attention(c, s));
         }
-        RC(launch_gemm(t5_gemm(b, b.att, I, L->co_w, I, b.h, D, b.h, D, M, D, I), 5, s));
-        RC(t5_ff(d, L, b, M, s));
+        {
+            GemmArgs gc = t5_gemm(b, b.att, I, L->co_w, I, b.h, D, b.h, D, M, D, I);
+            if (fuse_norm) { gc.ln_gamma = (const bf16 *)L->ln_ff; gc.ln_beta = nullptr; gc.ln_out = b.x; gc.ln_eps = d->eps; }
+            RC(launch_gemm(gc, 5, s));
+        }
+        RC(t5_ff(d, L, b, M, s, fuse_norm, fuse_norm ? (l + 1 < d->dec_layers ? w->dec_layers[l + 1].ln_sa : w->dec_final_ln) : nullptr));
     }
-    RC(launch_rmsnorm(b.h, D, (const bf16 *)w->dec_final_ln, b.x, D, M, D, d->eps, s));
+    if (!fuse_norm) RC(launch_rmsnorm(b.h, D, (const bf16 *)w->dec_final_ln, b.x, D, M, D, d->eps, s));
     if (hidden_out) EILEV_HIP_CHECK(hipMemcpyAsync((char *)hidden_out + d->dec_layers * hid_bytes, b.x, hid_bytes, hipMemcpyDeviceToDevice, s));
     GemmArgs g = t5_gemm(b, b.x, D, w->lm_head, D, nullptr, 0, logits, d->vocab, M, d->vocab, D);
     g.out_f32 = 1;
