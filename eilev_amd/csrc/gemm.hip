@@ -177,7 +177,9 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
         } else if (g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32)) {
             // round 4 (gemm_rows32_kernel): one workgroup per CU, the 32 rows loaded once per CU.  probe flag 1 << 28: the kernels below
-            const int grid_x = nb < skinny_n_cu() ? nb : skinny_n_cu();
+            // (the kernel deals the N weight rows over grid_x workgroups row by row; with a K split the grid is still one workgroup per CU)
+            const int cus = ks > 1 ? std::max(1, skinny_n_cu() / ks) : skinny_n_cu();
+            const int grid_x = nb < cus ? nb : cus;
             if (ks32 == 10) hipLaunchKernelGGL((gemm_rows32_kernel<2, 10, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else if (ks32 == 8) hipLaunchKernelGGL((gemm_rows32_kernel<2, 8, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((gemm_rows32_kernel<2, 5, 4>), dim3(grid_x, ks), dim3(512), 0, s, a);

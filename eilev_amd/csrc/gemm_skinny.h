@@ -356,31 +356,37 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
-    const int nb = (g.N + 15) / 16;
     const int G = gridDim.x;
-    // this CU's blocks of K split blockIdx.y: [b0, b1)
-    const int per = nb / G, rem = nb % G;
-    const int b0 = blockIdx.x * per + min((int)blockIdx.x, rem), b1 = b0 + per + ((int)blockIdx.x < rem ? 1 : 0);
-    const int nblk = b1 - b0;
+    // this CU's weight ROWS of K split blockIdx.y: [r0, r1) — N dealt row by row (round 5), not in 16-row blocks: fc1's 640 blocks on 256 CUs
+    // were 3 blocks on one half of the chip and 2 on the other (the launch takes what the 3-block CUs take: +20 %); now every CU has 40 rows
+    // = 2 blocks + 8 rows, the lanes of the missing rows requesting nothing.
+    const int per = g.N / G, rem = g.N % G;
+    const int r0 = blockIdx.x * per + min((int)blockIdx.x, rem), r1 = r0 + per + ((int)blockIdx.x < rem ? 1 : 0);
+    const int nblk = (r1 - r0 + 15) >> 4;
     if (nblk <= 0) return;  // (uniform per workgroup)
     const int k0 = (blockIdx.y * 8 + wid) * (KS * 32);
     bf16x8 wv[RB][KS];
-    float bv[RB];  // bias of the lane's output column, requested WITH the block's weights: a load in the epilogue put one global round trip
-                   // (~1.5 us) on the critical path of every block (measured without any operand loads: 7.5 us per q|k|v launch, 20.7 for the lm_head)
+    unsigned short bv[RB];  // bias of the lane's output column (raw bf16 bits), requested WITH the block's weights: a load in the epilogue put one
+                            // global round trip (~1.5 us) on the critical path of every block (measured without any operand loads: 7.5 us per
+                            // q|k|v launch, 20.7 for the lm_head).  Round 5: requested AFTER the block's weights and kept unconverted until the
+                            // epilogue — the bf16 -> float conversion at the request made hipcc wait (vmcnt(0)) for everything in flight before
+                            // it issued the next block's loads: the "ring" held one block at a time.
     const bool plain_epi = a.ks == 1 && !g.wscale && !g.resid;
+    const bool has_bias = plain_epi && g.bias;
     auto load_block = [&](int j, auto buf_c) {
         constexpr int B = decltype(buf_c)::value;
-        int gr = (b0 + j) * 16 + l15;
-        gr = gr < g.N ? gr : g.N - 1;
-        bv[B] = (plain_epi && g.bias) ? (float)g.bias[gr] : 0.0f;
-        const bf16 *wp = g.W + (int64_t)gr * g.ldw + k0 + lg * 8;
+        const int gr = r0 + j * 16 + l15;
+        if (gr < r1) {  // (a lane past the CU's rows keeps whatever its registers hold: that output column is never stored)
+            const bf16 *wp = g.W + (int64_t)gr * g.ldw + k0 + lg * 8;
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
+            for (int u = 0; u < KS; ++u) {
 #ifdef ROWS32_NOW
-            wv[B][u] = zero8();
+                wv[B][u] = zero8();
 #else
-            wv[B][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wp + u * 32));
+                wv[B][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wp + u * 32));
 #endif
+            }
+            bv[B] = reinterpret_cast<const unsigned short *>(has_bias ? g.bias : g.W)[has_bias ? gr : 0];
         }
     };
     bf16x8 av[MB][KS];
@@ -388,13 +394,13 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int r = mb * 16 + l15;
-            const bf16 *ap = g.A + (int64_t)(r < g.M ? r : 0) * g.lda + k0 + lg * 8;
+            const bf16 *ap = g.A + (int64_t)(r < g.M ? r : 0) * g.lda + k0 + lg * 8;  // rows past M: row 0 again (their outputs are never stored)
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
 #ifdef ROWS32_NOX
                 av[mb][u] = zero8();
 #else
-                av[mb][u] = r < g.M ? *reinterpret_cast<const bf16x8 *>(ap + u * 32) : zero8();
+                av[mb][u] = *reinterpret_cast<const bf16x8 *>(ap + u * 32);
 #endif
             }
         }
@@ -417,14 +423,14 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
         // 0 .. MB - 1 finishing four: the next block's barrier waits for the finishers (same-box step 4.95 -> 4.79 ms/token).  (All of a CU's
         // blocks behind ONE barrier — MFMAs of every block first, then every reduction — was measured too: 5.31, the longer code spills.)
         if ((wid >> 2) < MB) {
-            const int mb = wid >> 2, r = wid & 3, col = (b0 + j) * 16 + l15;
+            const int mb = wid >> 2, r = wid & 3, col = r0 + j * 16 + l15;
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[j & 1][w][mb][lane][r];
             const int row = mb * 16 + lg * 4 + r;
-            if (row < g.M && col < g.N) {
+            if (row < g.M && col < r1) {
                 if (plain_epi) {  // bias (prefetched) + activation + store: no load here
-                    v += bv[B];
+                    if (has_bias) v += __uint_as_float((unsigned)bv[B] << 16);
                     if (col < g.scale_cols) v *= g.scale;
                     if (g.epi == 1) v = gelu_erf(v);
                     else if (g.epi == 2) v = fmaxf(v, 0.0f);
@@ -435,9 +441,11 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
             }
         }
     };
+    // Request order (round 5): the 32 rows FIRST.  Loads return in order, so with the rows queued behind the ring (r4) the first block's
+    // MFMAs waited for every weight byte of the workgroup: no block's reduction overlapped the stream (4.77 -> 4.73 ms / token at batch 32).
     if (nblk >= 2 * RB) {  // long: the lm_head (12 blocks per CU) — ring with a branch-free steady loop
-        static_for<RB>([&](auto j_c) { load_block(decltype(j_c)::value, j_c); });
         load_x();
+        static_for<RB>([&](auto j_c) { load_block(decltype(j_c)::value, j_c); });
         int base = 0;
         for (; base + 2 * RB <= nblk; base += RB)
             static_for<RB>([&](auto j_c) {
@@ -453,10 +461,10 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
             if (base + decltype(j_c)::value < nblk) consume(base + decltype(j_c)::value, j_c);
         });
     } else {  // short: the block matrices (1-3 blocks per CU): everything requested up front
+        load_x();
         static_for<RB>([&](auto j_c) {
             if (decltype(j_c)::value < nblk) load_block(decltype(j_c)::value, j_c);
         });
-        load_x();
         static_for<RB>([&](auto j_c) {
             constexpr int J = decltype(j_c)::value;
             if (J < nblk) {
@@ -480,16 +488,19 @@ static bool rows32_plan(const GemmArgs &g, int nb, int n_cu, SkinnyArgs &a, int 
     for (int c = 1; c <= 8; c *= 2)
         if (per_wave % c == 0 && (per_wave / c == 10 || per_wave / c == 5 || (per_wave / c == 8 && c == 1))) {  // 8: K = 2048 (flan-t5 decoder, round 5)
             k5 = c;
-            if (nb * c >= n_cu || per_wave / c == 5 || !(g.dbg & 134217728)) break;
+            if (nb * c >= n_cu || per_wave / c == 5 || (g.dbg & 134217728)) break;
         }
     if (!k5) return false;
-    // fewer blocks than CUs (out_proj: 160): the unsplit form leaves a third of the chip idle and needs a separate LayerNorm launch after it
-    // (9.4 us: the split-K reduce of the round-2 kernel produces the LayerNorm for free) — those shapes keep the round-2 / round-3 kernels
-    if (k5 == 1 && nb < n_cu && g.ln_out && !(g.dbg & 134217728)) return false;
+    // fewer blocks than CUs (out_proj: 160) and no further split: the unsplit form leaves a third of the chip idle and needs a separate LayerNorm
+    // launch after it (the split-K reduce produces the LayerNorm for free) — those shapes keep the round-2 / round-3 kernels
+    if (k5 == 1 && nb < n_cu && g.ln_out) return false;
 #ifndef EILEV_ROWS32_SMALLN
     if (per_wave == 8 && nb < n_cu) return false;  // K = 2048 with fewer blocks than CUs (T5 o / cross q / cross o, N = 2048): the split-K kernels
 #endif
-    if (k5 > 1 && !(g.dbg & 134217728)) return false;  // measured: the split-K forms (out_proj, fc2) lose to the round-3 kernels in the step; probe flag 1 << 27 enables them
+    // The split-K forms (out_proj: 2 x 128 workgroups of 20 rows; fc2: 4 x 64 of 40 rows) lost to the round-3 kernels while the rows were dealt in
+    // 16-row blocks (r4); with the rows dealt one by one every CU streams the same bytes and they win: 4.65 -> 4.50 ms / token at batch 32 (r5).
+    // probe flag 1 << 27: the round-3 kernels for these shapes
+    if (k5 > 1 && (g.dbg & 134217728)) return false;
     if (k5 > 1 && (!g.scratch || (size_t)k5 * a.mr * g.N * sizeof(float) > g.scratch_bytes)) return false;
     ks = k5;
     a.ks = k5;

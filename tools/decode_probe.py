@@ -10,6 +10,11 @@ import bench
 from eilev_amd.configs import blip2_config
 from eilev_amd.engine import HipEngine
 
+from eilev_amd import abi
+
+if os.environ.get("PROBE_LIB"):  # A/B against another build of the probe library
+    abi.PROBES_LIB_PATH = os.path.abspath(os.environ["PROBE_LIB"])
+abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 cfg = blip2_config("opt27")
 dev = torch.device("cuda")
 w = bench.random_weights(cfg, dev)
@@ -20,11 +25,12 @@ am = torch.ones(B, L, dtype=torch.int32, device=dev)
 import ctypes as C
 from eilev_amd import abi
 
-abi.use_probes()  # the eilev_debug_* switches live in the probe build only (libeilev_hip_probes.so)
 raw = C.CDLL(abi.HIP_LIB_PATH)
 for rd in range(6):
     flag = int(os.environ.get("PROBE_FLAG", "536870912")) if rd % 2 else 0  # odd rounds: the probe flag (default: split-K reduce and LayerNorm as two launches)
     raw.eilev_debug_gemm_flags(flag)
+    if os.environ.get("PROBE_CALL"):  # e.g. eilev_debug_attn_part32: called with 1 on odd rounds, 0 on even ones
+        getattr(raw, os.environ["PROBE_CALL"])(rd % 2)
     eng._dec_cache = None  # re-capture the decode graph under this setting
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     eng.timing = []
