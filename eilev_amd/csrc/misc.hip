@@ -493,14 +493,14 @@ __global__ __launch_bounds__(1024) void attn_decode1_kernel(const bf16 *__restri
 // seq_len in the prompt cache of sample b / beams, key seq_len + g in generation-cache row anc[g][b], the new token to this row's own slot —
 // with this kernel's 128-key ranges and up-front loads: 5 rows x 32 heads x 8 ranges = 1280 workgroups where the 256-key split kernel ran 640
 // of twice the length (15.3 us per block for 5 rows).
-template <int NCH, int VK, bool BEAM = false>
+template <int NCH, int VK, bool BEAM = false, int KEYS = 128>
 __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                                float *__restrict__ part, const int32_t *__restrict__ attn_mask,
                                                                const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq,
                                                                bf16 *__restrict__ kg_ = nullptr, bf16 *__restrict__ vg_ = nullptr,
                                                                const int32_t *__restrict__ anc = nullptr, int beams = 1, int cap_g = 0, int rows = 0) {
-    constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1, KEYS = 128;
-    static_assert(G * VK >= KEYS, "every key of the range needs an owner");
+    constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1;
+    static_assert(G * VK >= KEYS && KEYS <= 256, "every key of the range needs an owner");
     __shared__ __attribute__((aligned(16))) float qs[128];
     __shared__ float ps[KEYS];
     __shared__ float wred[8];
@@ -605,6 +605,121 @@ __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__res
     if (tid == 0) {
         po[0] = mx;
         po[1] = lsum;
+    }
+}
+
+// ---- (round 5) any batch size: ONE workgroup per (row, head) walks the head's keys in ranges of KEYS with the loading scheme above ---------
+// At batch 32 the 128-key ranges were 8192 workgroups + a merge launch (60.7 + 6.4 us per block), 256-key ranges 4096 + 5.0 us.  Here the
+// 256 threads of a workgroup keep the flash-decoding state (max, sum, o) in registers across the ranges — the online form of the merge
+// kernel's arithmetic — and request range r + 1's keys as soon as range r's scores exist (its values after p . V): no partials, no merge
+// launch, the normalised row straight to `out`.  32 rows x 32 heads = 1024 workgroups = 4 per CU, all resident at once.
+// (measured and not kept: 128-key ranges at 4 workgroups per CU, 4.33 against 4.28 ms / token; 256-key ranges forced to 128 registers spill)
+template <int NCH, int VK, int KEYS>
+__global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
+                                                               bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
+                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
+    constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1;
+    static_assert(G * VK >= KEYS && KEYS <= 256, "every key of a range needs an owner");
+    __shared__ __attribute__((aligned(16))) float qs[128];
+    __shared__ float ps[KEYS];
+    __shared__ float wred[8];
+    __shared__ float red[KEYS * RS > G * hd ? KEYS * RS : G * hd];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, d = heads * hd;
+    const int kv_total = min(cap, seq_len + state[0]);
+    const int slot_new = kv_total - 1;
+    bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
+    const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
+    const int c = tid % NCH, kg = tid / NCH;
+    bf16x8 kr[VK], vr[VK];
+    auto load_k = [&](int k0) {
+        const int k1 = min(kv_total, k0 + KEYS);
+#pragma unroll
+        for (int i = 0; i < VK; ++i) {
+            int key = k0 + kg + i * G;
+            key = key < k1 ? key : k1 - 1;
+            kr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? knew : kbase + (int64_t)key * hd) + c * 8);
+        }
+    };
+    auto load_v = [&](int k0) {
+        const int k1 = min(kv_total, k0 + KEYS);
+#pragma unroll
+        for (int i = 0; i < VK; ++i) {
+            int key = k0 + kg + i * G;
+            key = key < k1 ? key : k1 - 1;
+            vr[i] = *reinterpret_cast<const bf16x8 *>((key == slot_new ? vnew : vbase + (int64_t)key * hd) + c * 8);
+        }
+    };
+    load_k(0);
+    load_v(0);
+    if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
+    if (tid >= 256 - 2 * NCH) {  // the newest key / value: from the q|k|v row of this step into the cache (fuse_new of the split kernel)
+        const int t2 = tid - (256 - 2 * NCH), which = t2 / NCH, cc = t2 - which * NCH;
+        bf16 *dst = (which ? vbase : kbase) + (int64_t)slot_new * hd;
+        *reinterpret_cast<bf16x8 *>(dst + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
+    }
+    __syncthreads();
+    const float4 q0 = *reinterpret_cast<const float4 *>(&qs[c * 8]), q1 = *reinterpret_cast<const float4 *>(&qs[c * 8 + 4]);
+    float m_run = -1e30f, l_run = 0.0f;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    for (int k0 = 0; k0 < kv_total; k0 += KEYS) {
+        const int k1 = min(kv_total, k0 + KEYS);
+        if (kg < G) {
+#pragma unroll
+            for (int i = 0; i < VK; ++i) {
+                const int kk = kg + i * G;
+                float kv[8];
+                unpack8(kr[i], kv);
+                if (kk < KEYS) red[kk * RS + c] = kv[0] * q0.x + kv[1] * q0.y + kv[2] * q0.z + kv[3] * q0.w + kv[4] * q1.x + kv[5] * q1.y + kv[6] * q1.z + kv[7] * q1.w;
+            }
+        }
+        if (k0 + KEYS < kv_total) load_k(k0 + KEYS);  // (uniform) the next range's keys: in flight under this range's softmax and p . V
+        __syncthreads();
+        const int jt = k0 + tid;
+        float s = -1e30f;
+        if (tid < KEYS && jt < k1 && (jt >= seq_len || !attn_mask || attn_mask[(int64_t)b * seq_len + jt] != 0)) {
+            float a = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) a += red[tid * RS + cc];
+            s = a;
+        }
+        const float mxw = wave_max(s);
+        if (lane == 0) wred[wid] = mxw;
+        __syncthreads();
+        const float m_new = fmaxf(m_run, fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+        const float p = s > -1e29f ? __expf(s - m_new) : 0.0f;
+        if (tid < KEYS) ps[tid] = (float)(bf16)p;  // P rounded to bf16 for the product like every attention kernel here; the row sum from the unrounded values
+        const float sw = wave_sum(p);
+        if (lane == 0) wred[4 + wid] = sw;
+        __syncthreads();
+        const float scale = __expf(m_run - m_new);  // first range: exp(-huge) = 0 (and the state it scales is 0)
+        l_run = l_run * scale + (wred[4] + wred[5] + wred[6] + wred[7]);
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= scale;
+#pragma unroll
+        for (int i = 0; i < VK; ++i) {
+            const int kk = kg + i * G;
+            const float pj = (kk < KEYS && k0 + kk < k1) ? ps[kk] : 0.0f;
+            float vv[8];
+            unpack8(vr[i], vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pj * vv[e];
+        }
+        if (k0 + KEYS < kv_total) load_v(k0 + KEYS);
+        __syncthreads();  // ps / red / wred are rewritten by the next range
+    }
+    if (kg < G) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[kg * hd + c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float v = 0.0f;
+        for (int k2 = 0; k2 < G; ++k2) v += red[k2 * hd + tid];
+        out[((int64_t)b * heads + h) * hd + tid] = (bf16)(l_run > 0.0f ? v / l_run : 0.0f);
     }
 }
 
@@ -1142,7 +1257,7 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
     return EILEV_OK;
 }
 static int g_beam_part = 1;
-static int g_attn_part32 = 1;  // (r5) plain decode at any batch size: 128-key ranges, every load up front (4.70 -> 4.61 ms / token at batch 32)
+static int g_attn_part32 = 1;  // 1 = by batch size (launch_attn_decode); probe build: 0 = the 256-key split kernel, 2 / 3 = force a form
 #ifdef EILEV_PROBES
 extern "C" int eilev_debug_attn_part32(int on) { g_attn_part32 = on; return 0; }  // probe: the 128-key up-front-load kernel at any batch size
 extern "C" int eilev_debug_beam_part(int on) { g_beam_part = on; return 0; }  // probe / test switch: 0 = the 256-key split kernel for beam rows too (round 3)
@@ -1172,10 +1287,25 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
         }
     }
     if (g_attn_part32 && !anc && out && state && fuse_new && !rel_tab && hd == 80 && cap_all <= 2048) {
-        const int ns = (cap_all + 127) / 128;
+        // (r5) plain decode steps of head size 80 at any batch size, same-box ms / token at batch 32: 256-key split kernel + merge 4.70,
+        // 128-key up-front-load ranges + merge 4.61 (mode 1), 256-key ranges 4.38 (mode 2), one workgroup per head looping over 256-key
+        // ranges with no partials and no merge 4.27 (mode 3, the default from 2 workgroups per CU; fewer rows keep the ranges: more workgroups)
+        const int mode = g_attn_part32 != 1 ? g_attn_part32 : (batch * heads >= 2 * eilev_num_cu() ? 3 : 1);
+        if (mode == 3) {
+            hipLaunchKernelGGL((attn_decode_loop_kernel<10, 11, 256>), dim3(heads, batch), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc), const_cast<bf16 *>(vc), out,
+                               attn_mask, state, seq_len, cap, heads, ldq);
+            EILEV_LAUNCH_CHECK();
+            return EILEV_OK;
+        }
+        const int keys = mode == 2 ? 256 : 128;
+        const int ns = (cap_all + keys - 1) / keys;
         if (scratch && scratch_bytes >= sizeof(float) * (size_t)batch * heads * ns * (hd + 2)) {
-            hipLaunchKernelGGL((attn_decode_part_kernel<10, 6, false>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc),
-                               const_cast<bf16 *>(vc), scratch, attn_mask, state, seq_len, cap, heads, ldq, nullptr, nullptr, nullptr, 1, 0, batch);
+            if (keys == 256)
+                hipLaunchKernelGGL((attn_decode_part_kernel<10, 11, false, 256>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc),
+                                   const_cast<bf16 *>(vc), scratch, attn_mask, state, seq_len, cap, heads, ldq, nullptr, nullptr, nullptr, 1, 0, batch);
+            else
+                hipLaunchKernelGGL((attn_decode_part_kernel<10, 6, false>), dim3(heads, batch, ns), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc),
+                                   const_cast<bf16 *>(vc), scratch, attn_mask, state, seq_len, cap, heads, ldq, nullptr, nullptr, nullptr, 1, 0, batch);
             EILEV_LAUNCH_CHECK();
             hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(heads, batch), dim3(128), 0, s, scratch, out, heads, hd, ns);
             EILEV_LAUNCH_CHECK();

@@ -176,24 +176,26 @@ def test_real_width_t5_path(golden_dir):
     assert any(np.array_equal(ids, g[k]) for k in ("fp32_greedy_free", "bf16_greedy_free")), (ids, g["fp32_greedy_free"], g["bf16_greedy_free"])
 
 
-@pytest.mark.parametrize("B", [2, 3, 5, 8, 20, 32])
-def test_batch_decode_step_at_real_widths_vs_oracle(B):
+@pytest.mark.parametrize("B,L", [(2, 24), (3, 24), (5, 24), (8, 24), (20, 24), (32, 24), (16, 530)])
+def test_batch_decode_step_at_real_widths_vs_oracle(B, L):
     """B <= 8: the row-dot block of round 4 (gemvm_kernel: rows staged in LDS behind the weight ring, DPP lane sums; attn_decode1_kernel;
     fc2 on gemv_rows_kernel or, at 8 rows, the MFMA kernel).  The batch-17..32 decode block at OPT-2.7B widths (round 4: gemm_skinny5_kernel — q|k|v and fc1 without a K split, out_proj and fc2
     with 2 / 4 K splits through the partial buffer and reduce_ln_kernel; K = 2560 / 10240) against the fp32 ORACLE: after a prefill of L
     positions, one decode step on token t must give the logits a prefill over the L + 1 positions gives for its last row (left padding in
-    two rows; ragged M = 20 exercises the row guards)."""
+    two rows; ragged M = 20 exercises the row guards).  (16, 530), round 5: 16 rows x 32 heads = 2 workgroups per CU, the form
+    attn_decode_loop_kernel takes — 531 keys = two whole 256-key ranges and a ragged one, one row whose first range is padding only."""
     import ctypes as C
 
     cfg, oracle, eng = models("real_1l")
     d = eng.dims
     rng = np.random.default_rng(5)
-    L = 24
     ids = rng.integers(4, 50000, size=(B, L + 1)).astype(np.int64)
     am = np.ones((B, L + 1), np.int64)
     am[1, :5] = 0
     if B > 2:
         am[B - 1, :9] = 0
+    if L > 300:
+        am[2, :300] = 0
     emb_o = oracle.embed_scatter(ids, None, None)
     ref, _, _ = oracle.prefill(emb_o, am, all_logits=False)
     t = lambda a: torch.from_numpy(a).cuda()

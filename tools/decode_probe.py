@@ -30,7 +30,7 @@ for rd in range(6):
     flag = int(os.environ.get("PROBE_FLAG", "536870912")) if rd % 2 else 0  # odd rounds: the probe flag (default: split-K reduce and LayerNorm as two launches)
     raw.eilev_debug_gemm_flags(flag)
     if os.environ.get("PROBE_CALL"):  # e.g. eilev_debug_attn_part32: called with 1 on odd rounds, 0 on even ones
-        getattr(raw, os.environ["PROBE_CALL"])(rd % 2)
+        getattr(raw, os.environ["PROBE_CALL"])(int(os.environ.get("PROBE_CALL_ON", "1")) if rd % 2 else int(os.environ.get("PROBE_CALL_OFF", "0")))
     eng._dec_cache = None  # re-capture the decode graph under this setting
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     eng.timing = []
