@@ -63,10 +63,14 @@ class OptLayerW8(C.Structure):
     _fields_ = [(n, vp) for n in ("qkv_w8", "qkv_scale", "o_w8", "o_scale", "fc1_w8", "fc1_scale", "fc2_w8", "fc2_scale")]
 
 
+class OptLayerStream(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_s", "o_s", "fc1_s", "fc2_s")]
+
+
 class OptWeights(C.Structure):
     _fields_ = [("embed_tokens", vp), ("embed_positions", vp), ("final_ln_w", vp), ("final_ln_b", vp),
                 ("layers", C.POINTER(OptLayer)), ("layers_w8", C.POINTER(OptLayerW8)), ("w8_expand", vp), ("w8_expand_bytes", C.c_size_t),
-                ("w8_act_fp8", C.c_int32)]
+                ("w8_act_fp8", C.c_int32), ("layers_stream", C.POINTER(OptLayerStream)), ("lm_head_stream", vp)]
 
 
 class T5Dims(C.Structure):
@@ -254,7 +258,7 @@ EXPORTS = [
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
     "eilev_attention_dropout_bwd", "eilev_comm_bind", "eilev_comm_unique_id", "eilev_comm_init", "eilev_comm_destroy",
     "eilev_gather_clip_tokens", "eilev_exchange_clip_tokens", "eilev_fold_layernorm", "eilev_linear_stats", "eilev_ln_finalize",
-    "eilev_linear_lnfold", "eilev_debug_ln_fold_min_rows",
+    "eilev_linear_lnfold", "eilev_debug_ln_fold_min_rows", "eilev_stream_layout_pack",
 ]
 
 
@@ -267,6 +271,23 @@ def attach_vit_fold(pack, per_layer):
                 setattr(arr[i], f"{name}_{f}", v)
     pack._vit_layers_fold = arr
     pack.vit.layers_fold = C.cast(arr, C.POINTER(VitLayerFold))
+
+
+def attach_opt_stream(pack, per_layer, lm_head_ptr):
+    """Point ``pack.opt`` at stream-layout copies of the decode matrices (eilev_stream_layout_pack): per_layer = [{"qkv": ptr or None,
+    "o": ..., "fc1": ..., "fc2": ...}, ...]; ``per_layer=None`` detaches them."""
+    if per_layer is None:
+        pack._opt_layers_stream = None
+        pack.opt.layers_stream = None
+        pack.opt.lm_head_stream = None
+        return
+    arr = (OptLayerStream * len(per_layer))()
+    for i, d in enumerate(per_layer):
+        for name in ("qkv", "o", "fc1", "fc2"):
+            setattr(arr[i], f"{name}_s", d.get(name))
+    pack._opt_layers_stream = arr
+    pack.opt.layers_stream = C.cast(arr, C.POINTER(OptLayerStream))
+    pack.opt.lm_head_stream = lm_head_ptr
 
 
 def attach_opt_w8(pack, per_layer, expand_ptr: int, expand_bytes: int, act_fp8: bool = False):
@@ -343,6 +364,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_opt_decode_step_beam.argtypes = [DP, C.POINTER(OptWeights), vp, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, sz, vp]
     lib.eilev_linear.restype = i32
     lib.eilev_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.eilev_stream_layout_pack.restype = i32
+    lib.eilev_stream_layout_pack.argtypes = [vp, i64, i64, vp, vp]
     lib.eilev_linear_rows.restype = i32
     lib.eilev_linear_rows.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.eilev_layernorm.restype = i32
@@ -428,7 +451,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 13:
+    if lib.eilev_abi_version() != 14:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

@@ -176,6 +176,7 @@ struct GemmArgs {
     int64_t lda;
     const bf16 *W;      // [N, K] row-major (checkpoint layout), leading dimension ldw
     int64_t ldw;
+    const bf16 *Wp = nullptr;  // optional: the same matrix in the stream layout of gemm_rows32_kernel (gemm_skinny.h; eilev_stream_layout_pack)
     const bf16 *bias;   // [N] or null
     const bf16 *resid;  // [M, N] (ldr) or null; in patch mode: position table [1+group, N]
     int64_t ldr;

@@ -82,6 +82,17 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
 
 // GemmArgs::ln_out: the LayerNorm of the output rows is either produced by the split-K reduction of the decode GEMV (launch_gemm_core
 // sets ln_done) or by a LayerNorm launch here.
+// include/eilev.h: eilev_stream_layout_pack
+extern "C" int eilev_stream_layout_pack(const void *w, int64_t n, int64_t k, void *out, void *stream) {
+    if (!w || !out || w == out || n < 1 || k < 256 || n > 0x7fffffff || k > 0x7fffffff || n * k > 0x7fffffff0ll) return EILEV_E_BADARG;
+    int ks = 0, ksteps = 0, grid_x = 0;
+    if (!rows32_shape((int)n, (int)k, skinny_n_cu(), ks, ksteps, grid_x)) return EILEV_E_UNSUPPORTED;
+    const int64_t chunks = n * (k >> 3);
+    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16 *)w, (bf16 *)out, (int)n, (int)k, grid_x);
+    EILEV_LAUNCH_CHECK();
+    return EILEV_OK;
+}
+
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
     bool ln_done = false;
     const int rc = launch_gemm_core(g, prof_kind, s, &ln_done);
@@ -154,7 +165,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         const int per_w = ((g.K / 256 + ks - 1) / ks + 3) / 4;
         const bool pre = per_w <= 3 && !(g.dbg & 128);
         // weight blocks per workgroup (activation fragments reused): probe override (dbg >> 26) & 7 = 1 / 2 / 4; default by shape below
-        int ks32 = 0;
+        int ks32 = 0, r32_grid = 0;
         int nbsel = (g.dbg >> 26) & 7;
         // measured at M = 32 (tools/skinny_sweep.py, 2 LDS stages so that two workgroups share a CU): lm_head (3142 blocks) 2.82 -> 3.45 /
         // 3.76 / 4.20 TB/s with 2 / 4 / 8 blocks per workgroup, qkv (480) 2.25 -> 2.46 with 2 (1.71 with 4: 120 workgroups leave CUs idle),
@@ -175,11 +186,11 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         } else if (g.W8) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
-        } else if (g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32)) {
+        } else if (g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32, r32_grid)) {
             // round 4 (gemm_rows32_kernel): one workgroup per CU, the 32 rows loaded once per CU.  probe flag 1 << 28: the kernels below
             // (the kernel deals the N weight rows over grid_x workgroups row by row; with a K split the grid is still one workgroup per CU)
-            const int cus = ks > 1 ? std::max(1, skinny_n_cu() / ks) : skinny_n_cu();
-            const int grid_x = nb < cus ? nb : cus;
+            const int grid_x = r32_grid;
+            if (a.g.Wp && (g.ldw != g.K || (g.dbg & 32768))) a.g.Wp = nullptr;  // (the stream layout has no row stride; probe flag 1 << 15: ignore it)
             if (ks32 == 10) hipLaunchKernelGGL((gemm_rows32_kernel<2, 10, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else if (ks32 == 8) hipLaunchKernelGGL((gemm_rows32_kernel<2, 8, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((gemm_rows32_kernel<2, 5, 4>), dim3(grid_x, ks), dim3(512), 0, s, a);

@@ -525,6 +525,7 @@ int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &
     if (fused) {
         GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
         g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+        if (w->layers_stream && M > 16 && M <= 32) g.Wp = (const bf16 *)w->layers_stream[l].qkv_s;
         return launch_gemm(g, 5, s);
     }
     GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, D, D, 0);
@@ -547,17 +548,22 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     const EilevOptLayer *L = &w->layers[l];
     const EilevOptLayerW8 *Q = w->layers_w8 ? &w->layers_w8[l] : nullptr;
     const int D = d->t_hidden, Ft = d->t_ffn;
+    // (decode steps of 17..32 rows: the stream-layout copies of the three matrices, where the caller packed them)
+    const EilevOptLayerStream *S = (w->layers_stream && !Q && M > 16 && M <= 32) ? &w->layers_stream[l] : nullptr;
     GemmArgs g = mk_gemm(b.att, D, L->o_w, D, L->o_b, b.h, D, b.h, D, M, D, D, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     g.ln_gamma = (const bf16 *)L->ln2_w; g.ln_beta = (const bf16 *)L->ln2_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
+    if (S) g.Wp = (const bf16 *)S->o_s;
     if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale, b, s));
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (S) g.Wp = (const bf16 *)S->fc1_s;
     if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale, b, s));
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (S) g.Wp = (const bf16 *)S->fc2_s;
     if (next_ln_w) {
         g.ln_gamma = (const bf16 *)next_ln_w; g.ln_beta = (const bf16 *)next_ln_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
     }
@@ -888,6 +894,7 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
     }
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (w->lm_head_stream && batch > 16 && batch <= 32) g.Wp = (const bf16 *)w->lm_head_stream;
     RC(launch_gemm(g, 5, s));
     return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
 }
@@ -964,6 +971,7 @@ extern "C" int eilev_opt_decode_step_beam(const EilevDims *d, const EilevOptWeig
     }
     GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, rows, d->vocab, D, 0);
     g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    if (w->lm_head_stream && rows > 16 && rows <= 32) g.Wp = (const bf16 *)w->lm_head_stream;
     RC(launch_gemm(g, 5, s));
     bump_step_kernel<<<1, 64, 0, s>>>(state);  // the step counter lives on the device: a captured step replays for every step
     EILEV_LAUNCH_CHECK();

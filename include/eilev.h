@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 13  /* 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
+#define EILEV_ABI_VERSION 14  /* 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -147,7 +147,17 @@ typedef struct EilevOptWeights {
      * per token to e4m3 (eilev_quant_rows_e4m3) and run the products on the fp8 MFMA (eilev_linear_a8w8) instead of expanding the
      * weights to bf16 — BASELINE configs[4] "fp8 MFMA".  Decode steps keep bf16 activations (weight-streaming, HBM-bound). */
     int32_t w8_act_fp8;
+    /* ABI version 14.  Optional second copy of the bf16 decode matrices in the STREAM LAYOUT of the 17..32-row decode kernel
+     * (eilev_stream_layout_pack): NULL, or a host array of t_layers entries (an entry's NULL members fall back to `layers`); lm_head_stream:
+     * NULL or the packed embed_tokens.  Only decode steps of 17..32 rows read them; results are bit-identical to the plain layout. */
+    const struct EilevOptLayerStream *layers_stream;
+    const void *lm_head_stream;
 } EilevOptWeights;
+
+/* q|k|v as ONE [3 Dt, Dt] matrix (rows q, k, v — what `layers[l].q_w` points at when the three are contiguous), out_proj, fc1, fc2 */
+typedef struct EilevOptLayerStream {
+    const void *qkv_s, *o_s, *fc1_s, *fc2_s;
+} EilevOptLayerStream;
 
 int eilev_abi_version(void);
 /* "hip-gfx950" or "cpu-oracle" */
@@ -474,6 +484,12 @@ int eilev_layernorm(const void *x, const void *gamma, const void *beta, void *y,
  * final_layer_norm -> lm_head: modeling_opt.py:226-247, 386) evaluated in the same launch; ln_gamma == NULL: plain linear.  The
  * normalised rows are rounded to bf16 before the product (HIP library), as the separate LayerNorm kernel stores them.
  * epilogue: 0 none, 2 ReLU.  Other shapes: EILEV_E_UNSUPPORTED (HIP library; eilev_linear / eilev_layernorm serve them). */
+/* Weight-streaming layout of a bf16 nn.Linear weight [n, k] (row-major, no row padding) for decode steps of 17..32 rows: the same n * k
+ * values reordered so that every load instruction of the decode kernel reads one contiguous kilobyte (the checkpoint layout gives it 16
+ * segments of 64 bytes, a row apart).  `out`: n * k bf16, device memory, must not alias w.  The order depends on (n, k) and on the CU count
+ * of the current device.  EILEV_E_UNSUPPORTED: the decode kernel does not take this shape (k % 256, or no 5 / 8 / 10-step K slice) — keep
+ * the plain layout.  hf counterpart: none (the arithmetic of nn.Linear in OPTDecoderLayer, modeling_opt.py:226-247, is unchanged). */
+int eilev_stream_layout_pack(const void *w, int64_t n, int64_t k, void *out, void *stream);
 int eilev_linear_rows(const void *x, const void *ln_gamma, const void *ln_beta, float eps, const void *w, const void *bias,
                       const void *residual, void *c, int64_t m, int64_t n, int64_t k, int epilogue, int out_f32, void *stream);
 /* Multi-head attention over packed projections. q: rows of length ldq with head h at column
