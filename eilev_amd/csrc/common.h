@@ -177,6 +177,9 @@ struct GemmArgs {
     const bf16 *W;      // [N, K] row-major (checkpoint layout), leading dimension ldw
     int64_t ldw;
     const bf16 *Wp = nullptr;  // optional: the same matrix in the stream layout of gemm_rows32_kernel (gemm_skinny.h; eilev_stream_layout_pack)
+    // Row-block layout of the <= 32 activation rows of a decode step (round 5; frag32_index below): only gemm_rows32_kernel reads (a_frag) or
+    // writes (c_frag: plain bf16 epilogue; ln_frag: the LayerNorm rows that ride on a split-K reduce) it — any other kernel family refuses
+    int a_frag = 0, c_frag = 0, ln_frag = 0;
     const bf16 *bias;   // [N] or null
     const bf16 *resid;  // [M, N] (ldr) or null; in patch mode: position table [1+group, N]
     int64_t ldr;
@@ -222,6 +225,11 @@ struct GemmArgs {
     int trace_tiles = 0;
 };
 
+// Row-block ("fragment order") layout of up to 32 activation rows x K: element (row, col) at (col / 32) * 1024 + row * 32 + col % 32 — the 16
+// rows x 32 columns an MFMA operand load of the decode GEMVs reads are ONE contiguous kilobyte (row-major gives it 16 segments of 64 bytes
+// a row apart: 4.04 -> 3.85 ms / token at batch 32).  A buffer in this layout holds 32 rows whatever M is.  8-element chunks stay contiguous.
+__host__ __device__ static inline int64_t frag32_index(int row, int col) { return (int64_t)(col >> 5) * 1024 + row * 32 + (col & 31); }
+
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm_pp4_ext.hip
 // every tile of a persistent-kernel launch can take the lean epilogue (what the 16 x 16 MFMA instances need: gemm_pp4.h M16)
@@ -260,7 +268,7 @@ int launch_layernorm(const bf16 *x, int64_t ldx, const bf16 *g, const bf16 *b, b
 int launch_fold_layernorm(const bf16 *w, const bf16 *gamma, const bf16 *beta, const bf16 *bias, int N, int K, bf16 *wf, float *csum, bf16 *bf,
                           hipStream_t s);
 int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
-                     int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s);
+                     int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s, int ln_frag = 0);
 int launch_ln_finalize(const float *part, int slots, int64_t rows, int cols, float eps, float *out, hipStream_t s);
 
 struct AttnArgs {

@@ -82,6 +82,17 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
 
 // GemmArgs::ln_out: the LayerNorm of the output rows is either produced by the split-K reduction of the decode GEMV (launch_gemm_core
 // sets ln_done) or by a LayerNorm launch here.
+// Would launch_gemm run this <= 32-row launch on gemm_rows32_kernel (the one kernel that reads / writes the row-block activation layout)?
+bool gemm_rows32_takes(const GemmArgs &g) {
+    if (!g.A || !g.W || !g.C || g.W8 || g.wscale || g.M <= 16 || g.M > 32 || g.K % 256 || g.patch_group || g.ln_rows || g.stat_out) return false;
+    if ((g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || (g.dbg & 268435456)) return false;
+    SkinnyArgs a;
+    a.g = g;
+    a.mr = 32;
+    int ks = 1, ksteps = 0, grid_x = 0;
+    return rows32_plan(g, (g.N + 15) / 16, skinny_n_cu(), a, ks, ksteps, grid_x);
+}
+
 // include/eilev.h: eilev_stream_layout_pack
 extern "C" int eilev_stream_layout_pack(const void *w, int64_t n, int64_t k, void *out, void *stream) {
     if (!w || !out || w == out || n < 1 || k < 256 || n > 0x7fffffff || k > 0x7fffffff || n * k > 0x7fffffff0ll) return EILEV_E_BADARG;
@@ -146,6 +157,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     const bool ln_fold = g.ln_rows != nullptr || g.stat_out != nullptr;  // LayerNorm-folding variants: the persistent kernel only
     if (ln_fold && (g.W8 || g.wscale || g.out_f32 || g.patch_group || g.scale_cols || g.K % BK || (int64_t)g.N * g.ldw * 2 >= 0x7fff0000ll)) return EILEV_E_UNSUPPORTED;
     const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0 && !ln_fold;
+    if ((g.a_frag || g.c_frag || g.ln_frag) && !skinny) return EILEV_E_UNSUPPORTED;
     if (!skinny && !g.out_f32 && ((g.ldc & 7) || (g.N & 3) || ((uintptr_t)g.C & 15) || (g.resid && ((g.ldr & 7) || ((uintptr_t)g.resid & 15))) ||
                                    (g.bias && ((uintptr_t)g.bias & 7))))
         return EILEV_E_UNSUPPORTED;
@@ -180,13 +192,16 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
         if (nbsel != 2 && nbsel != 4 && nbsel != 8) nbsel = 1;
         if (nbsel == 8 && g.M <= 16) nbsel = 4;
         if (g.W8) nbsel = 1;
+        // gemm_rows32_kernel takes this launch?  (the row-block activation layouts exist in that kernel only)
+        const bool r32 = !g.W8 && g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32, r32_grid);
+        if ((g.a_frag || g.c_frag || g.ln_frag) && !r32) return EILEV_E_UNSUPPORTED;
         if (g.W8 && g.M > 16) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<2, false>), dim3(nb, ks), dim3(256), 0, s, a);
         } else if (g.W8) {
             if (pre) hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, true>), dim3(nb, ks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_skinny_w8_kernel<1, false>), dim3(nb, ks), dim3(256), 0, s, a);
-        } else if (g.M > 16 && !(g.dbg & 268435456) && rows32_plan(g, nb, skinny_n_cu(), a, ks, ks32, r32_grid)) {
+        } else if (r32) {
             // round 4 (gemm_rows32_kernel): one workgroup per CU, the 32 rows loaded once per CU.  probe flag 1 << 28: the kernels below
             // (the kernel deals the N weight rows over grid_x workgroups row by row; with a K split the grid is still one workgroup per CU)
             const int grid_x = r32_grid;
@@ -228,11 +243,12 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
             if (g.ln_out && !(g.dbg & 536870912) && !g.out_f32 && g.epi == 0 && g.scale_cols == 0 && (g.N & 7) == 0 && g.N <= 4096 && (g.ldc & 7) == 0 && (!g.resid || (g.ldr & 7) == 0)) {
                 // split-K partials -> row (+ bias + residual) -> its LayerNorm in one launch (norm.hip)
                 const int rc_ln = launch_reduce_ln(a.part, ks, a.mr, g.M, g.N, g.wscale, g.bias, g.resid, g.ldr, reinterpret_cast<bf16 *>(g.C), g.ldc,
-                                                   g.ln_gamma, g.ln_beta, g.ln_out, g.ln_eps, s);
+                                                   g.ln_gamma, g.ln_beta, g.ln_out, g.ln_eps, s, g.ln_frag);
                 if (rc_ln != EILEV_OK) return rc_ln;
                 *ln_done = true;
                 return EILEV_OK;
             }
+            if (g.ln_frag) return EILEV_E_UNSUPPORTED;  // (the row-block LayerNorm rows exist in the fused reduce only)
             const int total = g.M * g.N;
             hipLaunchKernelGGL(skinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
             EILEV_LAUNCH_CHECK();

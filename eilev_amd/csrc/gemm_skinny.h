@@ -401,12 +401,17 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
         for (int mb = 0; mb < MB; ++mb) {
             const int r = mb * 16 + l15;
             const bf16 *ap = g.A + (int64_t)(r < g.M ? r : 0) * g.lda + k0 + lg * 8;  // rows past M: row 0 again (their outputs are never stored)
+            int ustride = 32;
+            if (g.a_frag) {  // the rows in the row-block layout (common.h frag32_index): this load reads one contiguous kilobyte
+                ap = g.A + (int64_t)(k0 / 32) * 1024 + mb * 512 + (l15 * 4 + lg) * 8;
+                ustride = 1024;
+            }
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
 #ifdef ROWS32_NOX
                 av[mb][u] = zero8();
 #else
-                av[mb][u] = *reinterpret_cast<const bf16x8 *>(ap + u * 32);
+                av[mb][u] = *reinterpret_cast<const bf16x8 *>(ap + u * ustride);
 #endif
             }
         }
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(512) void gemm_rows32_kernel(const SkinnyArgs a) {
                     if (g.epi == 1) v = gelu_erf(v);
                     else if (g.epi == 2) v = fmaxf(v, 0.0f);
                     if (g.out_f32) reinterpret_cast<float *>(g.C)[(int64_t)row * g.ldc + col] = v;
-                    else reinterpret_cast<bf16 *>(g.C)[(int64_t)row * g.ldc + col] = (bf16)v;
+                    else reinterpret_cast<bf16 *>(g.C)[g.c_frag ? frag32_index(row, col) : (int64_t)row * g.ldc + col] = (bf16)v;
                 } else if (a.ks == 1) skinny_epilogue(g, row, col, v);
                 else a.part[((int64_t)blockIdx.y * (16 * MB) + row) * g.N + col] = v;
             }
@@ -535,6 +540,9 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const bf16 *__restrict
 static bool rows32_plan(const GemmArgs &g, int nb, int n_cu, SkinnyArgs &a, int &ks, int &ksteps, int &grid_x) {
     int k5 = 0;
     if (!rows32_shape(g.N, g.K, n_cu, k5, ksteps, grid_x, (g.dbg & 134217728) != 0)) return false;
+    if (g.c_frag && (k5 > 1 || g.out_f32 || g.wscale || g.resid || (g.N & 31))) return false;  // c_frag: the plain bf16 epilogue only
+    if (g.ln_frag && (k5 == 1 || !g.ln_out)) return false;                                      // ln_frag: the fused split-K reduce only
+    if (g.a_frag && g.M > 32) return false;
     const int per_wave = g.K / 256;
     if (!k5) return false;
     // fewer blocks than CUs (out_proj: 160) and no further split: the unsplit form leaves a third of the chip idle and needs a separate LayerNorm

@@ -617,7 +617,8 @@ __global__ __launch_bounds__(256) void attn_decode_part_kernel(const bf16 *__res
 template <int NCH, int VK, int KEYS>
 __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                                bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
-                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq) {
+                                                               const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq,
+                                                               int out_frag) {
     constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1;
     static_assert(G * VK >= KEYS && KEYS <= 256, "every key of a range needs an owner");
     __shared__ __attribute__((aligned(16))) float qs[128];
@@ -719,7 +720,8 @@ __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__res
     if (tid < hd) {
         float v = 0.0f;
         for (int k2 = 0; k2 < G; ++k2) v += red[k2 * hd + tid];
-        out[((int64_t)b * heads + h) * hd + tid] = (bf16)(l_run > 0.0f ? v / l_run : 0.0f);
+        // out_frag: the row-block layout out_proj's GEMV reads at 17..32 rows (common.h frag32_index)
+        out[out_frag ? frag32_index(b, h * hd + tid) : ((int64_t)b * heads + h) * hd + tid] = (bf16)(l_run > 0.0f ? v / l_run : 0.0f);
     }
 }
 
@@ -1262,6 +1264,10 @@ static int g_attn_part32 = 1;  // 1 = by batch size (launch_attn_decode); probe 
 extern "C" int eilev_debug_attn_part32(int on) { g_attn_part32 = on; return 0; }  // probe: the 128-key up-front-load kernel at any batch size
 extern "C" int eilev_debug_beam_part(int on) { g_beam_part = on; return 0; }  // probe / test switch: 0 = the 256-key split kernel for beam rows too (round 3)
 #endif
+// the launch takes attn_decode_loop_kernel (one workgroup per (row, head), no partials): the only form that can write the row-block layout
+bool attn_decode_loop_ok(int batch, int heads, int hd, int cap_all, bool beam, const void *out, const void *state, int fuse_new, const void *rel_tab) {
+    return g_attn_part32 == 1 && !beam && out && state && fuse_new && !rel_tab && hd == 80 && cap_all <= 2048 && batch * heads >= 2 * eilev_num_cu() && batch <= 32;
+}
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
     const int nsplit = (cap + 127) / 128;  // the 128-key ranges of attn_decode_part_kernel (>= the 256-key splits of attn_decode_split_kernel)
     return sizeof(float) * (size_t)batch * heads * nsplit * (hd + 2);
@@ -1269,8 +1275,9 @@ size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap) {
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
                        int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0,
-                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0) {
+                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0, int out_frag = 0) {
     if (ldq == 0) ldq = 3 * (int64_t)heads * hd;  // q | k | v rows
+    if (out_frag && !attn_decode_loop_ok(batch, heads, hd, anc ? seq_len + cap_g : cap, anc != nullptr, out, state, fuse_new, rel_tab)) return EILEV_E_UNSUPPORTED;
     if (hd > 128 || (hd & 7)) return EILEV_E_UNSUPPORTED;
     const int cap_all = anc ? seq_len + cap_g : cap;  // beam form: prompt keys (prefill cache) + generated keys (generation cache)
     if (anc && out && state && fuse_new && !rel_tab && hd == 80 && batch <= 8 && cap_all <= 2048 && g_beam_part) {
@@ -1293,7 +1300,7 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
         const int mode = g_attn_part32 != 1 ? g_attn_part32 : (batch * heads >= 2 * eilev_num_cu() ? 3 : 1);
         if (mode == 3) {
             hipLaunchKernelGGL((attn_decode_loop_kernel<10, 11, 256>), dim3(heads, batch), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc), const_cast<bf16 *>(vc), out,
-                               attn_mask, state, seq_len, cap, heads, ldq);
+                               attn_mask, state, seq_len, cap, heads, ldq, out_frag);
             EILEV_LAUNCH_CHECK();
             return EILEV_OK;
         }

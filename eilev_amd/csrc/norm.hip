@@ -186,9 +186,10 @@ template <int KS>
 __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restrict__ part, int ks, int mr, int N, const float *__restrict__ wscale,
                                                            const bf16 *__restrict__ bias, const bf16 *__restrict__ resid, int64_t ldr,
                                                            bf16 *__restrict__ C, int64_t ldc, const bf16 *__restrict__ gamma,
-                                                           const bf16 *__restrict__ beta, bf16 *__restrict__ y, float eps) {
+                                                           const bf16 *__restrict__ beta, bf16 *__restrict__ y, float eps, int y_frag) {
     __shared__ float red[2][16];
     const int c = threadIdx.x, row = blockIdx.x, lane = c & 63, wid = c >> 6, nw = (blockDim.x + 63) >> 6;
+    bf16 *yp = y + (y_frag ? frag32_index(row, c * 8) : (int64_t)row * N + c * 8);  // (y_frag: the row-block layout the decode GEMVs read, common.h)
     const bool on = c < (N >> 3);
     float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gv[8], bt[8];
     if (on) {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = gv[e] * (float)(bf16)(t[e] * rs);
-            *reinterpret_cast<bf16x8 *>(y + (int64_t)row * N + c * 8) = pack8(o);
+            *reinterpret_cast<bf16x8 *>(yp) = pack8(o);
         }
         return;
     }
@@ -264,16 +265,17 @@ __global__ __launch_bounds__(1024) void reduce_ln_wg_kernel(const float *__restr
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (t[e] - mean) * rstd * gv[e] + bt[e];
-        *reinterpret_cast<bf16x8 *>(y + (int64_t)row * N + c * 8) = pack8(o);
+        *reinterpret_cast<bf16x8 *>(yp) = pack8(o);
     }
 }
 
 int launch_reduce_ln(const float *part, int ks, int mr, int M, int N, const float *wscale, const bf16 *bias, const bf16 *resid, int64_t ldr, bf16 *C,
-                     int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s) {
+                     int64_t ldc, const bf16 *gamma, const bf16 *beta, bf16 *ln_out, float eps, hipStream_t s, int ln_frag) {
     if (!part || !C || !gamma || !ln_out || M <= 0 || (N & 7) || N > 8 * 512) return EILEV_E_UNSUPPORTED;  // beta == nullptr: the RMS form
+    if (ln_frag && (M > 32 || (N & 31))) return EILEV_E_UNSUPPORTED;
     {
         const int threads = (((N >> 3) + 63) / 64) * 64;
-#define EILEV_RLW(KS_) hipLaunchKernelGGL((reduce_ln_wg_kernel<KS_>), dim3(M), dim3(threads), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps)
+#define EILEV_RLW(KS_) hipLaunchKernelGGL((reduce_ln_wg_kernel<KS_>), dim3(M), dim3(threads), 0, s, part, ks, mr, N, wscale, bias, resid, ldr, C, ldc, gamma, beta, ln_out, eps, ln_frag)
         if (ks == 2) EILEV_RLW(2); else if (ks == 4) EILEV_RLW(4); else EILEV_RLW(0);
 #undef EILEV_RLW
         EILEV_LAUNCH_CHECK();

@@ -22,7 +22,9 @@ int launch_kv_write(const bf16 *qkv, bf16 *kc, bf16 *vc, int batch, int rows_per
 int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *out, const int32_t *attn_mask, const int32_t *state,
                        int batch, int seq_len, int cap, int heads, int hd, float *scratch, size_t scratch_bytes, hipStream_t s,
                        int64_t ldq = 0, const float *rel_tab = nullptr, int64_t rel_hs = 0, int rel_off = 0, int fuse_new = 0,
-                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0);
+                       const bf16 *kg = nullptr, const bf16 *vg = nullptr, const int32_t *anc = nullptr, int beams = 1, int cap_g = 0, int out_frag = 0);
+bool attn_decode_loop_ok(int batch, int heads, int hd, int cap_all, bool beam, const void *out, const void *state, int fuse_new, const void *rel_tab);
+bool gemm_rows32_takes(const GemmArgs &g);  // gemm.hip
 size_t attn_decode_scratch_bytes(int batch, int heads, int hd, int cap);
 int launch_select(const float *logits, int batch, int vocab, int32_t *state, uint8_t *finished, int64_t eos_id, int64_t pad_id,
                   int64_t *tokens, int64_t *out_tokens, int64_t max_new, hipStream_t s);
@@ -443,8 +445,10 @@ extern "C" int eilev_embed_scatter(const EilevDims *d, const void *embed_tokens,
 // =====================================================================================================
 // Stage 4/5: OPT
 // =====================================================================================================
+// rows of the activation buffers: a decode step of 17..32 rows keeps its activations in the 32-row row-block layout (common.h frag32_index)
+static inline int64_t opt_ws_rows(int64_t M) { return (M > 16 && M < 32) ? 32 : M; }
 extern "C" size_t eilev_opt_workspace_bytes(const EilevDims *d, int64_t batch, int64_t seq_len) {
-    const int64_t M = batch * (seq_len > 1 ? seq_len : 1);
+    const int64_t M = opt_ws_rows(batch * (seq_len > 1 ? seq_len : 1));
     size_t b = 0;
     b += align_up((size_t)M * d->t_hidden * 2, 256) * 3;       // h, x, att
     b += align_up((size_t)M * d->t_hidden * 3 * 2, 256);        // qkv
@@ -471,6 +475,7 @@ struct OptBufs {
 
 bool carve_opt(const EilevDims *d, int64_t M, void *ws, size_t bytes, OptBufs &b) {
     Carver cv{(char *)ws, (char *)ws + bytes};
+    M = opt_ws_rows(M);
     b.h = cv.take<bf16>((size_t)M * d->t_hidden);
     b.x = cv.take<bf16>((size_t)M * d->t_hidden);
     b.att = cv.take<bf16>((size_t)M * d->t_hidden);
@@ -508,7 +513,7 @@ int use_w8(GemmArgs &g, const EilevOptWeights *w, const uint8_t *w8, const float
 }
 
 // q|k|v projection of x into b.qkv (q pre-scaled by head_dim^-0.5, hf modeling_opt.py:151)
-int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s) {
+int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s, int a_frag = 0) {
     const EilevOptLayer *L = &w->layers[l];
     const int D = d->t_hidden;
     const float scaling = 1.0f / sqrtf((float)(D / d->t_heads));
@@ -526,16 +531,17 @@ int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &
         GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, 3 * D, D, 0);
         g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
         if (w->layers_stream && M > 16 && M <= 32) g.Wp = (const bf16 *)w->layers_stream[l].qkv_s;
+        g.a_frag = a_frag;
         return launch_gemm(g, 5, s);
     }
     GemmArgs g = mk_gemm(b.x, D, L->q_w, D, L->q_b, nullptr, 0, b.qkv, 3 * D, M, D, D, 0);
-    g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    g.scale = scaling; g.scale_cols = D; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2; g.a_frag = a_frag;
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->k_w, D, L->k_b, nullptr, 0, b.qkv + D, 3 * D, M, D, D, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2; g.a_frag = a_frag;
     RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->v_w, D, L->v_b, nullptr, 0, b.qkv + 2 * D, 3 * D, M, D, D, 0);
-    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
+    g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2; g.a_frag = a_frag;
     return launch_gemm(g, 5, s);
 }
 
@@ -543,8 +549,9 @@ int opt_qkv(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &
 // next_ln_w / next_ln_b (decode): the LayerNorm that consumes this block's output (the next block's self_attn_layer_norm, or
 // final_layer_norm) — then b.x leaves as that LayerNorm of b.h, and both LayerNorms of the block ride on the split-K reductions of
 // out_proj / fc2 (GemmArgs::ln_out)
+// frag (decode steps of 17..32 rows, eilev_opt_decode_step): b.att, b.x and b.ffn in the row-block layout (common.h frag32_index); b.h stays row-major
 int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs &b, int64_t M, hipStream_t s, const void *next_ln_w = nullptr,
-             const void *next_ln_b = nullptr) {
+             const void *next_ln_b = nullptr, int frag = 0, bool dry = false) {
     const EilevOptLayer *L = &w->layers[l];
     const EilevOptLayerW8 *Q = w->layers_w8 ? &w->layers_w8[l] : nullptr;
     const int D = d->t_hidden, Ft = d->t_ffn;
@@ -554,24 +561,32 @@ int opt_tail(const EilevDims *d, const EilevOptWeights *w, int l, const OptBufs 
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     g.ln_gamma = (const bf16 *)L->ln2_w; g.ln_beta = (const bf16 *)L->ln2_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
     if (S) g.Wp = (const bf16 *)S->o_s;
+    g.a_frag = g.ln_frag = frag;
+    if (dry && !gemm_rows32_takes(g)) return EILEV_E_UNSUPPORTED;
     if (Q) RC(use_w8(g, w, Q->o_w8, Q->o_scale, b, s));
-    RC(launch_gemm(g, 5, s));
+    if (!dry) RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.x, D, L->fc1_w, D, L->fc1_b, nullptr, 0, b.ffn, Ft, M, Ft, D, 2);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     if (S) g.Wp = (const bf16 *)S->fc1_s;
+    g.a_frag = g.c_frag = frag;
+    if (dry && !gemm_rows32_takes(g)) return EILEV_E_UNSUPPORTED;
     if (Q) RC(use_w8(g, w, Q->fc1_w8, Q->fc1_scale, b, s));
-    RC(launch_gemm(g, 5, s));
+    if (!dry) RC(launch_gemm(g, 5, s));
     g = mk_gemm(b.ffn, Ft, L->fc2_w, Ft, L->fc2_b, b.h, D, b.h, D, M, D, Ft, 0);
     g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
     if (S) g.Wp = (const bf16 *)S->fc2_s;
     if (next_ln_w) {
         g.ln_gamma = (const bf16 *)next_ln_w; g.ln_beta = (const bf16 *)next_ln_b; g.ln_out = b.x; g.ln_eps = d->t_eps;
     }
+    g.a_frag = frag;
+    g.ln_frag = next_ln_w ? frag : 0;
+    if (dry) return gemm_rows32_takes(g) ? EILEV_OK : EILEV_E_UNSUPPORTED;
     if (Q) RC(use_w8(g, w, Q->fc2_w8, Q->fc2_scale, b, s));
     return launch_gemm(g, 5, s);
 }
 
 // ---- small-batch decode (M <= 8 rows): the block as 5 launches of gemv.hip + the attention split ---------------------------------------
+int g_decode_frag = 1;  // probe / test switch (eilev_debug_decode_frag, probe build): 0 = row-major activations in the 17..32-row decode step
 int g_decode_rows = 1;  // probe / test switch (eilev_debug_decode_rows): 0 = the MFMA weight-streaming kernels at every batch size
 constexpr int kDecodeKeys = 256;  // keys per flash-decoding split (misc.hip DEC_KEYS)
 
@@ -671,6 +686,7 @@ int opt_rows_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b
 
 #ifdef EILEV_PROBES
 extern "C" int eilev_debug_decode_rows(int on) { g_decode_rows = on; return 0; }
+extern "C" int eilev_debug_decode_frag(int on) { g_decode_frag = on; return 0; }
 #endif
 namespace {
 int opt_prefill_impl(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask, int64_t batch,
@@ -880,22 +896,37 @@ extern "C" int eilev_opt_decode_step(const EilevDims *d, const EilevOptWeights *
         RC(opt_rows_head(d, w, b, batch, logits, s));
         return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
     }
+    // 17..32 rows (round 5): the activations between the kernels of a block (attention rows, LayerNorm rows, fc1 rows) in the row-block layout
+    // (common.h frag32_index) when every linear of the block runs on gemm_rows32_kernel and the attention on attn_decode_loop_kernel — a
+    // dry run of the block's launches decides; the first q|k|v projection reads the row-major LayerNorm of the embedding rows
+    GemmArgs gh = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
+    gh.out_f32 = 1; gh.scratch = b.scratch; gh.scratch_bytes = kSkinnyScratch / 2;
+    if (w->lm_head_stream && batch > 16 && batch <= 32) gh.Wp = (const bf16 *)w->lm_head_stream;
+    int frag = 0;
+    if (g_decode_frag && batch > 16 && batch <= 32 && !w->layers_w8 && D % 32 == 0 && d->t_ffn % 32 == 0 &&
+        attn_decode_loop_ok((int)batch, H, hd, (int)kv_capacity, false, b.att, state, 1, nullptr)) {
+        gh.a_frag = 1;
+        GemmArgs gq = mk_gemm(b.x, D, w->layers[0].q_w, D, w->layers[0].q_b, nullptr, 0, b.qkv, 3 * D, batch, D, D, 0);  // q, k, v one by one
+        gq.scratch = b.scratch; gq.scratch_bytes = kSkinnyScratch / 2; gq.a_frag = 1;
+        GemmArgs gq3 = gq;  // ... or as one [3 D, D] matrix (opt_qkv decides per block)
+        gq3.N = 3 * D;
+        frag = gemm_rows32_takes(gh) && gemm_rows32_takes(gq) && gemm_rows32_takes(gq3) &&
+               opt_tail(d, w, 0, b, batch, s, w->final_ln_w, w->final_ln_b, 1, true) == EILEV_OK;
+        gh.a_frag = frag;
+    }
     for (int l = 0; l < d->t_layers; ++l) {
         const EilevOptLayer *L = &w->layers[l];
         bf16 *kc = (bf16 *)kv_cache + l * per_layer, *vc = kc + per_layer / 2;
         if (l == 0) RC(launch_layernorm(b.h, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, b.x, D, batch, D, d->t_eps, s));
-        RC(opt_qkv(d, w, l, b, batch, s));
+        RC(opt_qkv(d, w, l, b, batch, s, l > 0 ? frag : 0));
         // the new token's K / V go into the cache inside the attention kernel (fuse_new): one launch less per layer
         RC(launch_attn_decode(b.qkv, kc, vc, b.att, attn_mask, state, (int)batch, (int)seq_len, (int)kv_capacity, H, hd,
-                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1));
+                              b.scratch + kSkinnyScratch / 2 / sizeof(float), kSkinnyScratch / 2, s, 0, nullptr, 0, 0, 1, nullptr, nullptr, nullptr, 1, 0, frag));
         // the block's output goes straight into the LayerNorm that reads it next (the next block's, or final_layer_norm): b.x
         const bool last = l + 1 == d->t_layers;
-        RC(opt_tail(d, w, l, b, batch, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b));
+        RC(opt_tail(d, w, l, b, batch, s, last ? w->final_ln_w : w->layers[l + 1].ln1_w, last ? w->final_ln_b : w->layers[l + 1].ln1_b, frag));
     }
-    GemmArgs g = mk_gemm(b.x, D, w->embed_tokens, D, nullptr, nullptr, 0, logits, d->vocab, batch, d->vocab, D, 0);
-    g.out_f32 = 1; g.scratch = b.scratch; g.scratch_bytes = kSkinnyScratch / 2;
-    if (w->lm_head_stream && batch > 16 && batch <= 32) g.Wp = (const bf16 *)w->lm_head_stream;
-    RC(launch_gemm(g, 5, s));
+    RC(launch_gemm(gh, 5, s));
     return launch_select(logits, (int)batch, d->vocab, state, finished, eos_id, pad_id, tokens, out_tokens, max_new, s);
 }
 

@@ -272,7 +272,9 @@ void eilev_debug_ln_fold_min_rows(int64_t rows);
  *   eilev_debug_attn_ts : int (void*)         phase stamps of the frame attention kernel (tools/attn_ts.py)
  *   eilev_debug_decode_rows : int (int)       0: MFMA weight-streaming kernels at every batch size; 1 (default): row-dot kernels at <= 4 rows; 3: the round-3 row-dot kernels
  *   eilev_debug_grid_cus : int (int)          persistent kernels size their grids for n CUs (a CU-masked stream: tools/overlap_probe.py); 0 = all
- *   eilev_debug_beam_part : int (int)         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges */
+ *   eilev_debug_beam_part : int (int)         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges
+ *   eilev_debug_attn_part32 : int (int)       plain decode attention of head size 80: 0 the 256-key split kernel; 1 (default) by batch size; 2 / 3 force the 256-key ranges / the per-head loop
+ *   eilev_debug_decode_frag : int (int)       0: row-major activations inside the 17..32-row decode step; 1 (default): the row-block layout where every kernel of the block supports it */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the
  * bf16 MFMA rate).  The reference has no fp8 path; parity is against the oracle on the same quantised operands.

@@ -121,6 +121,47 @@ def test_decode_step_bit_identical_with_stream_layout(B):
     assert torch.equal(kv_a, kv_b)
 
 
+@pytest.mark.parametrize("B", [17, 20, 32])
+def test_decode_step_bit_identical_with_row_block_activations(probes, B):
+    """Inside a decode step of 17..32 rows the attention rows, the LayerNorm rows and the fc1 rows travel between the kernels in the
+    row-block layout (csrc/common.h frag32_index: what an MFMA operand load of the next GEMV reads is one contiguous kilobyte).  Same
+    values, same arithmetic: the step gives the logits, the ids and the cache of the row-major step (probe build switch)."""
+    cfg, _, eng = models("real_1l")
+    d = eng.dims
+    rng = np.random.default_rng(13)
+    L, cap = 300, 304  # two key ranges in the attention loop
+    ids = torch.from_numpy(rng.integers(4, 50000, size=(B, L + 1)).astype(np.int64)).cuda()
+    am = torch.ones((B, L), dtype=torch.int32, device="cuda")
+    am[2, :270] = 0
+    emb = eng.embed_scatter(ids, None, None)
+    kv0 = eng.new_kv_cache(B, cap)
+    eng.prefill(emb[:, :L].contiguous(), am, kv_cache=kv0, kv_capacity=cap)
+    n_valid = am.sum(dim=1).to(torch.int32).contiguous()
+    ws = torch.empty(int(probes.eilev_opt_workspace_bytes(C.byref(d), B, 1)), dtype=torch.uint8, device="cuda")
+    res = {}
+    try:
+        for frag in (0, 1):
+            probes.eilev_debug_decode_frag(frag)
+            kv = kv0.clone()
+            state = torch.tensor([1, B], dtype=torch.int32, device="cuda")
+            tokens = ids[:, L].contiguous()
+            finished = torch.zeros(B, dtype=torch.uint8, device="cuda")
+            out = torch.zeros((B, 4), dtype=torch.int64, device="cuda")
+            logits = torch.empty((B, d.vocab), dtype=torch.float32, device="cuda")
+            ws.fill_(0x7f)  # stale rows of the 32-row buffers must not matter
+            rc = probes.eilev_opt_decode_step(C.byref(d), C.byref(eng.pack.opt), P(tokens), P(state), P(am), P(n_valid), B, L, P(kv), cap, P(logits),
+                                              P(finished), -1, 1, P(out), 4, P(ws), ws.numel(), stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            res[frag] = (logits.cpu().numpy(), out[:, 1].cpu().numpy(), kv)
+    finally:
+        probes.eilev_debug_decode_frag(1)
+    assert np.isfinite(res[1][0]).all()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
+
+
 def test_greedy_decode_ids_with_and_without_stream_layout():
     """engine.greedy_decode at 32 rows (hipGraph replay): the lazily packed copies change no id."""
     cfg, _, eng = models("real_1l")
