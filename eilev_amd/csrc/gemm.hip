@@ -95,7 +95,8 @@ bool gemm_rows32_takes(const GemmArgs &g) {
 
 // include/eilev.h: eilev_stream_layout_pack
 extern "C" int eilev_stream_layout_pack(const void *w, int64_t n, int64_t k, void *out, void *stream) {
-    if (!w || !out || w == out || n < 1 || k < 256 || n > 0x7fffffff || k > 0x7fffffff || n * k > 0x7fffffff0ll) return EILEV_E_BADARG;
+    if (!w || !out || w == out || n < 1 || k < 1) return EILEV_E_BADARG;
+    if (n > 0x7fffffff || k > 0x7fffffff || n * k > 0x7fffffff0ll) return EILEV_E_UNSUPPORTED;
     int ks = 0, ksteps = 0, grid_x = 0;
     if (!rows32_shape((int)n, (int)k, skinny_n_cu(), ks, ksteps, grid_x)) return EILEV_E_UNSUPPORTED;
     const int64_t chunks = n * (k >> 3);

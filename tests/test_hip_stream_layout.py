@@ -71,6 +71,7 @@ def test_pack_rejects_what_the_decode_kernel_does_not_take():
     b = torch.empty_like(a)
     assert lib.eilev_stream_layout_pack(P(a), 64, 384, P(b), stream_ptr()) == -2  # k % 256
     assert lib.eilev_stream_layout_pack(P(a), 32, 768, P(b), stream_ptr()) == -2  # k / 256 = 3: no 5 / 8 / 10-step slice
+    assert lib.eilev_stream_layout_pack(P(a), 384, 64, P(b), stream_ptr()) == -2  # a test-sized model: the engine keeps the checkpoint layout
     assert lib.eilev_stream_layout_pack(P(a), 64, 256, P(a), stream_ptr()) == -1  # in place
     assert lib.eilev_stream_layout_pack(None, 64, 256, P(b), stream_ptr()) == -1
 
