@@ -834,6 +834,14 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         // >= 512 frames: two wave groups one phase apart (attn_frame3.h; 512: with phase stamps): 2-13 % faster at 544 / 1088 frames over
         // six boxes (profiles/r03_attn_frame3.log), slower below ~384 frames (its slots are longer: more exposed at the start and the end
         // of a workgroup's walk).  Probe flag 16 forces it, 32 forbids it.
+#ifdef EILEV_PROBES
+        if (a.dbg & 1024) {  // TIMING PROBE (wrong results): q / k / v read as if stored head-major ([frame][head][token][88]: an image is 45 KB contiguous)
+            a.ldq = a.ldk = a.ldv = a.hd;
+            a.q_hs = a.k_hs = a.v_hs = (int64_t)a.sq * a.hd;
+            a.k = a.q + (int64_t)a.sq * a.heads * a.hd;  // three planes per frame inside the fused q|k|v rows: the same bytes are read, none twice
+            a.v = a.q + 2 * (int64_t)a.sq * a.heads * a.hd;
+        }
+#endif
         if (a.sq == 257 && !(a.dbg & 32) && ((a.dbg & (16 | 512)) || a.batch >= 512)) return launch_attn_frame3<88, 17>(a, s);
         return launch_attn_frame<88, 17>(a, s);
     }
