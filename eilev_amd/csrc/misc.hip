@@ -618,7 +618,9 @@ template <int NCH, int VK, int KEYS>
 __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                                bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
                                                                const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq,
-                                                               int out_frag) {
+                                                               int out_frag, int fuse_new) {
+    // state == nullptr: kv_total = seq_len, given by the host (the flan-t5 cross-attention: keys = encoder positions, attn_mask = their
+    // padding mask, q rows of stride ldq); fuse_new == 0: every key is in the cache already
     constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1;
     static_assert(G * VK >= KEYS && KEYS <= 256, "every key of a range needs an owner");
     __shared__ __attribute__((aligned(16))) float qs[128];
@@ -627,8 +629,8 @@ __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__res
     __shared__ float red[KEYS * RS > G * hd ? KEYS * RS : G * hd];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, d = heads * hd;
-    const int kv_total = min(cap, seq_len + state[0]);
-    const int slot_new = kv_total - 1;
+    const int kv_total = min(cap, seq_len + (state ? state[0] : 0));
+    const int slot_new = fuse_new ? kv_total - 1 : -1;
     bf16 *kbase = kc + ((int64_t)b * heads + h) * cap * hd, *vbase = vc + ((int64_t)b * heads + h) * cap * hd;
     const bf16 *knew = qkv + (int64_t)b * ldq + d + h * hd, *vnew = knew + d;
     const int c = tid % NCH, kg = tid / NCH;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__res
     load_k(0);
     load_v(0);
     if (tid < hd) qs[tid] = (float)qkv[(int64_t)b * ldq + h * hd + tid];
-    if (tid >= 256 - 2 * NCH) {  // the newest key / value: from the q|k|v row of this step into the cache (fuse_new of the split kernel)
+    if (fuse_new && tid >= 256 - 2 * NCH) {  // the newest key / value: from the q|k|v row of this step into the cache (fuse_new of the split kernel)
         const int t2 = tid - (256 - 2 * NCH), which = t2 / NCH, cc = t2 - which * NCH;
         bf16 *dst = (which ? vbase : kbase) + (int64_t)slot_new * hd;
         *reinterpret_cast<bf16x8 *>(dst + cc * 8) = *reinterpret_cast<const bf16x8 *>((which ? vnew : knew) + cc * 8);
@@ -1293,6 +1295,13 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
             return EILEV_OK;
         }
     }
+    // (r5) hd 64 without a position bias (the flan-t5 cross-attention over 960 encoder keys: state == nullptr, nothing to store): the per-head loop too
+    if (g_attn_part32 == 1 && !anc && out && !rel_tab && hd == 64 && batch * heads >= 2 * eilev_num_cu()) {
+        hipLaunchKernelGGL((attn_decode_loop_kernel<8, 8, 256>), dim3(heads, batch), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc), const_cast<bf16 *>(vc), out,
+                           attn_mask, state, seq_len, cap, heads, ldq, 0, fuse_new);
+        EILEV_LAUNCH_CHECK();
+        return EILEV_OK;
+    }
     if (g_attn_part32 && !anc && out && state && fuse_new && !rel_tab && hd == 80 && cap_all <= 2048) {
         // (r5) plain decode steps of head size 80 at any batch size, same-box ms / token at batch 32: 256-key split kernel + merge 4.70,
         // 128-key up-front-load ranges + merge 4.61 (mode 1), 256-key ranges 4.38 (mode 2), one workgroup per head looping over 256-key
@@ -1300,7 +1309,7 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
         const int mode = g_attn_part32 != 1 ? g_attn_part32 : (batch * heads >= 2 * eilev_num_cu() ? 3 : 1);
         if (mode == 3) {
             hipLaunchKernelGGL((attn_decode_loop_kernel<10, 11, 256>), dim3(heads, batch), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc), const_cast<bf16 *>(vc), out,
-                               attn_mask, state, seq_len, cap, heads, ldq, out_frag);
+                               attn_mask, state, seq_len, cap, heads, ldq, out_frag, 1);
             EILEV_LAUNCH_CHECK();
             return EILEV_OK;
         }

@@ -1382,13 +1382,16 @@ static int t5_decode_impl(const EilevT5Dims *d, const EilevT5Weights *w, const i
         //  writes h and RMSNorm(h) in one launch (GemmArgs::ln_out with ln_beta == nullptr) — so only block 0 normalises here)
         if (!fuse_norm || l == 0) RC(launch_rmsnorm(b.h, D, (const bf16 *)L->ln_sa, b.x, D, M, D, d->eps, s));
         RC(t5_proj(b, b.x, D, L->q_w, L->k_w, L->v_w, I, b.qkv, 3 * I, M, s));
-        RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
-        RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
+        // (graph-replayed decode steps, round 5: the new token's K / V go into the cache inside the attention kernel — fuse_new, as in the OPT step)
+        if (!state) {
+            RC(launch_rows_to_cache(b.qkv, 3 * I, I, kc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
+            RC(launch_rows_to_cache(b.qkv, 3 * I, 2 * I, vc, (int)batch, (int)new_len, H, hd, (int)kv_capacity, (int)past_len, s, state));
+        }
         if (single) {
             // one query row per sequence: flash-decoding split kernel (keys 0 .. total - 1 of the cache, bias of a single row)
             if (state)  // kv_total = 1 + state[0] on the device; the table is this query's row (entry j = key j)
                 RC(launch_attn_decode(b.qkv, kc, vc, b.att, nullptr, state, (int)batch, 1, (int)kv_capacity, H, hd, b.scratch + skinny_f,
-                                      kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, -1));
+                                      kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, -1, 1));
             else
                 RC(launch_attn_decode(b.qkv, kc, vc, b.att, dec_mask, nullptr, (int)batch, (int)total, (int)kv_capacity, H, hd,
                                       b.scratch + skinny_f, kSkinnyScratch / 2, s, 3 * (int64_t)I, b.rel, total, (int)total - 1));
