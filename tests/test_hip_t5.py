@@ -184,10 +184,13 @@ def test_t5_decoder_mask_and_hidden_states(golden_dir):
     assert out.qformer_outputs.hidden_states is not None and out.vision_outputs.hidden_states is not None
 
 
-def test_t5_xl_widths_decode_equals_teacher_forcing():
+@pytest.mark.parametrize("B", [3, 16])
+def test_t5_xl_widths_decode_equals_teacher_forcing(B):
     """flan-t5-xl widths (d_model 2048, 32 heads x 64, d_ff 5120, vocab 32128; 2 + 2 layers), L = 300 with right padding:
     size-independent properties — cached single-step decoding == teacher forcing, and padded encoder positions do not
-    influence the logits."""
+    influence the logits.  B = 16 (round 5): 16 rows x 32 heads = 2 workgroups per CU — the cross-attention of a decode step runs on
+    attn_decode_loop_kernel<8, 8, 256> (two key ranges, the second ragged, one row with masked encoder positions); the graph-replayed greedy
+    loop (new keys / values stored by the self-attention kernel itself) gives the ids of the rows decoded one at a time."""
     import ctypes as C
 
     from eilev_amd.configs import blip2_config
@@ -202,7 +205,7 @@ def test_t5_xl_widths_decode_equals_teacher_forcing():
              for k, shp in state_dict_shapes(cfg).items() if k.startswith("language_model")}
     eng = HipEngine(cfg, named, device="cuda", parts=("t5",))
     torch.manual_seed(3)
-    B, L, T, D = 3, 300, 5, 2048
+    L, T, D = 300, 5, 2048
     emb = (0.5 * torch.randn(B, L, D, device="cuda")).to(torch.bfloat16)
     am = torch.ones(B, L, dtype=torch.int32, device="cuda")
     am[1, 250:] = 0
@@ -218,6 +221,11 @@ def test_t5_xl_widths_decode_equals_teacher_forcing():
     for i in range(T):
         step = eng.t5_decode(dec[:, i:i + 1], am, i, skv, T, ckv, L)
         assert rel_rms(host(step[:, 0]), host(full[:, i])) <= 1e-2, i
+    if B >= 16:
+        ids = eng.t5_greedy(emb, am, 6, eos_id=-1).cpu().numpy()
+        for r in (0, 1, B - 1):
+            one = eng.t5_greedy(emb[r:r + 1], am[r:r + 1], 6, eos_id=-1).cpu().numpy()
+            assert np.array_equal(ids[r], one[0]), (r, ids[r], one[0])
 
 
 @pytest.mark.parametrize("nm,nb,lp", [("beam5_lpm1", 5, -1.0), ("beam3_lp1", 3, 1.0)])
