@@ -618,7 +618,8 @@ template <int NCH, int VK, int KEYS>
 __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ kc, bf16 *__restrict__ vc,
                                                                bf16 *__restrict__ out, const int32_t *__restrict__ attn_mask,
                                                                const int32_t *__restrict__ state, int seq_len, int cap, int heads, int64_t ldq,
-                                                               int out_frag, int fuse_new) {
+                                                               int out_frag, int fuse_new, const float *__restrict__ rel_tab = nullptr,
+                                                               int64_t rel_hs = 0, int rel_off = 0) {
     // state == nullptr: kv_total = seq_len, given by the host (the flan-t5 cross-attention: keys = encoder positions, attn_mask = their
     // padding mask, q rows of stride ldq); fuse_new == 0: every key is in the cache already
     constexpr int hd = NCH * 8, G = 256 / NCH, RS = NCH + 1;
@@ -686,6 +687,8 @@ __global__ __launch_bounds__(256) void attn_decode_loop_kernel(const bf16 *__res
             float a = 0.0f;
 #pragma unroll
             for (int cc = 0; cc < NCH; ++cc) a += red[tid * RS + cc];
+            // (flan-t5 self-attention: per-head position bias over key - query position, the query at kv_total - 1; rel_off < 0: the table of this query row)
+            if (rel_tab) a += rel_tab[(int64_t)h * rel_hs + (rel_off >= 0 ? (jt - (kv_total - 1)) + rel_off : jt)];
             s = a;
         }
         const float mxw = wave_max(s);
@@ -1295,10 +1298,10 @@ int launch_attn_decode(const bf16 *qkv, const bf16 *kc, const bf16 *vc, bf16 *ou
             return EILEV_OK;
         }
     }
-    // (r5) hd 64 without a position bias (the flan-t5 cross-attention over 960 encoder keys: state == nullptr, nothing to store): the per-head loop too
-    if (g_attn_part32 == 1 && !anc && out && !rel_tab && hd == 64 && batch * heads >= 2 * eilev_num_cu()) {
+    // (r5) hd 64 (flan-t5: the cross-attention over 960 encoder keys — state == nullptr, nothing to store — and the self-attention with its position bias): the per-head loop too
+    if (g_attn_part32 == 1 && !anc && out && hd == 64 && batch * heads >= 2 * eilev_num_cu()) {
         hipLaunchKernelGGL((attn_decode_loop_kernel<8, 8, 256>), dim3(heads, batch), dim3(256), 0, s, qkv, const_cast<bf16 *>(kc), const_cast<bf16 *>(vc), out,
-                           attn_mask, state, seq_len, cap, heads, ldq, 0, fuse_new);
+                           attn_mask, state, seq_len, cap, heads, ldq, 0, fuse_new, rel_tab, rel_hs, rel_off);
         EILEV_LAUNCH_CHECK();
         return EILEV_OK;
     }
