@@ -50,9 +50,13 @@ OptLayer = _ptr_struct("OptLayer", OPT_LAYER_FIELDS)
 VitLayerFold = _ptr_struct("VitLayerFold", ["qkv_w", "qkv_b", "qkv_csum", "fc1_w", "fc1_b", "fc1_csum"])
 
 
+VitLayerFoldHm = _ptr_struct("VitLayerFoldHm", ["qkv_w", "qkv_b", "qkv_csum"])
+
+
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", vp), ("patch_b", vp), ("cls", vp), ("pos", vp), ("post_ln_w", vp),
-                ("post_ln_b", vp), ("layers", C.POINTER(VitLayer)), ("layers_fold", C.POINTER(VitLayerFold))]
+                ("post_ln_b", vp), ("layers", C.POINTER(VitLayer)), ("layers_fold", C.POINTER(VitLayerFold)),
+                ("layers_fold_hm", C.POINTER(VitLayerFoldHm)), ("qkv_hm_table", vp)]
 
 
 class QfWeights(C.Structure):
@@ -273,6 +277,22 @@ def attach_vit_fold(pack, per_layer):
     pack.vit.layers_fold = C.cast(arr, C.POINTER(VitLayerFold))
 
 
+def attach_vit_fold_hm(pack, per_layer, table_ptr):
+    """Point ``pack.vit`` at the block-ordered copies of the folded q|k|v matrices (EilevVitWeights.layers_fold_hm): per_layer =
+    [(w_ptr, b_ptr, csum_ptr), ...] + the device chunk table; ``per_layer=None`` detaches them."""
+    if per_layer is None:
+        pack._vit_layers_fold_hm = None
+        pack.vit.layers_fold_hm = None
+        pack.vit.qkv_hm_table = None
+        return
+    arr = (VitLayerFoldHm * len(per_layer))()
+    for i, (w, b, cs) in enumerate(per_layer):
+        arr[i].qkv_w, arr[i].qkv_b, arr[i].qkv_csum = w, b, cs
+    pack._vit_layers_fold_hm = arr
+    pack.vit.layers_fold_hm = C.cast(arr, C.POINTER(VitLayerFoldHm))
+    pack.vit.qkv_hm_table = table_ptr
+
+
 def attach_opt_stream(pack, per_layer, lm_head_ptr):
     """Point ``pack.opt`` at stream-layout copies of the decode matrices (eilev_stream_layout_pack): per_layer = [{"qkv": ptr or None,
     "o": ..., "fc1": ..., "fc2": ...}, ...]; ``per_layer=None`` detaches them."""
@@ -451,7 +471,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 14:
+    if lib.eilev_abi_version() != 15:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

@@ -828,6 +828,12 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
     if ((a.hd & 7) || a.hd > 128 || (a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 7) || ((uintptr_t)a.o & 15) || (a.q_hs & 7) ||
         (a.k_hs & 7) || (a.v_hs & 7) || (a.o_hs & 7) || (a.q_bs & 7) || (a.k_bs & 7) || (a.v_bs & 7) || (a.o_bs & 7))
         return EILEV_E_UNSUPPORTED;
+    if (a.hm) {  // the scattered q|k|v blocks (AttnArgs::hm): attn_frame3_kernel's HM form only
+        if (a.hd != 88 || a.sq != 257 || a.skv != 257 || a.causal || a.key_mask || a.rel_tab || a.drop_thr || (a.q_hs & 7) || (a.q_bs & 7) ||
+            a.q_hs != a.k_hs || a.q_hs != a.v_hs || (int64_t)a.sq * a.hd * 2 >= 0x7fff0000ll)
+            return EILEV_E_UNSUPPORTED;
+        return launch_attn_frame3<88, 17, true>(a, s);
+    }
     // whole-frame ViT attention: S = 257 (17 tiles of 16), hd = 88, no mask, q / k / v rows of one fused buffer
     if (!g_attn_force_v1 && !(a.dbg & 4) && !a.rel_tab && !a.drop_thr && a.hd == 88 && a.sq == a.skv && a.sq > 256 && a.sq <= 272 && !a.causal && !a.key_mask &&
         a.ldk == a.ldv && !(a.ldq & 3) && (int64_t)a.sq * a.ldk * 2 < 0x7fff0000ll) {

@@ -29,7 +29,9 @@ __device__ __forceinline__ void attn_static_for(F &&f) {
     attn_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int HD, int NT>
+// HM (round 5): q, k and v of a (frame, head) are each one block of [S][64] followed by [S][HD - 64] elements (what the q|k|v GEMM
+// writes with GemmArgs::hm_tab): an image is staged from two contiguous runs, the LDS image ([key][HD], compact) is unchanged.
+template <int HD, int NT, bool HM = false>
 __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
     constexpr int NW = 8;
     constexpr int CH = HD / 8, RS = HD * 2;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
     }(), "chunk / CH by multiply-shift");
     auto stage_piece = [&](const bf16 *src, int buf, int k) {
         const int ld2 = __builtin_amdgcn_readfirstlane((int)(a.ldk * 2));
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, (S - 1) * ld2 + HD * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, HM ? S * HD * 2 : (S - 1) * ld2 + HD * 2, 0x00020000);
         int ln = lane;
         asm volatile("" : "+v"(ln));  // opaque: the piece geometry is recomputed per call (a handful of VALU ops), not kept in registers
         int i = wid + NW * k;
@@ -73,6 +75,16 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         const int q0 = (i * 64) / CH, r0 = i * 64 - q0 * CH;  // wave-uniform
         const unsigned t = (unsigned)(ln + r0);
         const unsigned kq = __umul24(t, DIVM) >> DIVS;
+        if constexpr (HM) {
+            // chunk c = t - CH kq of key q0 + kq: c < 8 in the [S][64] block (128-byte rows), else in the [S][HD - 64] block behind it;
+            // keys past S - 1 (zeros in the LDS image) would land in the second block: sent outside the descriptor instead
+            const unsigned key = (unsigned)q0 + kq, c = t - __umul24(kq, CH);
+            const unsigned va = (key << 7) + (c << 4), vb = (unsigned)(S * 128 - 128) + __umul24(key, (HD - 64) * 2) + (c << 4);  // vb: (c - 8) * 16
+            unsigned voff = c < 8 ? va : vb;
+            voff = key < (unsigned)S ? voff : 0x7ffffff0u;
+            attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), voff);
+            return;
+        }
         // (q0 + kq) ld2 + 16 (t - CH kq) = kq (ld2 - 16 CH) + (q0 ld2 + 16 t): no remainder to form
         const unsigned voff = __umul24(kq, (unsigned)(ld2 - 16 * CH)) + ((unsigned)(q0 * ld2) + (t << 4));  // kq < 2^9, ld2 < 2^24
         attn_dma16(r, (lds_void_t *)(smem + buf * BUF + i * 1024), voff);
@@ -103,13 +115,16 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
         const int row = tile * 16 + l15o;
         // one descriptor per (frame, head): rows past S and head-dim slots past HD read 0 through the bounds / the offset trick below
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(a.q + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs), 0,
-                                                                            (int)(((int64_t)(S - 1) * a.ldq + HD) * 2), 0x00020000);
-        const unsigned rb = row < S ? __umul24((unsigned)row, (unsigned)(a.ldq * 2)) : 0x7ffffff0u;  // out of bounds -> 0 (row < 2^9, ldq < 2^23)
+                                                                            HM ? S * HD * 2 : (int)(((int64_t)(S - 1) * a.ldq + HD) * 2), 0x00020000);
+        const unsigned rb = row < S ? (HM ? (unsigned)row << 7 : __umul24((unsigned)row, (unsigned)(a.ldq * 2))) : 0x7ffffff0u;  // out of bounds -> 0 (row < 2^9, ldq < 2^23)
+        // HM: head dims 64 .. HD - 1 of a row live in the second block ([S][HD - 64] behind the [S][64] block)
+        const unsigned rb2 = row < S ? (unsigned)(S * 128) + __umul24((unsigned)row, (HD - 64) * 2) - 128u : 0x7ffffff0u;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = ks * 32 + 4 * go, d1 = d0 + 16;  // go < 4: only a slot whose LAST lane group passes HD needs the per-lane test
-            const unsigned o0 = (ks * 32 + 16 <= HD || d0 + 4 <= HD) ? rb + d0 * 2 : 0x7ffffff0u;
-            const unsigned o1 = (ks * 32 + 32 <= HD || d1 + 4 <= HD) ? rb + d1 * 2 : 0x7ffffff0u;
+            const unsigned base = (HM && ks >= 2) ? rb2 : rb;  // (rb2 + d * 2 with d >= 64: the - 128 above)
+            const unsigned o0 = (ks * 32 + 16 <= HD || d0 + 4 <= HD) ? base + d0 * 2 : 0x7ffffff0u;
+            const unsigned o1 = (ks * 32 + 32 <= HD || d1 + 4 <= HD) ? base + d1 * 2 : 0x7ffffff0u;
             asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(lo[ks]) : "v"(o0), "s"(rq));
             asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(hi[ks]) : "v"(o1), "s"(rq));
         }
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
 #undef FA_BARRIER
 }
 
-template <int HD, int NT>
+template <int HD, int NT, bool HM = false>
 int launch_attn_frame3(const AttnArgs &a, hipStream_t s) {
     constexpr int CH = HD / 8;
     constexpr int NPIECE = (NT * 16 * CH + (12 - CH) + 63) / 64;
@@ -650,7 +665,7 @@ int launch_attn_frame3(const AttnArgs &a, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_frame3_kernel<HD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_frame3_kernel<HD, NT, HM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         int dev = 0;
         EILEV_HIP_CHECK(hipGetDevice(&dev));
         EILEV_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -659,7 +674,7 @@ int launch_attn_frame3(const AttnArgs &a, hipStream_t s) {
     const int npairs = a.batch * a.heads;
     const int ncu = eilev_grid_cus() < num_cu ? eilev_grid_cus() : num_cu;
     const int grid = npairs < ncu ? npairs : ncu;
-    hipLaunchKernelGGL((attn_frame3_kernel<HD, NT>), dim3(grid), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((attn_frame3_kernel<HD, NT, HM>), dim3(grid), dim3(512), smem, s, a);
     EILEV_LAUNCH_CHECK();
     return EILEV_OK;
 }

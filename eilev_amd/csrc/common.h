@@ -180,6 +180,15 @@ struct GemmArgs {
     // Row-block layout of the <= 32 activation rows of a decode step (round 5; frag32_index below): only gemm_rows32_kernel reads (a_frag) or
     // writes (c_frag: plain bf16 epilogue; ln_frag: the LayerNorm rows that ride on a split-K reduce) it — any other kernel family refuses
     int a_frag = 0, c_frag = 0, ln_frag = 0;
+    // Scattered output of the ViT q|k|v projection (round 5): C is not [M][N].  Per frame of hm_tok token rows (frame stride hm_tok * N
+    // elements) the 8-column chunk j of a token row t goes to hm_tab[2 j] + t * hm_tab[2 j + 1] (elements): with the weight rows permuted
+    // to match (engine: ensure_vit_fold), every (q | k | v, head) owns a block [token][64] followed by a block [token][24] — the frame
+    // attention stages a head's 45-KB image from two contiguous runs (row-major rows: 257 segments of 176 bytes, 8448 bytes apart, each
+    // straddling 2-3 cache lines that the neighbouring heads fetch again), and a wave's store of 8 token rows x 64 columns is one contiguous
+    // kilobyte in the [token][64] blocks (a plain head-major [token][88] layout made it ~12 partial lines: profiles/r05_head_major_*).
+    // Only the folded-LayerNorm 16 x 16 instance of the persistent kernel writes it (hm_takes below); everything else refuses.
+    int hm_tok = 0;
+    const int32_t *hm_tab = nullptr;  // device memory, 2 * (N / 8) entries
     const bf16 *bias;   // [N] or null
     const bf16 *resid;  // [M, N] (ldr) or null; in patch mode: position table [1+group, N]
     int64_t ldr;
@@ -238,6 +247,11 @@ static inline bool pp4_all_lean(const GemmArgs &g) {
     const bool scale_ok = g.scale_cols == 0 || (g.scale_cols % 16 == 0 && g.epi == 0 && !g.resid && !g.ln_rows && !g.stat_out);
     return g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && scale_ok && !g.wscale && !g.ascale && !g.dbg && !g.trace;
 }
+// the launch can write the head-major q|k|v layout (GemmArgs::hm_tok)
+static inline bool hm_takes(const GemmArgs &g) {
+    return g.hm_tok > 0 && g.hm_tab && g.ln_rows && g.epi == 0 && !g.resid && !g.stat_out && !g.scale_cols && pp4_all_lean(g) && g.N % 64 == 0 &&
+           g.M % g.hm_tok == 0 && (int64_t)g.M * g.N * 2 < 0xfffffff0ll;
+}
 // gemv.hip: nn.Linear on M <= 8 rows as row dot products with the LayerNorm / flash-decoding merge in its prologue
 bool gemv_rows_ok(int M, int N, int K);
 int launch_gemv_rows(int pro, const bf16 *x, int64_t ldx, const bf16 *gamma, const bf16 *beta, float eps, const float *part, int heads, int hd,
@@ -288,6 +302,9 @@ struct AttnArgs {
     const float *rel_tab = nullptr;
     int64_t rel_hs = 0;
     int rel_off = 0, rel_n = 0;
+    // ViT frame attention on the scattered q|k|v of GemmArgs::hm_tab (round 5): q / k / v point at the first (frame, head) block of their
+    // plane, *_bs = frame stride, *_hs = block stride (S * hd); a block is [S][64] followed by [S][hd - 64] elements.  ld* are ignored.
+    int hm = 0;
     // dropout on the attention probabilities (training graph): element (b, h, i, j) is kept iff eilev_hash32(drop_seed, its linear
     // index) >= drop_thr, kept probabilities are scaled by drop_scale = 1 / (1 - p); drop_thr = 0: none
     uint32_t drop_thr = 0, drop_seed = 0;

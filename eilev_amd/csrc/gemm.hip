@@ -155,6 +155,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
     if (!g.A || !g.W || !g.C || g.N <= 0 || g.K <= 0) return EILEV_E_BADARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return EILEV_E_UNSUPPORTED;
     const bool dma_ok = g.K % 256 == 0 && (!(g.dbg & 8) || g.W8);
+    if (g.hm_tok && (!hm_takes(g) || (int64_t)g.M * g.lda * 2 >= 0x7fff0000ll)) return EILEV_E_UNSUPPORTED;  // head-major q|k|v: common.h hm_takes
     const bool ln_fold = g.ln_rows != nullptr || g.stat_out != nullptr;  // LayerNorm-folding variants: the persistent kernel only
     if (ln_fold && (g.W8 || g.wscale || g.out_f32 || g.patch_group || g.scale_cols || g.K % BK || (int64_t)g.N * g.ldw * 2 >= 0x7fff0000ll)) return EILEV_E_UNSUPPORTED;
     const bool skinny = (g.M <= 16 || (g.M <= 32 && dma_ok)) && g.patch_group == 0 && !ln_fold;

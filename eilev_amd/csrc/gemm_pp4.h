@@ -289,6 +289,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + coff, rows * (int)(g.ldc * 2));
         const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + cn0 + coff : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
         const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
+        // scattered q|k|v output (GemmArgs::hm_tok / hm_tab; the folded-LayerNorm consumer without activation only): the lane's 16-byte chunk of
+        // token row t goes to base + t * stride of its column chunk — fixed for the call; the row part walks 8 token rows per store
+#ifndef EILEV_HM_AUX
+#define EILEV_HM_AUX EILEV_ST_AUX
+#endif
+        constexpr bool HMI = LN == 1 && !RES && EPI == 0 && M16K == 1;
+        const bool hm = HMI && g.hm_tok != 0;  // (uniform)
+        __amdgpu_buffer_rsrc_t rch = rc;
+        unsigned hm_off = 0, hm_str2 = 0;  // byte offset of the lane's chunk in token row m0 = r0 + srow; bytes per token row of its block
+        int hm_t = 0;
+        if constexpr (HMI) {
+            if (hm) {
+                const int TOK = g.hm_tok;
+                const int2 ent = *reinterpret_cast<const int2 *>(g.hm_tab + 2 * (((cn0 + coff) >> 3) + schunk));
+                const int fw = __builtin_amdgcn_readfirstlane(r0 / TOK);  // frame of the wave's first row: offsets below stay inside 32 bits
+                const int m0 = r0 + srow, f0 = m0 / TOK;
+                hm_t = m0 - f0 * TOK;
+                hm_str2 = (unsigned)(ent.y * 2);
+                hm_off = (unsigned)(((f0 - fw) * TOK * g.N + ent.x + hm_t * ent.y) * 2);
+                const int64_t left = ((int64_t)g.M / TOK - fw) * TOK * g.N * 2;
+                rch = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)fw * TOK * g.N, (int)(unsigned)(left < 0xfffffff0ll ? left : 0xfffffff0ll));
+            }
+        }
         u32x4_t rv[4];
         auto res_load = [&](int u) {
 #pragma unroll
@@ -444,9 +467,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                     const int row = (h2 * 2 + b) * 8 + srow;
                     erb[b] = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((schunk ^ (row & 7)) << 4));
                 }
+                if (hm) {
+                    if constexpr (HMI) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const int RO = U * 32 + (h2 * 2 + b) * 8;  // row of this store relative to srow: < 128 < hm_tok, at most one frame step
+                            unsigned vo = hm_off + (unsigned)RO * hm_str2;
+                            if (hm_t + RO >= g.hm_tok) vo += (unsigned)(g.hm_tok * g.N * 2) - (unsigned)g.hm_tok * hm_str2;
+                            if (srow + RO >= rows) vo = 0xfffffff8u;  // past M: outside the descriptor, dropped
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rch, vo, 0, EILEV_HM_AUX);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rc, st_voff, (U * 32 + (h2 * 2 + b) * 8) * (int)(g.ldc * 2), EILEV_ST_AUX);
+                }
             }
             // Measured on gfx950 (round 2): with the next unit's arithmetic scheduled between these stores, a VALU write to the data
             // registers of a 128-bit buffer store issued the cycle before corrupted the first dword of the stored chunk (the "SGPR

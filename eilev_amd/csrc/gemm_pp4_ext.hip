@@ -5,6 +5,7 @@
 // The fp8-MFMA and LayerNorm-folding instances of the persistent kernel (called by launch_pp4 with its grid).
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s) {
     constexpr int smem = PP4_SMEM;
+    if (g.A8 && g.hm_tok) return EILEV_E_UNSUPPORTED;
     if (g.A8) {  // fp8 x fp8 on the fp8 MFMA: byte operands, K halved so that the kernel's 2-byte strides are byte strides
         static bool attr8 = false;
         if (!attr8) {
@@ -22,6 +23,7 @@ int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s) {
         EILEV_LAUNCH_CHECK();
         return EILEV_OK;
     }
+    if (g.hm_tok && !hm_takes(g)) return EILEV_E_UNSUPPORTED;  // head-major q|k|v: the 16 x 16 folded-LayerNorm consumer only (common.h)
     // LayerNorm-folding variants: consumer (qkv, fc1 + GELU) / producer (proj, fc2 with the residual)
     static bool attr_ln = false;
     if (!attr_ln) {

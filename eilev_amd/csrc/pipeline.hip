@@ -147,6 +147,7 @@ bool dims_ok_opt(const EilevDims *d) {
            (d->t_hidden / d->t_heads) % 8 == 0 && d->t_hidden / d->t_heads <= 128 && d->t_hidden <= 4096;
 }
 
+int g_vit_head_major = 1;  // probe / test switch (eilev_debug_vit_head_major, probe build): 0 = row-major q|k|v in every ViT launch
 constexpr size_t kSkinnyScratch = 16u << 20;  // halves: split-K partials of the decode GEMVs | flash-decoding partials (batch 32 x 40 heads x 9 key splits x (128 + 2) floats = 6 MB)
 
 }  // namespace
@@ -279,10 +280,23 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     for (int l = 0; l < d->v_layers; ++l) {
         const EilevVitLayer *L = &w->layers[l];
         const EilevVitLayerFold *LF = fold ? &w->layers_fold[l] : nullptr;
+        bool hm = false;  // this block's q|k|v scattered into per-head blocks (GemmArgs::hm_tab): large folded launches whose attention is attn_frame3_kernel
         if (fold && l > 0) {  // fc2 of the previous block left the row statistics of x: qkv reads the raw stream
             GemmArgs g = mk_gemm(x, D, LF->qkv_w, D, LF->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0);
             g.ln_rows = lnrows;
             g.ln_csum = LF->qkv_csum;
+            if (g_vit_head_major && w->layers_fold_hm && w->qkv_hm_table && F >= 512 && tok == 257 && hd == 88) {
+                const EilevVitLayerFoldHm *LH = &w->layers_fold_hm[l];  // the same folded matrix with its rows (output columns) in block order
+                GemmArgs gh = mk_gemm(x, D, LH->qkv_w, D, LH->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0);
+                gh.ln_rows = lnrows;
+                gh.ln_csum = LH->qkv_csum;
+                gh.hm_tok = (int)tok;
+                gh.hm_tab = w->qkv_hm_table;
+                if (LH->qkv_w && LH->qkv_csum && hm_takes(gh)) {
+                    g = gh;
+                    hm = true;
+                }
+            }
             RC(launch_gemm(g, 3, s));
         } else {
             if (!(l == 0 && ln0_done)) RC(launch_layernorm(x, D, (const bf16 *)L->ln1_w, (const bf16 *)L->ln1_b, ln, D, M, D, d->v_eps, s));
@@ -298,6 +312,11 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
         a.q_bs = a.k_bs = a.v_bs = tok * 3 * (int64_t)D; a.o_bs = tok * (int64_t)D;
         a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
         a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+        if (hm) {  // three planes per frame, one block of tok * hd elements per head ([tok][64] then [tok][24]: AttnArgs::hm)
+            a.k = qkv + tok * (int64_t)D; a.v = qkv + 2 * tok * (int64_t)D;
+            a.q_hs = a.k_hs = a.v_hs = tok * (int64_t)hd;
+            a.hm = 1;
+        }
         a.batch = (int)F; a.heads = H; a.sq = (int)tok; a.skv = (int)tok; a.hd = hd; a.scale = scale; a.causal = 0;
         a.key_mask = nullptr; a.mask_ld = 0;
         RC(launch_attention(a, s));
@@ -687,6 +706,7 @@ int opt_rows_head(const EilevDims *d, const EilevOptWeights *w, const OptBufs &b
 #ifdef EILEV_PROBES
 extern "C" int eilev_debug_decode_rows(int on) { g_decode_rows = on; return 0; }
 extern "C" int eilev_debug_decode_frag(int on) { g_decode_frag = on; return 0; }
+extern "C" int eilev_debug_vit_head_major(int on) { g_vit_head_major = on; return 0; }
 #endif
 namespace {
 int opt_prefill_impl(const EilevDims *d, const EilevOptWeights *w, const void *inputs_embeds, const int32_t *attn_mask, int64_t batch,

@@ -21,7 +21,7 @@ class HipEngine:
     """Runs the stages of VideoBlipForConditionalGeneration.forward/generate on gfx950 kernels."""
 
     def __init__(self, config, named_tensors: dict, device=None, parts=None, lm_weights: str = "bf16", vit_ln_fold: bool = True,
-                 decode_stream_layout: bool = True):
+                 decode_stream_layout: bool = True, vit_block_order: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = abi.load_hip()
@@ -52,6 +52,7 @@ class HipEngine:
         # LayerNorm folding of the ViT blocks (profiles/HISTORY.md §3f): the folded qkv / fc1 copies (+1.1 GB at ViT-g) are built lazily by the first
         # launch large enough to use them (>= 24576 token rows); vit_ln_fold=False keeps the LayerNorm kernels for every launch
         self.vit_ln_fold = bool(vit_ln_fold)
+        self.vit_block_order = bool(vit_block_order)
         self._vit_folded = False
         # Stream-layout copies of the OPT decode matrices (eilev_stream_layout_pack; + one copy of the language model's linears and of the
         # lm_head, 5.3 GB at OPT-2.7B): built lazily by the first greedy decode of 17..32 rows; decode_stream_layout=False keeps one copy
@@ -205,6 +206,43 @@ class HipEngine:
             per_layer.append(entry)
         self._vit_fold_keep = keep
         abi.attach_vit_fold(self.pack, per_layer)
+        self._attach_vit_block_order(per_layer)
+
+    def _attach_vit_block_order(self, per_layer):
+        """Second copy of the folded q|k|v matrices with their rows in BLOCK ORDER + the chunk table of include/eilev.h ABI 15 (+ 0.46 GB at
+        ViT-g): launches of >= 512 frames write q, k, v of a (frame, head) as [token][64] + [token][24] blocks, which the frame attention
+        stages as two contiguous runs (932 -> ~800 us per 1088 frames) and the GEMM stores as whole lines.  Only ViT-g's geometry (257
+        tokens, head size 88) takes it; `vit_block_order=False` keeps one copy."""
+        d = self.dims
+        hd = d.v_hidden // d.v_heads
+        if not self.vit_block_order or self.tokens_per_frame != 257 or hd != 88:
+            return
+        D, H, tok = d.v_hidden, d.v_heads, self.tokens_per_frame
+        lo, hi = 64, hd - 64
+        # new column order of a third: [h][0..63] for every head, then [h][64..hd-1]
+        third = torch.cat([torch.arange(H).repeat_interleave(lo) * hd + torch.arange(lo).repeat(H),
+                           torch.arange(H).repeat_interleave(hi) * hd + lo + torch.arange(hi).repeat(H)])
+        perm = torch.cat([p * D + third for p in range(3)]).to(self.device)
+        # chunk j (8 columns of the reordered output) of token t -> table[2 j] + t * table[2 j + 1] elements inside the frame's tok * 3 D region
+        base, stride = [], []
+        for p in range(3):
+            for h in range(H):
+                for c in range(lo // 8):
+                    base.append((p * H + h) * tok * hd + c * 8)
+                    stride.append(lo)
+            for h in range(H):
+                for c in range(hi // 8):
+                    base.append((p * H + h) * tok * hd + tok * lo + c * 8)
+                    stride.append(hi)
+        table = torch.tensor(list(zip(base, stride)), dtype=torch.int32).reshape(-1).to(self.device)
+        keep, per = [table], []
+        for i, entry in enumerate(per_layer):
+            wf, bf, cs = (t for t in self._vit_fold_keep[6 * i: 6 * i + 3])  # the folded q|k|v of block i (w, b, csum)
+            wp, bp, cp = wf.index_select(0, perm).contiguous(), bf.index_select(0, perm).contiguous(), cs.index_select(0, perm).contiguous()
+            keep += [wp, bp, cp]
+            per.append((wp.data_ptr(), bp.data_ptr(), cp.data_ptr()))
+        self._vit_hm_keep = keep
+        abi.attach_vit_fold_hm(self.pack, per, table.data_ptr())
 
     # ---- workspaces ----------------------------------------------------------------------------------
     def _workspace(self, tag, nbytes):

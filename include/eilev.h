@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 14  /* 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
+#define EILEV_ABI_VERSION 15  /* 15: EilevVitWeights.layers_fold_hm / qkv_hm_table (round 5); 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -94,7 +94,21 @@ typedef struct EilevVitWeights {
      * the same function; the bf16 rounding the reference puts on the LayerNorm output sits on gamma (.) W instead).  `layers`
      * stays required (smaller launches, the debug outputs and block 0's layer_norm1 use it). */
     const EilevVitLayerFold *layers_fold;
+    /* ABI version 15.  NULL, or (with layers_fold) a host array of v_layers entries: the folded q|k|v matrix of a block once more with its
+     * ROWS (= output columns) reordered, per q | k | v third, as [head 0 dims 0..63, head 1 dims 0..63, ..., head 0 dims 64.., head 1 dims
+     * 64.., ...], and qkv_hm_table: device memory, 2 * (3 Dv / 8) int32 — for the 8-column chunk j of the reordered output (element offset
+     * inside a frame of tokens_per_frame rows, elements per token row): chunk j of token t goes to table[2 j] + t * table[2 j + 1] in a frame
+     * region of tokens_per_frame * 3 Dv elements.  The engine's table gives every (q | k | v, head) one block [token][64] followed by
+     * [token][head_dim - 64].  Used by launches of >= 512 frames with 257 tokens and head size 88 (the frame attention then stages a head's
+     * image from two contiguous runs); everything else runs from `layers_fold` / `layers`.  Same values, same arithmetic. */
+    const struct EilevVitLayerFoldHm *layers_fold_hm;
+    const int32_t *qkv_hm_table;
 } EilevVitWeights;
+
+typedef struct EilevVitLayerFoldHm {
+    const void *qkv_w, *qkv_b;
+    const float *qkv_csum;
+} EilevVitLayerFoldHm;
 
 /* One Q-Former block: hf Blip2QFormerLayer (modeling_blip_2.py:701-752). cross_* are NULL on
  * layers without cross-attention (layer_idx % q_cross_freq != 0). */
@@ -274,6 +288,7 @@ void eilev_debug_ln_fold_min_rows(int64_t rows);
  *   eilev_debug_grid_cus : int (int)          persistent kernels size their grids for n CUs (a CU-masked stream: tools/overlap_probe.py); 0 = all
  *   eilev_debug_beam_part : int (int)         0: beam-search attention at <= 8 rows through the 256-key split kernel (round 3); 1 (default): 128-key ranges
  *   eilev_debug_attn_part32 : int (int)       plain decode attention of head size 80: 0 the 256-key split kernel; 1 (default) by batch size; 2 / 3 force the 256-key ranges / the per-head loop
+ *   eilev_debug_vit_head_major : int (int)    0: row-major q|k|v rows in every ViT launch; 1 (default): per-head blocks in launches of >= 512 frames (layers_fold_hm)
  *   eilev_debug_decode_frag : int (int)       0: row-major activations inside the 17..32-row decode step; 1 (default): the row-block layout where every kernel of the block supports it */
 
 /* fp8 ACTIVATIONS x fp8 weights on the fp8 MFMA (BASELINE configs[4] "fp8 MFMA weights"; v_mfma_f32_32x32x64_f8f6f4, twice the

@@ -220,3 +220,43 @@ def test_batch_decode_step_at_real_widths_vs_oracle(B, L):
     for b in range(B):
         assert rel_rms(got[b], ref[b]) <= 1e-2, (b, rel_rms(got[b], ref[b]))
     assert np.array_equal(out[:, 1].cpu().numpy(), got.argmax(-1))
+
+
+def test_vit_head_major_qkv_launch(probes):
+    """Round 5: in ViT launches of >= 512 frames the folded q|k|v GEMM of every block but the first scatters its output into per-head blocks
+    ([frame][q, k, v][head]: [token][64] then [token][24]; weight rows reordered to match, include/eilev.h ABI 15) and attn_frame3_kernel's HM
+    form stages a head's image from the two contiguous runs.  Three blocks at ViT-g widths, 544 frames: the same bits as the row-major launch
+    (probe-build switch), and the small-tile 2-frame launches that the real_b1 fixture pins to the reference."""
+    import ctypes as C
+
+    cfg, _, eng = models("real_vit_3l")
+    d = eng.dims
+    frames = 544
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    px = torch.randn((frames // 8, 3, 8, 224, 224), device="cuda", generator=g).clamp_(-2.5, 2.5).to(torch.bfloat16)
+    eng.ensure_vit_fold()
+    assert eng.pack.vit.layers_fold_hm and eng.pack.vit.qkv_hm_table
+    ws = torch.empty(int(probes.eilev_vit_workspace_bytes(C.byref(d), frames // 8, 8)), dtype=torch.uint8, device="cuda")
+    outs = {}
+    try:
+        for hm in (0, 1):
+            probes.eilev_debug_vit_head_major(hm)
+            out = torch.empty((frames // 8, 8 * 257, d.v_hidden), dtype=torch.bfloat16, device="cuda")
+            assert probes.eilev_vit_forward(C.byref(d), C.byref(eng.pack.vit), P(px), 1, frames // 8, 8, P(out), None, P(ws), ws.numel(), stream_ptr()) == 0
+            torch.cuda.synchronize()
+            outs[hm] = out
+    finally:
+        probes.eilev_debug_vit_head_major(1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    big = eng.vit(px)  # the product library: head-major by default
+    assert torch.equal(big, outs[1])
+    worst = 0.0
+    for c in (0, 33, 67):
+        small = eng.vit(px[c:c + 1, :, :2])
+        a, b = host(big[c, : 2 * 257]), host(small[0])
+        worst = max(worst, rel_rms(a, b))
+        assert np.abs(a - b).max() <= 2.0 ** -5 * max(1.0, float(np.abs(b).max())), c
+    record_parity("vit_head_major_launch", relrms_vs_small_launch=worst)
+    assert worst <= 6e-3
