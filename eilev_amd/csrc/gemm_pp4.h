@@ -297,8 +297,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         constexpr bool HMI = LN == 1 && !RES && EPI == 0 && M16K == 1;
         const bool hm = HMI && g.hm_tok != 0;  // (uniform)
         __amdgpu_buffer_rsrc_t rch = rc;
-        unsigned hm_off = 0, hm_str2 = 0;  // byte offset of the lane's chunk in token row m0 = r0 + srow; bytes per token row of its block
-        int hm_t = 0;
+        unsigned hm_off = 0, hm_off_w = 0;  // byte offset of the lane's chunk in token row m0 = r0 + srow, and the same one frame step further
+        int hm_str2 = 0, hm_t = 0;           // bytes per token row of the wave's block (uniform: a wave's 64 columns lie in one kind of block)
         if constexpr (HMI) {
             if (hm) {
                 const int TOK = g.hm_tok;
@@ -306,8 +306,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 const int fw = __builtin_amdgcn_readfirstlane(r0 / TOK);  // frame of the wave's first row: offsets below stay inside 32 bits
                 const int m0 = r0 + srow, f0 = m0 / TOK;
                 hm_t = m0 - f0 * TOK;
-                hm_str2 = (unsigned)(ent.y * 2);
+                hm_str2 = __builtin_amdgcn_readfirstlane(ent.y * 2);
                 hm_off = (unsigned)(((f0 - fw) * TOK * g.N + ent.x + hm_t * ent.y) * 2);
+                hm_off_w = hm_off + (unsigned)(TOK * g.N * 2) - (unsigned)(TOK * hm_str2);
+                // rows past M lie in frames past the descriptor's range (M % TOK == 0): dropped without a test
                 const int64_t left = ((int64_t)g.M / TOK - fw) * TOK * g.N * 2;
                 rch = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)fw * TOK * g.N, (int)(unsigned)(left < 0xfffffff0ll ? left : 0xfffffff0ll));
             }
@@ -472,9 +474,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             const int RO = U * 32 + (h2 * 2 + b) * 8;  // row of this store relative to srow: < 128 < hm_tok, at most one frame step
-                            unsigned vo = hm_off + (unsigned)RO * hm_str2;
-                            if (hm_t + RO >= g.hm_tok) vo += (unsigned)(g.hm_tok * g.N * 2) - (unsigned)g.hm_tok * hm_str2;
-                            if (srow + RO >= rows) vo = 0xfffffff8u;  // past M: outside the descriptor, dropped
+                            // (the whole offset in the VECTOR operand: that is the part the descriptor's range check sees)
+                            const unsigned vo = (hm_t + RO >= g.hm_tok ? hm_off_w : hm_off) + (unsigned)(RO * hm_str2);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rch, vo, 0, EILEV_HM_AUX);
                         }
                     }
