@@ -474,9 +474,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             const int RO = U * 32 + (h2 * 2 + b) * 8;  // row of this store relative to srow: < 128 < hm_tok, at most one frame step
-                            // (the whole offset in the VECTOR operand: that is the part the descriptor's range check sees)
-                            const unsigned vo = (hm_t + RO >= g.hm_tok ? hm_off_w : hm_off) + (unsigned)(RO * hm_str2);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rch, vo, 0, EILEV_HM_AUX);
+                            // the row part RO * stride rides in the scalar offset (range-checked with the rest on gfx950: tools/probes/canary_rows_past_m.py)
+                            const unsigned vo = hm_t + RO >= g.hm_tok ? hm_off_w : hm_off;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, erb[b]), rch, vo, RO * hm_str2, EILEV_HM_AUX);
                         }
                     }
                 } else {
