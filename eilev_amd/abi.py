@@ -56,7 +56,7 @@ VitLayerFoldHm = _ptr_struct("VitLayerFoldHm", ["qkv_w", "qkv_b", "qkv_csum"])
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", vp), ("patch_b", vp), ("cls", vp), ("pos", vp), ("post_ln_w", vp),
                 ("post_ln_b", vp), ("layers", C.POINTER(VitLayer)), ("layers_fold", C.POINTER(VitLayerFold)),
-                ("layers_fold_hm", C.POINTER(VitLayerFoldHm)), ("qkv_hm_table", vp)]
+                ("layers_fold_hm", C.POINTER(VitLayerFoldHm))]
 
 
 class QfWeights(C.Structure):
@@ -277,20 +277,18 @@ def attach_vit_fold(pack, per_layer):
     pack.vit.layers_fold = C.cast(arr, C.POINTER(VitLayerFold))
 
 
-def attach_vit_fold_hm(pack, per_layer, table_ptr):
+def attach_vit_fold_hm(pack, per_layer):
     """Point ``pack.vit`` at the block-ordered copies of the folded q|k|v matrices (EilevVitWeights.layers_fold_hm): per_layer =
-    [(w_ptr, b_ptr, csum_ptr), ...] + the device chunk table; ``per_layer=None`` detaches them."""
+    [(w_ptr, b_ptr, csum_ptr), ...]; ``per_layer=None`` detaches them."""
     if per_layer is None:
         pack._vit_layers_fold_hm = None
         pack.vit.layers_fold_hm = None
-        pack.vit.qkv_hm_table = None
         return
     arr = (VitLayerFoldHm * len(per_layer))()
     for i, (w, b, cs) in enumerate(per_layer):
         arr[i].qkv_w, arr[i].qkv_b, arr[i].qkv_csum = w, b, cs
     pack._vit_layers_fold_hm = arr
     pack.vit.layers_fold_hm = C.cast(arr, C.POINTER(VitLayerFoldHm))
-    pack.vit.qkv_hm_table = table_ptr
 
 
 def attach_opt_stream(pack, per_layer, lm_head_ptr):

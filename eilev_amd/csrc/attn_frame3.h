@@ -30,7 +30,7 @@ __device__ __forceinline__ void attn_static_for(F &&f) {
 }
 
 // HM (round 5): q, k and v of a (frame, head) are each one block of [S][64] followed by [S][HD - 64] elements (what the q|k|v GEMM
-// writes with GemmArgs::hm_tab): an image is staged from two contiguous runs, the LDS image ([key][HD], compact) is unchanged.
+// writes with GemmArgs::hm_tok): an image is staged from two contiguous runs, the LDS image ([key][HD], compact) is unchanged.
 template <int HD, int NT, bool HM = false>
 __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
     constexpr int NW = 8;

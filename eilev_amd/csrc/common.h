@@ -180,15 +180,14 @@ struct GemmArgs {
     // Row-block layout of the <= 32 activation rows of a decode step (round 5; frag32_index below): only gemm_rows32_kernel reads (a_frag) or
     // writes (c_frag: plain bf16 epilogue; ln_frag: the LayerNorm rows that ride on a split-K reduce) it — any other kernel family refuses
     int a_frag = 0, c_frag = 0, ln_frag = 0;
-    // Scattered output of the ViT q|k|v projection (round 5): C is not [M][N].  Per frame of hm_tok token rows (frame stride hm_tok * N
-    // elements) the 8-column chunk j of a token row t goes to hm_tab[2 j] + t * hm_tab[2 j + 1] (elements): with the weight rows permuted
-    // to match (engine: ensure_vit_fold), every (q | k | v, head) owns a block [token][64] followed by a block [token][24] — the frame
+    // Scattered output of the ViT q|k|v projection (round 5): C is not [M][N].  With the weight rows reordered so that, per third of N, the output
+    // columns are [head h dims 0..63] for all hm_heads heads and then [head h dims 64..hm_hd-1] for all heads (engine: ensure_vit_fold), the
+    // epilogue gives every (frame, q | k | v, head) one block of hm_tok * hm_hd elements: [token][64] followed by [token][hm_hd - 64].  The frame
     // attention stages a head's 45-KB image from two contiguous runs (row-major rows: 257 segments of 176 bytes, 8448 bytes apart, each
-    // straddling 2-3 cache lines that the neighbouring heads fetch again), and a wave's store of 8 token rows x 64 columns is one contiguous
-    // kilobyte in the [token][64] blocks (a plain head-major [token][88] layout made it ~12 partial lines: profiles/r05_head_major_*).
+    // straddling 2-3 cache lines that the neighbouring heads fetch again), and a wave's store of 8 token rows x 64 columns of a [token][64]
+    // block is one contiguous kilobyte (a plain head-major [token][88] layout made every store ~12 partial lines: profiles/r05_head_major_*).
     // Only the folded-LayerNorm 16 x 16 instance of the persistent kernel writes it (hm_takes below); everything else refuses.
-    int hm_tok = 0;
-    const int32_t *hm_tab = nullptr;  // device memory, 2 * (N / 8) entries
+    int hm_tok = 0, hm_heads = 0, hm_hd = 0;
     const bf16 *bias;   // [N] or null
     const bf16 *resid;  // [M, N] (ldr) or null; in patch mode: position table [1+group, N]
     int64_t ldr;
@@ -249,8 +248,8 @@ static inline bool pp4_all_lean(const GemmArgs &g) {
 }
 // the launch can write the head-major q|k|v layout (GemmArgs::hm_tok)
 static inline bool hm_takes(const GemmArgs &g) {
-    return g.hm_tok > 0 && g.hm_tab && g.ln_rows && g.epi == 0 && !g.resid && !g.stat_out && !g.scale_cols && pp4_all_lean(g) && g.N % 64 == 0 &&
-           g.M % g.hm_tok == 0 && (int64_t)g.M * g.N * 2 < 0xfffffff0ll;
+    return g.hm_tok > 0 && g.hm_heads > 0 && g.hm_hd > 64 && g.hm_hd % 8 == 0 && g.N == 3 * g.hm_heads * g.hm_hd && g.ln_rows && g.epi == 0 && !g.resid &&
+           !g.stat_out && !g.scale_cols && pp4_all_lean(g) && g.N % 64 == 0 && g.M % g.hm_tok == 0 && (int64_t)g.M * g.N * 2 < 0xfffffff0ll;
 }
 // gemv.hip: nn.Linear on M <= 8 rows as row dot products with the LayerNorm / flash-decoding merge in its prologue
 bool gemv_rows_ok(int M, int N, int K);
@@ -302,7 +301,7 @@ struct AttnArgs {
     const float *rel_tab = nullptr;
     int64_t rel_hs = 0;
     int rel_off = 0, rel_n = 0;
-    // ViT frame attention on the scattered q|k|v of GemmArgs::hm_tab (round 5): q / k / v point at the first (frame, head) block of their
+    // ViT frame attention on the scattered q|k|v of GemmArgs::hm_tok (round 5): q / k / v point at the first (frame, head) block of their
     // plane, *_bs = frame stride, *_hs = block stride (S * hd); a block is [S][64] followed by [S][hd - 64] elements.  ld* are ignored.
     int hm = 0;
     // dropout on the attention probabilities (training graph): element (b, h, i, j) is kept iff eilev_hash32(drop_seed, its linear

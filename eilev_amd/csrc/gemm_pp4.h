@@ -289,8 +289,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(reinterpret_cast<bf16 *>(g.C) + (int64_t)r0 * g.ldc + cn0 + coff, rows * (int)(g.ldc * 2));
         const __amdgpu_buffer_rsrc_t rr = uniform_rsrc(RES ? g.resid + (int64_t)r0 * g.ldr + cn0 + coff : g.A, RES ? rows * (int)(g.ldr * 2) : 0);
         const unsigned st_voff = (unsigned)srow * (unsigned)(g.ldc * 2) + schunk * 16, rs_voff = (unsigned)srow * (unsigned)(g.ldr * 2) + schunk * 16;
-        // scattered q|k|v output (GemmArgs::hm_tok / hm_tab; the folded-LayerNorm consumer without activation only): the lane's 16-byte chunk of
-        // token row t goes to base + t * stride of its column chunk — fixed for the call; the row part walks 8 token rows per store
+        // scattered q|k|v output (GemmArgs::hm_tok; the folded-LayerNorm consumer without activation only): the lane's 16-byte chunk of token row t
+        // goes to its head's block — the column part is fixed for the call and computed here (a table in memory put a dependent global load of
+        // ~1.5 us in front of the first store of every tile: the q|k|v GEMM +45 us), the row part walks 8 token rows per store
 #ifndef EILEV_HM_AUX
 #define EILEV_HM_AUX EILEV_ST_AUX
 #endif
@@ -301,8 +302,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         int hm_str2 = 0, hm_t = 0;           // bytes per token row of the wave's block (uniform: a wave's 64 columns lie in one kind of block)
         if constexpr (HMI) {
             if (hm) {
-                const int TOK = g.hm_tok;
-                const int2 ent = *reinterpret_cast<const int2 *>(g.hm_tab + 2 * (((cn0 + coff) >> 3) + schunk));
+                const int TOK = g.hm_tok, HD = g.hm_hd, NH = g.hm_heads, D3 = g.N / 3;
+                const int n0 = cn0 + coff;  // the wave's 64 columns (uniform): all in [token][64] blocks or all in [token][HD - 64] blocks
+                const int plane = __builtin_amdgcn_readfirstlane(n0 / D3), rr = n0 - plane * D3;
+                int2 ent;  // (element offset inside the frame of the lane's chunk in token row 0, elements per token row of its block)
+                if (rr < NH * 64) {
+                    ent.x = (plane * NH + (rr >> 6)) * TOK * HD + schunk * 8;
+                    ent.y = 64;
+                } else {  // chunk jb of the second part: head jb / CPH, chunk jb % CPH of its (HD - 64)-wide rows
+                    const int cph = (HD - 64) >> 3, jb = ((rr - NH * 64) >> 3) + schunk, hh = jb / cph;
+                    ent.x = (plane * NH + hh) * TOK * HD + TOK * 64 + (jb - hh * cph) * 8;
+                    ent.y = HD - 64;
+                }
                 const int fw = __builtin_amdgcn_readfirstlane(r0 / TOK);  // frame of the wave's first row: offsets below stay inside 32 bits
                 const int m0 = r0 + srow, f0 = m0 / TOK;
                 hm_t = m0 - f0 * TOK;

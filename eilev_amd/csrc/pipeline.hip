@@ -280,18 +280,19 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     for (int l = 0; l < d->v_layers; ++l) {
         const EilevVitLayer *L = &w->layers[l];
         const EilevVitLayerFold *LF = fold ? &w->layers_fold[l] : nullptr;
-        bool hm = false;  // this block's q|k|v scattered into per-head blocks (GemmArgs::hm_tab): large folded launches whose attention is attn_frame3_kernel
+        bool hm = false;  // this block's q|k|v scattered into per-head blocks (GemmArgs::hm_tok): large folded launches whose attention is attn_frame3_kernel
         if (fold && l > 0) {  // fc2 of the previous block left the row statistics of x: qkv reads the raw stream
             GemmArgs g = mk_gemm(x, D, LF->qkv_w, D, LF->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0);
             g.ln_rows = lnrows;
             g.ln_csum = LF->qkv_csum;
-            if (g_vit_head_major && w->layers_fold_hm && w->qkv_hm_table && F >= 512 && tok == 257 && hd == 88) {
+            if (g_vit_head_major && w->layers_fold_hm && F >= 512 && tok == 257 && hd == 88) {
                 const EilevVitLayerFoldHm *LH = &w->layers_fold_hm[l];  // the same folded matrix with its rows (output columns) in block order
                 GemmArgs gh = mk_gemm(x, D, LH->qkv_w, D, LH->qkv_b, nullptr, 0, qkv, 3 * D, M, 3 * D, D, 0);
                 gh.ln_rows = lnrows;
                 gh.ln_csum = LH->qkv_csum;
                 gh.hm_tok = (int)tok;
-                gh.hm_tab = w->qkv_hm_table;
+                gh.hm_heads = H;
+                gh.hm_hd = hd;
                 if (LH->qkv_w && LH->qkv_csum && hm_takes(gh)) {
                     g = gh;
                     hm = true;

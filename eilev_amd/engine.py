@@ -209,7 +209,7 @@ class HipEngine:
         self._attach_vit_block_order(per_layer)
 
     def _attach_vit_block_order(self, per_layer):
-        """Second copy of the folded q|k|v matrices with their rows in BLOCK ORDER + the chunk table of include/eilev.h ABI 15 (+ 0.46 GB at
+        """Second copy of the folded q|k|v matrices with their rows in BLOCK ORDER (include/eilev.h ABI 15; + 0.46 GB at
         ViT-g): launches of >= 512 frames write q, k, v of a (frame, head) as [token][64] + [token][24] blocks, which the frame attention
         stages as two contiguous runs (932 -> ~800 us per 1088 frames) and the GEMM stores as whole lines.  Only ViT-g's geometry (257
         tokens, head size 88) takes it; `vit_block_order=False` keeps one copy."""
@@ -223,26 +223,14 @@ class HipEngine:
         third = torch.cat([torch.arange(H).repeat_interleave(lo) * hd + torch.arange(lo).repeat(H),
                            torch.arange(H).repeat_interleave(hi) * hd + lo + torch.arange(hi).repeat(H)])
         perm = torch.cat([p * D + third for p in range(3)]).to(self.device)
-        # chunk j (8 columns of the reordered output) of token t -> table[2 j] + t * table[2 j + 1] elements inside the frame's tok * 3 D region
-        base, stride = [], []
-        for p in range(3):
-            for h in range(H):
-                for c in range(lo // 8):
-                    base.append((p * H + h) * tok * hd + c * 8)
-                    stride.append(lo)
-            for h in range(H):
-                for c in range(hi // 8):
-                    base.append((p * H + h) * tok * hd + tok * lo + c * 8)
-                    stride.append(hi)
-        table = torch.tensor(list(zip(base, stride)), dtype=torch.int32).reshape(-1).to(self.device)
-        keep, per = [table], []
+        keep, per = [], []
         for i, entry in enumerate(per_layer):
             wf, bf, cs = (t for t in self._vit_fold_keep[6 * i: 6 * i + 3])  # the folded q|k|v of block i (w, b, csum)
             wp, bp, cp = wf.index_select(0, perm).contiguous(), bf.index_select(0, perm).contiguous(), cs.index_select(0, perm).contiguous()
             keep += [wp, bp, cp]
             per.append((wp.data_ptr(), bp.data_ptr(), cp.data_ptr()))
         self._vit_hm_keep = keep
-        abi.attach_vit_fold_hm(self.pack, per, table.data_ptr())
+        abi.attach_vit_fold_hm(self.pack, per)
 
     # ---- workspaces ----------------------------------------------------------------------------------
     def _workspace(self, tag, nbytes):

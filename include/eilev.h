@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 15  /* 15: EilevVitWeights.layers_fold_hm / qkv_hm_table (round 5); 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
+#define EILEV_ABI_VERSION 15  /* 15: EilevVitWeights.layers_fold_hm (round 5); 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -96,13 +96,11 @@ typedef struct EilevVitWeights {
     const EilevVitLayerFold *layers_fold;
     /* ABI version 15.  NULL, or (with layers_fold) a host array of v_layers entries: the folded q|k|v matrix of a block once more with its
      * ROWS (= output columns) reordered, per q | k | v third, as [head 0 dims 0..63, head 1 dims 0..63, ..., head 0 dims 64.., head 1 dims
-     * 64.., ...], and qkv_hm_table: device memory, 2 * (3 Dv / 8) int32 — for the 8-column chunk j of the reordered output (element offset
-     * inside a frame of tokens_per_frame rows, elements per token row): chunk j of token t goes to table[2 j] + t * table[2 j + 1] in a frame
-     * region of tokens_per_frame * 3 Dv elements.  The engine's table gives every (q | k | v, head) one block [token][64] followed by
-     * [token][head_dim - 64].  Used by launches of >= 512 frames with 257 tokens and head size 88 (the frame attention then stages a head's
-     * image from two contiguous runs); everything else runs from `layers_fold` / `layers`.  Same values, same arithmetic. */
+     * 64.., ...].  Launches of >= 512 frames with 257 tokens and head size 88 then write q, k, v of a (frame, head) as one block [token][64]
+     * followed by [token][head_dim - 64] (frame region: tokens_per_frame * 3 Dv elements, thirds in the order q, k, v, heads in order) and
+     * the frame attention stages a head's image from two contiguous runs; everything else runs from `layers_fold` / `layers`.  Same values,
+     * same arithmetic, bit-identical image_embeds. */
     const struct EilevVitLayerFoldHm *layers_fold_hm;
-    const int32_t *qkv_hm_table;
 } EilevVitWeights;
 
 typedef struct EilevVitLayerFoldHm {

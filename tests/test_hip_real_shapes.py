@@ -236,7 +236,7 @@ def test_vit_head_major_qkv_launch(probes):
     g.manual_seed(9)
     px = torch.randn((frames // 8, 3, 8, 224, 224), device="cuda", generator=g).clamp_(-2.5, 2.5).to(torch.bfloat16)
     eng.ensure_vit_fold()
-    assert eng.pack.vit.layers_fold_hm and eng.pack.vit.qkv_hm_table
+    assert eng.pack.vit.layers_fold_hm
     ws = torch.empty(int(probes.eilev_vit_workspace_bytes(C.byref(d), frames // 8, 8)), dtype=torch.uint8, device="cuda")
     outs = {}
     try:
