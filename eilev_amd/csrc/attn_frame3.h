@@ -298,6 +298,9 @@ __global__ __launch_bounds__(512) void attn_frame3_kernel(const AttnArgs a) {
             const int d0 = 32 * m + (go & 1) * 16 + (go >> 1) * 8;
             const bf16x8 v8 = {lo.v[0], lo.v[1], lo.v[2], lo.v[3], hi.v[0], hi.v[1], hi.v[2], hi.v[3]};
             // rows past S and d past HD are dropped by the offset (out of the descriptor's range)
+#ifdef EILEV_PROBES
+            if (a.dbg & 2048) continue;  // TIMING PROBE (no output): the kernel without its O stores
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_o, v8), ro, (row < S && d0 + 8 <= HD) ? ob_off + 64 * m : 0x7ffffff0u, 0, 0);
         }
     };
