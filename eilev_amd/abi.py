@@ -56,7 +56,7 @@ VitLayerFoldHm = _ptr_struct("VitLayerFoldHm", ["qkv_w", "qkv_b", "qkv_csum"])
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", vp), ("patch_b", vp), ("cls", vp), ("pos", vp), ("post_ln_w", vp),
                 ("post_ln_b", vp), ("layers", C.POINTER(VitLayer)), ("layers_fold", C.POINTER(VitLayerFold)),
-                ("layers_fold_hm", C.POINTER(VitLayerFoldHm))]
+                ("layers_fold_hm", C.POINTER(VitLayerFoldHm)), ("fold_min_rows", C.c_int64)]
 
 
 class QfWeights(C.Structure):
@@ -262,7 +262,7 @@ EXPORTS = [
     "eilev_rmsnorm_bwd", "eilev_gated_gelu", "eilev_gated_gelu_bwd", "eilev_dropout_add", "eilev_attention_dropout",
     "eilev_attention_dropout_bwd", "eilev_comm_bind", "eilev_comm_unique_id", "eilev_comm_init", "eilev_comm_destroy",
     "eilev_gather_clip_tokens", "eilev_exchange_clip_tokens", "eilev_fold_layernorm", "eilev_linear_stats", "eilev_ln_finalize",
-    "eilev_linear_lnfold", "eilev_debug_ln_fold_min_rows", "eilev_stream_layout_pack",
+    "eilev_linear_lnfold", "eilev_stream_layout_pack",
 ]
 
 
@@ -353,8 +353,6 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.eilev_ln_finalize.argtypes = [vp, i64, i64, f32, vp, vp]
     lib.eilev_linear_lnfold.restype = i32
     lib.eilev_linear_lnfold.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
-    lib.eilev_debug_ln_fold_min_rows.restype = None
-    lib.eilev_debug_ln_fold_min_rows.argtypes = [i64]
     lib.eilev_linear_a8w8.restype = i32
     lib.eilev_linear_a8w8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.eilev_process_workspace_bytes.restype = sz
@@ -469,7 +467,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 def load_library(path: str) -> C.CDLL:
     lib = bind(C.CDLL(path))
-    if lib.eilev_abi_version() != 15:
+    if lib.eilev_abi_version() != 16:
         raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 

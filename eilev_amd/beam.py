@@ -182,7 +182,7 @@ def beam_search_device(step_dev, logits_buf: torch.Tensor, first_logits: torch.T
 @torch.no_grad()
 def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
                 eos_id=-1, pad_id: int = 1, early_stopping=False, num_return_sequences: int = 1, sampler: dict | None = None,
-                min_new_tokens: int = 0, processors=None, stopping=None, prefix: torch.Tensor | None = None) -> torch.Tensor:
+                min_new_tokens: int = 0, processors=None, stopping=None, prefix: torch.Tensor | None = None, fill_id: int | None = None) -> torch.Tensor:
     """``first_logits``: (batch, vocab) fp32 from the prefill.  Returns int64 (batch * num_return_sequences, n_generated).
 
     ``sampler`` (``generate(num_beams > 1, do_sample=True)``, hf `_get_top_k_continuations`): the 2K continuations of a step are DRAWN
@@ -204,7 +204,8 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
 
     # hf `_beam_search`: `output_fill_value = pad_token_id or eos_token_id[0] if eos_token_id is not None else -1` — without an EOS id the unused
     # tail of a hypothesis is -1, whatever the pad id (reachable only through stopping criteria: every hypothesis has full length otherwise)
-    fill = int(pad_id) if eos else -1
+    # ``fill_id``: the caller knows better (generate() empties the EOS list when min_new_tokens >= max_new_tokens; hf still fills with the pad id there)
+    fill = int(fill_id) if fill_id is not None else (int(pad_id) if eos else -1)
     run_seq = torch.full((B, nb, T), fill, dtype=torch.int64, device=dev)
     fin_seq = run_seq.clone()
     run_len = torch.zeros((B, nb), dtype=torch.int64, device=dev)  # generated length of every finished hypothesis
@@ -251,7 +252,7 @@ def beam_search(step, first_logits: torch.Tensor, batch: int, num_beams: int, ma
             cs = cand[:, :, : cur + 1].reshape(B * keep, cur + 1)
             if prefix is not None:
                 cs = torch.cat((prefix.to(dev, torch.int64).repeat_interleave(keep, dim=0), cs), dim=1)
-            flagged = stopping(cs, None)
+            flagged = stopping(cs, top_lp.reshape(B * keep))  # (hf passes the step's scores)
             if not torch.is_tensor(flagged):
                 flagged = torch.full((B * keep,), bool(flagged), dtype=torch.bool, device=dev)
             hit = hit | flagged.to(dev).view(B, keep)

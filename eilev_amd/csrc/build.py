@@ -58,8 +58,8 @@ def build_hip(force: bool = False, verbose: bool = False, variant: str = "", ext
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn, file=sys.stderr)
-    if force or jobs or _stale(lib, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"])
+    if force or jobs or _stale(lib, objs + [os.path.join(HERE, "exports.map")]):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl", "-Wl,--version-script=" + os.path.join(HERE, "exports.map")])
     return lib
 
 

@@ -23,16 +23,16 @@
 #include "gemm_w6.h"
 #include "gemm_skinny.h"
 
+int g_eilev_grid_cus = 0;  // 0 = every CU (common.h: eilev_grid_cus); written by the probe build only
+#ifdef EILEV_PROBES  // the probe build only (build.py --variant probes -DEILEV_PROBES): the product library has neither the switches nor their state
 int g_gemm_debug = 0;  // probe-only switches (tools/gemm_probe.py): 1 = skip stores, 2 = skip main loop
-int g_eilev_grid_cus = 0;  // 0 = every CU (common.h: eilev_grid_cus)
-#ifdef EILEV_PROBES  // the probe build only (build.py --variant probes -DEILEV_PROBES): the product library exports no switch
 extern "C" int eilev_debug_gemm_flags(int f) { g_gemm_debug = f; return 0; }
 extern "C" int eilev_debug_grid_cus(int n) { g_eilev_grid_cus = n; return 0; }
 #endif
 int g_skinny_nb_default = 1;  // weight blocks per workgroup of the weight-streaming GEMV (set after measurement; see launch_gemm)
+#ifdef EILEV_PROBES
 unsigned long long *g_gemm_trace = nullptr;  // probe-only: see GemmArgs::trace
 int g_gemm_trace_tiles = 0;
-#ifdef EILEV_PROBES
 extern "C" int eilev_debug_gemm_trace(void *buf, int tiles) { g_gemm_trace = (unsigned long long *)buf; g_gemm_trace_tiles = tiles; return 0; }
 #endif
 
@@ -116,9 +116,15 @@ int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s) {
 
 static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, bool *ln_done) {
     GemmArgs g = g_in;
+#ifdef EILEV_PROBES
     g.dbg = g_gemm_debug;
     g.trace = g_gemm_trace;
     g.trace_tiles = g_gemm_trace_tiles;
+#else
+    g.dbg = 0;  // (the product library: no process-global reaches a launch)
+    g.trace = nullptr;
+    g.trace_tiles = 0;
+#endif
     if (g.dbg & 4096) g.lda = 0;   // probe: every A row aliases row 0 (cache-resident operand)
     if (g.dbg & 8192) g.ldw = 0;   // probe: every W row aliases row 0
     if (g.dbg & 131072) g.ldc = 0;  // probe: every output row aliases row 0 (stores stay in L2)
@@ -207,7 +213,7 @@ static int launch_gemm_core(const GemmArgs &g_in, int prof_kind, hipStream_t s, 
             // round 4 (gemm_rows32_kernel): one workgroup per CU, the 32 rows loaded once per CU.  probe flag 1 << 28: the kernels below
             // (the kernel deals the N weight rows over grid_x workgroups row by row; with a K split the grid is still one workgroup per CU)
             const int grid_x = r32_grid;
-            if (a.g.Wp && (g.ldw != g.K || (g.dbg & 32768))) a.g.Wp = nullptr;  // (the stream layout has no row stride; probe flag 1 << 15: ignore it)
+            if (a.g.Wp && (g.ldw != g.K || (g.dbg & (32768 | 134217728)))) a.g.Wp = nullptr;  // (the stream layout has no row stride; probe flags 1 << 15: ignore it, 1 << 27: first-fit plan — its grid may differ from the one the copy was dealt for)
             if (ks32 == 10) hipLaunchKernelGGL((gemm_rows32_kernel<2, 10, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else if (ks32 == 8) hipLaunchKernelGGL((gemm_rows32_kernel<2, 8, 3>), dim3(grid_x, ks), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((gemm_rows32_kernel<2, 5, 4>), dim3(grid_x, ks), dim3(512), 0, s, a);

@@ -97,8 +97,7 @@ extern "C" int eilev_prof_collect(int kind, int64_t *launches, double *total_ms,
 extern "C" int eilev_abi_version(void) { return EILEV_ABI_VERSION; }
 // (r4) 24 576: tools/vit_small_launch.py — the fold wins from 96 frames per launch (53.3 vs 55.7 ms; 136 frames 69.3 vs 71.5), ties at 32-64
 // frames and loses below (8 frames 11.2 vs 8.9 ms: too few 256 x 256 tiles for the persistent kernel)
-static int64_t g_ln_fold_min_rows = 24576;
-extern "C" void eilev_debug_ln_fold_min_rows(int64_t rows) { g_ln_fold_min_rows = rows; }  // (part of the ABI: tests/test_ln_fold.py runs both routes)
+constexpr int64_t kLnFoldMinRows = 24576;  // EilevVitWeights.fold_min_rows == 0
 // The patch path: im2col_strip_kernel reads the frame tensor with coalesced 16-byte loads at 3.9 TB/s (168 us per 1088 frames) and im2col +
 // GEMM + CLS rows take 0.93 ms per launch; the fused patch-embed + LayerNorm kernel of rounds 1-2 took 2.74 ms (0.69 TB/s on the pixels:
 // 50 spilled VGPRs in its K loop, W re-streamed from L2 by every workgroup) and was retired to tools/probes/patch_fused.hip in round 5.
@@ -254,7 +253,7 @@ int vit_forward_impl(const EilevDims *d, const EilevVitWeights *w, const void *p
     if (!cv.ok()) return EILEV_E_WORKSPACE;
     // LayerNorm folded into qkv / fc1 (EilevVitWeights.layers_fold): the throughput path of large launches.  The debug outputs and
     // small launches (where other GEMM kernels than the persistent one win) keep the LayerNorm kernels.
-    const bool fold = w->layers_fold && M >= g_ln_fold_min_rows && !hidden_states && !attentions && D % 64 == 0 && Fi % 64 == 0 &&
+    const bool fold = w->layers_fold && w->fold_min_rows >= 0 && M >= (w->fold_min_rows ? w->fold_min_rows : kLnFoldMinRows) && !hidden_states && !attentions && D % 64 == 0 && Fi % 64 == 0 &&
                       (int64_t)M * D * 2 < 0x7fff0000ll && (int64_t)Fi * D * 2 < 0x7fff0000ll;
 
     // patch embedding (+ bias + position, CLS rows): hf modeling_blip_2.py:243-255 as im2col (coalesced strip reads of the frame tensor) ->

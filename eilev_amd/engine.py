@@ -858,7 +858,7 @@ class HipEngine:
         if sampler is not None and num_beams == 1:  # multinomial sampling: eilev_amd/sampling.py on the same decode step
             from .sampling import sample_loop
 
-            return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler, **(rules or {}))
+            return sample_loop(step, last, max_new_tokens, eos_id, pad_id, **sampler, **{k: v for k, v in (rules or {}).items() if k != "fill_id"})
         return beam_search(step, last, B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id, early_stopping,
                            num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens, **(rules or {}))
 
@@ -1051,7 +1051,7 @@ class HipEngine:
         if sampler is not None and num_beams == 1:
             from .sampling import sample_loop
 
-            ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler, **(rules or {}))
+            ids = sample_loop(step, first, max_new_tokens, eos_id, pad_id, **sampler, **{k: v for k, v in (rules or {}).items() if k != "fill_id"})
         else:
             ids = beam_search(step, first[::num_beams].contiguous(), B, num_beams, max_new_tokens, length_penalty, eos_id, pad_id,
                               early_stopping, num_return_sequences, sampler=sampler, min_new_tokens=min_new_tokens, **(rules or {}))

@@ -534,6 +534,7 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         pad = kw.pop("pad_token_id", None)
         if pad is None:
             pad = self.config.text_config.pad_token_id if self.config.text_config.pad_token_id is not None else (eos_ids[0] if eos_ids else 0)
+        had_eos = bool(eos_ids)
         if min_new >= max_new:
             eos_ids = []  # EOS can never fire before the budget is exhausted
             min_new = 0
@@ -566,6 +567,8 @@ class VideoBlipForConditionalGeneration(PreTrainedModel):
         rules = None
         if len(procs) or len(crit):
             rules = dict(processors=procs if len(procs) else None, stopping=crit if len(crit) else None)
+            if had_eos and not eos_ids:  # the EOS list was emptied above, the model still has an EOS id: hf fills shortened hypotheses with the pad id
+                rules["fill_id"] = int(pad)
         if kw:
             raise NotImplementedError(f"unsupported generate() arguments on the HIP path: {sorted(kw)}")
         if want_dict and not (want_scores or want_logits):  # sequences only: any decoding mode, wrapped like hf wraps it

@@ -19,8 +19,9 @@
  * Conventions: the caller owns every buffer (weights, activations, workspace, KV cache); the
  * library never allocates device memory and never synchronises the stream.  Returns 0 on
  * success, a negative EILEV_E_* for bad arguments / unsupported dimensions, a positive value
- * = passthrough hipError_t.  Global mutable state: none — the product library exports ONE tuning knob
- * (`eilev_debug_ln_fold_min_rows`, a row threshold read at launch time; tests run both of its routes) and no probe switch.  The
+ * = passthrough hipError_t.  Global mutable state: the product library (which exports exactly the symbols declared here:
+ * csrc/exports.map) has ONE process-global, the timing recorder behind eilev_prof_enable / eilev_prof_collect (off by default; a
+ * caller that turns it on owns it for the process), and no probe switch; every tuning threshold is an argument or a struct field.  The
  * `eilev_debug_*` switches of the tools (tile-configuration overrides, phase stamps, alternative kernels for A/B runs) exist only in the
  * PROBE build of the same sources (`python eilev_amd/csrc/build.py --variant probes -DEILEV_PROBES` -> libeilev_hip_probes.so, loaded by
  * tools/ and by the few tests that compare an alternative kernel): listed at the end of this header.
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EILEV_ABI_VERSION 15  /* 15: EilevVitWeights.layers_fold_hm (round 5); 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
+#define EILEV_ABI_VERSION 16  /* 16: EilevVitWeights.fold_min_rows instead of a process-global knob (round 6); 15: EilevVitWeights.layers_fold_hm (round 5); 14: EilevOptWeights.layers_stream / lm_head_stream, eilev_stream_layout_pack (round 5); 10: eilev_opt_decode_step_beam, eilev_linear_rows; 11: eilev_opt_prefill_debug (round 3); 12: eilev_attention_probs; 13: eilev_t5_encode_debug, eilev_t5_decode_debug, rel_tab of eilev_attention_probs, eilev_topk_logprob, eilev_beam_advance (round 4) */
 
 #define EILEV_OK 0
 #define EILEV_E_BADARG (-1)
@@ -101,6 +102,10 @@ typedef struct EilevVitWeights {
      * the frame attention stages a head's image from two contiguous runs; everything else runs from `layers_fold` / `layers`.  Same values,
      * same arithmetic, bit-identical image_embeds. */
     const struct EilevVitLayerFoldHm *layers_fold_hm;
+    /* ABI version 16.  Minimum token rows of a launch for the folded path: 0 = the library's default (24 576: tools/vit_small_launch.py — the
+     * fold wins from 96 frames per launch, ties at 32-64 and loses below: too few 256 x 256 tiles for the persistent kernel); 1 = every launch
+     * (with layers_fold set); negative = never.  (Rounds 4-5: a process-global knob, eilev_debug_ln_fold_min_rows.) */
+    int64_t fold_min_rows;
 } EilevVitWeights;
 
 typedef struct EilevVitLayerFoldHm {
@@ -275,8 +280,6 @@ int eilev_linear_stats(const void *a, const void *w, const void *bias, const voi
 int eilev_ln_finalize(const float *stats, int64_t m, int64_t n, float eps, float *ln_rows, void *stream);
 int eilev_linear_lnfold(const void *a, const void *w_f, const void *bias_f, const float *csum, const float *ln_rows, void *c, int64_t m,
                         int64_t n, int64_t k, int epilogue, void *stream);
-/* probe / test knob: minimum token rows of a launch for the folded ViT path (default 24 576; 0 = always when layers_fold is set) */
-void eilev_debug_ln_fold_min_rows(int64_t rows);
 /* PROBE build only (-DEILEV_PROBES; not exported by libeilev_hip.so): process-global switches, all default 0 = the product path
  *   eilev_debug_gemm_flags : int (int)        force a GEMM tile configuration / remove phases (tools/gemm_probe.py documents the bits)
  *   eilev_debug_gemm_trace : int (void*, int) per-tile time stamps of the persistent GEMM (tools/gemm_trace.py, tools/gemm_itrace.py)

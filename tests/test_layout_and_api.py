@@ -147,6 +147,12 @@ def test_c_abi_library_exports_every_declared_symbol():
         for sw in ("eilev_debug_gemm_flags", "eilev_debug_gemm_trace", "eilev_debug_attn_v1", "eilev_debug_attn_ts", "eilev_debug_decode_rows",
                    "eilev_debug_beam_part", "eilev_debug_fused_patch", "eilev_debug_decode_prefetch", "eilev_debug_reduce_ln_wave"):
             assert not hasattr(lib, sw), sw
+        # round 6: the dynamic symbol table IS the header — nothing else leaves the library (csrc/exports.map: no C++ launcher, no kernel stub)
+        import subprocess
+
+        nm = subprocess.run(["nm", "-D", "--defined-only", abi.HIP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+        assert exported == declared, (sorted(exported - declared)[:8], sorted(declared - exported)[:8])
     from oracle.runner import lib as oracle_lib
 
     for sym in declared:

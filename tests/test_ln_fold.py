@@ -162,14 +162,14 @@ def _vit_three_ways(cfg_name, frames):
     px = synth_pixels(1, frames, cfg.vision_config.image_size)
     ref = oracle.vit(px)
     pxd = torch.from_numpy(px).cuda()
-    try:
-        eng.lib.eilev_debug_ln_fold_min_rows(0)
+    try:  # EilevVitWeights.fold_min_rows (ABI 16): 1 = every launch, negative = never, 0 = the library's default
+        eng.pack.vit.fold_min_rows = 1
         folded = eng.vit(pxd).float().cpu().numpy()
         folded2 = eng.vit(pxd).float().cpu().numpy()
-        eng.lib.eilev_debug_ln_fold_min_rows(1 << 40)
+        eng.pack.vit.fold_min_rows = -1
         plain = eng.vit(pxd).float().cpu().numpy()
     finally:
-        eng.lib.eilev_debug_ln_fold_min_rows(24576)
+        eng.pack.vit.fold_min_rows = 0
     return ref, folded, folded2, plain, rel_rms
 
 

@@ -31,9 +31,12 @@ lib = abi.load_hip()
 raw = C.CDLL(abi.HIP_LIB_PATH)
 if not hasattr(raw, "eilev_debug_gemm_flags"):  # product library: no switches (flags 0 only, see above)
     class _NoSwitch:
+        product = True  # no register-staged reference kernel to compare with: the self-comparison below is skipped, and says so
+
         def eilev_debug_gemm_flags(self, f):
-            assert f in (0, 4)
+            assert f == 0, f
     raw = _NoSwitch()
+    print("product library: timing only (the max-error check against the register-staged kernel needs the probe build)")
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 NOBIAS = bool(os.environ.get("PROBE_NOBIAS"))
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -76,8 +79,9 @@ for name in names:
         call = lambda dst: lib.eilev_linear_stats(P(a), P(w), P(b), P(r), P(dst), m, n, k, P(stats), st())
     else:
         call = lambda dst: lib.eilev_linear(P(a), P(w), P(b), P(r), P(dst), m, n, k, epi, 0, st())
-    fold = name.endswith(("_ln", "_st"))  # (no register-staged reference of these: tests/test_ln_fold.py checks them)
-    raw.eilev_debug_gemm_flags(4)   # reference: register-staged kernel
+    fold = name.endswith(("_ln", "_st")) or getattr(raw, "product", False)  # (no register-staged reference of these: tests/test_ln_fold.py checks them)
+    if not fold:
+        raw.eilev_debug_gemm_flags(4)   # reference: register-staged kernel
     ref = torch.empty_like(o)
     if not fold:
         call(ref)

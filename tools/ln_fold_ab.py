@@ -22,11 +22,11 @@ eng = HipEngine(cfg, w, device="cuda", parts=("vit",))
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
 px = torch.randn((136, 3, 8, 224, 224), device="cuda", generator=g).clamp_(-2.5, 2.5).to(torch.bfloat16)
-times = {0: [], 1 << 40: []}
+times = {1: [], -1: []}  # EilevVitWeights.fold_min_rows (ABI 16): 1 = every launch, -1 = never
 outs = {}
 for rd in range(rounds + 1):
     for knob in times:
-        eng.lib.eilev_debug_ln_fold_min_rows(knob)
+        eng.pack.vit.fold_min_rows = knob
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         outs[knob] = eng.vit(px)
@@ -34,9 +34,9 @@ for rd in range(rounds + 1):
         torch.cuda.synchronize()
         if rd:
             times[knob].append(e0.elapsed_time(e1))
-eng.lib.eilev_debug_ln_fold_min_rows(65536)
-a, b = outs[0].float(), outs[1 << 40].float()
+eng.pack.vit.fold_min_rows = 0
+a, b = outs[1].float(), outs[-1].float()
 rel = float(((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item())
-f, u = statistics.median(times[0]), statistics.median(times[1 << 40])
+f, u = statistics.median(times[1]), statistics.median(times[-1])
 print(f"{layers} blocks x 1088 frames: folded {f:.2f} ms | LayerNorm kernels {u:.2f} ms | per block {f / layers:.3f} vs {u / layers:.3f} ms | "
       f"folded/unfolded time {f / u:.4f} | rel-RMS folded vs unfolded {rel:.2e}")

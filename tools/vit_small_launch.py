@@ -16,15 +16,13 @@ dev = torch.device("cuda")
 w = bench.random_weights(cfg, dev)
 eng = HipEngine(cfg, w, device=dev, parts=("vit",))
 eng.ensure_vit_fold()
-raw = C.CDLL(abi.HIP_LIB_PATH)
-raw.eilev_debug_ln_fold_min_rows.argtypes = [C.c_int64]
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 clips = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 px = torch.randn((clips, 3, 8, 224, 224), device="cuda", generator=g).clamp_(-2.5, 2.5).to(torch.bfloat16)
 res, outs = {}, {}
 for rd in range(4):
-    for tag, rows in (("fold off", 1 << 40), ("fold on", 1)):
-        raw.eilev_debug_ln_fold_min_rows(rows)
+    for tag, rows in (("fold off", -1), ("fold on", 1)):
+        eng.pack.vit.fold_min_rows = rows  # EilevVitWeights.fold_min_rows (ABI 16)
         eng.vit(px); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -32,7 +30,7 @@ for rd in range(4):
         e1.record(); torch.cuda.synchronize()
         if rd: res.setdefault(tag, []).append(e0.elapsed_time(e1) / 3)
         outs[tag] = out[0].float() if isinstance(out, (tuple, list)) else out.float()
-raw.eilev_debug_ln_fold_min_rows(24576)
+eng.pack.vit.fold_min_rows = 0
 for t, v in res.items():
     print(f"{clips} clips ({clips * 8} frames), {t}: {statistics.median(v):.2f} ms")
 a, b = outs["fold off"], outs["fold on"]
