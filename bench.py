@@ -265,11 +265,24 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
     state = np.array([1, 1], np.int32); fin = np.zeros(1, np.uint8); tok = np.zeros(1, np.int64)
     scratch = np.zeros((1, new_tokens), np.int64); nv = np.array([L], np.int32); lg = np.empty((1, d.vocab), np.float32)
     nb = ora.lib.eilev_opt_workspace_bytes(C.byref(d), 1, 1); ws = np.empty(nb // 4 + 1, np.float32)
+    # Round 6: an id is REQUIRED to equal the oracle's argmax wherever the oracle's own top-2 margin exceeds what bf16 storage can move two
+    # logits against each other: 4 x (measured bf16-storage noise of the prefill logits, relative RMS) x rms(logits).  Below that floor the
+    # step is undecided (either of the tied ids is a correct greedy continuation of a bf16 run) and the HIP id's logit must lie within the floor.
     margins, exact, logits = [], 0, ref_last
+    decided, decided_exact, undecided_steps = 0, 0, []
     for t in range(new_tokens):
         row = logits[0]
         margins.append(float((row.max() - row[hip_ids[t]]) / (row.std() + 1e-30)))
         exact += int(row.argmax() == hip_ids[t])
+        top2 = np.partition(row, -2)[-2:]
+        floor_t = 4.0 * p_noise * float(np.sqrt((row ** 2).mean()))
+        if float(top2[1] - top2[0]) > floor_t:
+            decided += 1
+            decided_exact += int(row.argmax() == hip_ids[t])
+        else:
+            undecided_steps.append(t)
+            if float(row.max() - row[hip_ids[t]]) > floor_t:  # a tie between OTHER ids: the HIP id is outside the floor -> a miss
+                decided += 1
         if t + 1 == new_tokens:
             break
         tok[0] = hip_ids[t]                                            # teacher forcing: feed what the HIP path generated
@@ -278,15 +291,17 @@ def verify_against_oracle(cfg, eng, weights, px, ids, vm, am, new_tokens):  # we
                                            P(lg), P(fin), -1, 1, P(scratch), new_tokens, P(ws), nb, None)
         assert rc == 0, rc
         logits = lg
-    ok = bool(q_rel <= 1.5 * q_noise + 1e-3 and p_rel <= 1.5 * p_noise + 1e-3 and max(margins) <= 0.05)
+    ok = bool(q_rel <= 1.5 * q_noise + 1e-3 and p_rel <= 1.5 * p_noise + 1e-3 and decided_exact == decided)
     return ok, {"query_tokens_rel_rms_vs_fp32": round(q_rel, 5), "bf16_storage_noise_query_tokens": round(q_noise, 5),
                 "prefill_logits_rel_rms_vs_fp32": round(p_rel, 5), "bf16_storage_noise_prefill_logits": round(p_noise, 5),
                 "ids_equal_oracle_argmax": f"{exact}/{new_tokens}",
-                "ids_exact_required": False,
-                "ids_exact_note": "random-init N(0, 0.02) weights at full depth give nearly flat logits: a HIP id may differ from the fp32 oracle's argmax at "
-                                  "a near-tie (margin <= 5 % of the logit std) and still pass.  Exact greedy ids at THIS shape and depth (17 clips, L = 960, "
-                                  "left padding, 39 / 12 / 32 blocks) are pinned against the REFERENCE's own fp32 / bf16 runs by tests/golden/full_c2.npz, "
-                                  "replayed in this run: `reference_parity.headline_shape` (round 5), and by tests/test_hip_full_depth_c2.py",
+                "ids_exact_required": True,
+                "ids_exact_at_decided_steps": f"{decided_exact}/{decided}", "undecided_steps": undecided_steps,
+                "ids_exact_note": "exact wherever the fp32 oracle's top-2 margin exceeds the bf16 floor (4 x the measured bf16-storage noise x rms(logits)); at an "
+                                  "undecided step (random-init weights at full depth give nearly flat logits) the HIP id's logit must lie within that floor of the "
+                                  "maximum.  Exact greedy ids at THIS shape and depth (17 clips, L = 960, left padding, 39 / 12 / 32 blocks) are also pinned against "
+                                  "the REFERENCE's own fp32 / bf16 runs by tests/golden/full_c2.npz, replayed in this run (`reference_parity.headline_shape`), and the "
+                                  "timed decode step (32 rows x 975 keys, stream + row-block layouts, hipGraph) by tests/test_hip_real_shapes.py::test_decode_step_at_the_timed_bench_shape_vs_oracle",
                 "max_margin_over_logit_std": round(max(margins), 5), "seconds": round(time.perf_counter() - t0, 1),
                 "what": "oracle/libeilev_ref.so fp32 (and its bf16-storage emulation as the noise floor) on the same weights: clip 0 pixels -> projected query tokens (from a 1088-frame launch); "
                         "sample 0 inputs_embeds -> prefill last-row logits + teacher-forced decode on the HIP ids (batch-32 prefill, hipGraph decode)"}

@@ -62,10 +62,10 @@ def P(t):
 
 
 def record_parity(section: str, **numbers):
-    """Append measured parity distances to gpurun_out/parity_r05.json (merged back from the GPU box; the copy under
+    """Append measured parity distances to gpurun_out/parity_r06.json (merged back from the GPU box; the copy under
     profiles/ is the tracked one).  Numbers only: what HIP-vs-reference distances actually are, next to the tolerance."""
     root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "parity_r05.json")
+    path = os.path.join(root, "gpurun_out", "parity_r06.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     try:
         with open(path) as fh:

@@ -8,7 +8,7 @@ flags (eilev_debug_gemm_flags): 4 register-staged reference kernel; 8 old skinny
 kernel pp4, 12: one-wave-per-SIMD kernel w6, 13: 64x128 two-wave tiles, 14: 128x128); 1024 no epilogue; 2048 no store phase; 4096 / 8192 alias all A / W rows onto row 0
 (cache-resident operand — also changes the MFMA data statistics and with them the clock: not a memory-system measurement);
 131072 alias all output rows onto row 0; 524288 no half-tile path; 1048576 per-tile kernel for N = 1408; 2097152 never pick w6;
-16777216 pp4 without the lean epilogue / second pre-staged K-step; (n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
+16777216 pp4 without the lean epilogue / second pre-staged K-step; 65536 half tiles dealt as single tiles (round 6: the deal before half-tile pairing); (n << 22) tile-group height override (1: 4 rows, 2: 8, 3: 16).
 PROBE_M / PROBE_MOPT override the row count of the ViT / OPT shapes.
 """
 import ctypes as C
@@ -53,7 +53,9 @@ ALL = {"fc1": (34952, 6144, 1408, 1, False), "fc2": (34952, 1408, 6144, 0, True)
        # round 5: the flan-t5-xl encoder linears of a bench step (32 samples x 960 tokens; no biases: PROBE_NOBIAS=1)
        "t5_qkv": (30720, 6144, 2048, 0, False), "t5_o": (30720, 2048, 2048, 0, True), "t5_wi": (30720, 10240, 2048, 0, False),
        "t5_wo": (30720, 2048, 5120, 0, True),
-       "fc2_n1280": (34952, 1280, 6144, 0, True), "fc2_n1536": (34952, 1536, 6144, 0, True), "fc2_n2048": (34952, 2048, 6144, 0, True)}
+       "fc2_n1280": (34952, 1280, 6144, 0, True), "fc2_n1536": (34952, 1536, 6144, 0, True), "fc2_n2048": (34952, 2048, 6144, 0, True),
+       # round 6: what does a half tile cost?  One column of half tiles (N = 128) against one column of whole tiles (N = 256), PROBE_M = 262144 = 4 exact rounds
+       "fc2_n128": (34952, 128, 6144, 0, True), "fc2_n256": (34952, 256, 6144, 0, True), "proj_n128": (34952, 128, 1408, 0, True), "proj_n256": (34952, 256, 1408, 0, True)}
 flags_list = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ALL)
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
