@@ -214,17 +214,24 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 constexpr int ATTN_V2_REL_MAX = 4096, ATTN_V2_REL_SLACK = 64;
 // bytes of the K / V stages + key-mask words, or of the O staging that overlays them at the end, whichever is larger (16-byte multiple):
 // the relative-position table sits behind both
+// Round 6: DB = 4 is the hd = 128 form (OPT-6.7B, BASELINE configs[4]; the round-1 kernel ran its prefill attention at 3.9 ms per block = 23 % of
+// the fp8 prefill).  256-byte rows would put every row's chunk c on the same 16 banks, so the LDS image PADS a row to 17 chunks (272 bytes:
+// the 16 lanes one ds_read_b128 services together then hit 16 different slots, like the 160 / 176-byte rows of DB = 3); the LDS-DMA fills the
+// 17th chunk with a second copy of the 16th (lane -> source chunk is free on the source side), 6 % more bytes through the DMA, none read.
+__host__ __device__ inline int attn_v2_row_bytes(int hd) { return hd == 128 ? 272 : hd * 2; }
+__host__ __device__ inline int attn_v2_ostage_bytes(int hd) { return hd == 128 ? 272 : 200; }  // row stride of the per-wave O staging
 __host__ __device__ inline int attn_v2_rel_offset(int nwq, int hd) {
-    int b = 4 * 64 * hd * 2 + 256 + (2 * 64 + 2) * (int)sizeof(int);
-    if (b < nwq * 32 * 200) b = nwq * 32 * 200;
+    int b = 4 * 64 * attn_v2_row_bytes(hd) + 256 + (2 * 64 + 2) * (int)sizeof(int);
+    if (b < nwq * 32 * attn_v2_ostage_bytes(hd)) b = nwq * 32 * attn_v2_ostage_bytes(hd);
     return (b + 15) & ~15;
 }
 template <int NWQ, int DB = 3, bool REL = false>
 __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArgs a) {
-    constexpr int KD = 2 * DB;         // k = 16 MFMA steps over DP = 32 DB (96: hd 72 / 80 / 88; 64: hd 64)
+    constexpr int KD = 2 * DB;         // k = 16 MFMA steps over DP = 32 DB (96: hd 72 / 80 / 88; 64: hd 64; 128: hd 128)
     constexpr bool SWZ = DB == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int RS = a.hd * 2, CH = a.hd >> 3;  // LDS row stride (bytes), 16-byte chunks per row
+    const int RS = DB == 4 ? 272 : a.hd * 2, CH = RS >> 4;  // LDS row stride (bytes), 16-byte chunks per LDS row
+    const int CHS = a.hd >> 3;                                // 16-byte chunks per row of q / k / v / o in memory
     const int T = 64 * RS;                     // bytes per K (or V) tile
     int *msk = reinterpret_cast<int *>(smem + 4 * T + 256);
     float *rel_lds = reinterpret_cast<float *>(smem + attn_v2_rel_offset(NWQ, a.hd));  // behind everything else (incl. the O staging)
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
             const bool isv = i >= CH;
             const int pi = isv ? i - CH : i;
             const int pch = pi * 64 + lane, key = pch / CH, cl = pch - key * CH;
-            const int c = SWZ ? (cl ^ ((key >> 1) & 7)) : cl;  // the global chunk that lives at LDS chunk cl of this row
+            const int c = SWZ ? (cl ^ ((key >> 1) & 7)) : (DB == 4 && cl >= CHS ? CHS - 1 : cl);  // the global chunk that lives at LDS chunk cl of this row
             int gk = kv0 + key;
             gk = gk < a.skv ? gk : a.skv - 1;
             const bf16 *src = isv ? vp + (int64_t)gk * a.ldv + c * 8 : kp + (int64_t)gk * a.ldk + c * 8;
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
     // o[db][r] = O[q = l31][d = db*32 + (r&3) + 8*(r>>2) + 4*hi]; stage the wave's 32 x hd tile in LDS (the KV
     // stages are dead after the last barrier; each wave owns a private region) and store coalesced rows.
     {
-        constexpr int OS = 200;  // staging row stride (bytes): 96 bf16 + pad
+        constexpr int OS = DB == 4 ? 272 : 200;  // staging row stride (bytes): 96 (128) bf16 + pad
         char *reg = smem + wid * (32 * OS);
         const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
 #pragma unroll
@@ -451,8 +458,8 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
                 *reinterpret_cast<bf16x4 *>(reg + l31 * OS + (db * 32 + g * 8 + hi * 4) * 2) = w;
             }
         bf16 *ob = a.o + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
-        for (int pch = lane; pch < 32 * CH; pch += 64) {
-            const int row = pch / CH, c = pch - row * CH;
+        for (int pch = lane; pch < 32 * CHS; pch += 64) {
+            const int row = pch / CHS, c = pch - row * CHS;
             if (q0 + row < a.sq) {
                 const bf16x4 *sp = reinterpret_cast<const bf16x4 *>(reg + row * OS + c * 16);
                 const bf16x4 lo = sp[0], hi4 = sp[1];
@@ -858,6 +865,11 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
         const int qt = (a.sq + 31) / 32;
         if (a.rel_tab) return qt >= 5 ? launch_attn_v2<8, 2, true>(a, s) : launch_attn_v2<4, 2, true>(a, s);
         return qt >= 5 ? launch_attn_v2<8, 2, false>(a, s) : launch_attn_v2<4, 2, false>(a, s);
+    }
+    // hd = 128 (OPT-6.7B prefill), >= 64 query rows: round 6
+    if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && a.hd == 128 && a.sq >= 64 && a.skv >= 64) {
+        const int qt = (a.sq + 31) / 32;
+        return qt >= 5 ? launch_attn_v2<8, 4>(a, s) : launch_attn_v2<4, 4>(a, s);
     }
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {
         const int qt = (a.sq + 31) / 32;

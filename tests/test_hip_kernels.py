@@ -124,7 +124,11 @@ def test_layernorm(hip, rows, cols):
     (2, 12, 32, 2056, 64, 0, False),   # Q-Former cross over 8 frames
     (2, 4, 100, 100, 80, 1, True),     # OPT prefill, left padding
     (1, 32, 200, 200, 80, 1, False),   # OPT-2.7B heads
-    (2, 2, 70, 130, 128, 1, True),     # causal with offset (sq < skv), d=128
+    (2, 2, 70, 130, 128, 1, True),     # causal with offset (sq < skv), d=128: attn_prefill_v2_kernel<4, 4> (round 6: 272-byte padded LDS rows)
+    (2, 3, 333, 333, 128, 1, True),    # OPT-6.7B heads: ragged length, left padding, <8, 4>
+    (1, 2, 960, 960, 128, 1, False),   # the configs[4] prefill length
+    (2, 2, 64, 200, 128, 0, True),     # not causal, masked, the smallest query count the route takes
+    (1, 2, 40, 40, 128, 1, False),     # below it: the round-1 kernel
 ])
 def test_attention(hip, batch, heads, sq, skv, hd, causal, masked):
     D = heads * hd
