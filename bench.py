@@ -80,7 +80,7 @@ def build_inputs(cfg, samples, device, seed=1234):
     return px, ids, vm, am
 
 
-def cpu_baseline(cfg, host_weights):
+def cpu_baseline(cfg, host_weights, full_c2=False):
     """The host-CPU number printed beside the GPU number: stock transformers modules (the classes the
     reference instantiates, ref:eilev/model/v2.py:111-127) composed by oracle/hf_baseline.py and timed on every host core —
     configs[0] (C1: 1 clip, 0-shot, greedy) end to end, and a bounded sample of the headline 16-shot workload (one clip's
@@ -90,7 +90,7 @@ def cpu_baseline(cfg, host_weights):
     try:
         from oracle.hf_baseline import time_hf_cpu
 
-        hf = time_hf_cpu(cfg, host_weights, N_CTX, FRAMES, NEW_TOKENS, synth_interleaved_ids)
+        hf = time_hf_cpu(cfg, host_weights, N_CTX, FRAMES, NEW_TOKENS, synth_interleaved_ids, full_c2=full_c2)
     except Exception as e:  # no transformers on the box (or a module API drift): report the port, say why
         port["hf_unavailable"] = f"{type(e).__name__}: {e}"[:200]
         return port
@@ -102,6 +102,13 @@ def cpu_baseline(cfg, host_weights):
         pass
     # `cores` = the threads the timed run really used (the probe picks them under the container's CPU quota), not the logical CPUs the
     # box reports; `value` is EXTRAPOLATED from a bounded sample (BASELINE.md 3 wanted C2 timed once in full: ~20 min of CPU per sample)
+    if "c2_full_clips_per_s" in hf:  # --cpu-full: one whole headline sample was run (profiles/r06_cpu_full.json holds such a line)
+        return {"value": hf["c2_full_clips_per_s"], "unit": "clips/s", "cores": hf["threads"], "logical_cpus": hf["cores"],
+                "effective_cpus": hf.get("effective_cpus"), "kind": "hf", "extrapolated": False,
+                "sample": (f"ONE COMPLETE 16-shot sample, nothing scaled: stock transformers Blip2VisionModel + Blip2QFormerModel + OPTForCausalLM (torch {hf['torch']}, fp32, "
+                           f"{hf['threads']} threads, {cpu_model}) on the same random-init weights: 17 different clips x 8 frames encoded one by one "
+                           f"({hf['c2_full_encode_seconds']} s), L=960 prefill + 32 greedy tokens: {hf['c2_full_seconds']} s in all"),
+                "extrapolation_of_the_default_run": hf["c2_clips_per_s"], "c1_clips_per_s": hf["c1_clips_per_s"], "c1_seconds": hf["c1_seconds"], "oracle_port": port}
     return {"value": hf["c2_clips_per_s"], "unit": "clips/s", "cores": hf["threads"], "logical_cpus": hf["cores"],
             "effective_cpus": hf.get("effective_cpus"), "kind": "hf", "extrapolated": True,
             "sample": (f"EXTRAPOLATED from a bounded sample, not a full C2 run: stock transformers Blip2VisionModel + Blip2QFormerModel + OPTForCausalLM (torch {hf['torch']}, fp32, {hf['threads']} threads, "
@@ -491,6 +498,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=32, help="16-shot samples per GPU per step (<= 32: one decode batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline from ONE complete 16-shot sample on the host cores (17 clips encoded + L = 960 prefill + 32 tokens: "
+                    "~1.5-2 minutes of CPU) instead of the default bounded sample that is extrapolated")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling phase (SURVEY 8(d): 8 samples per GLOBAL step) that "
                     "runs after the headline weak-scaling steps and is reported as `strong_scaling` in the same JSON line")
     ap.add_argument("--strong-samples", type=int, default=8, help="samples per GLOBAL step of the strong-scaling phase")
@@ -883,7 +892,7 @@ def main():
                 res["reference_parity"] = ref_par
                 res["verified"] = bool(res["verified"] and ref_par["ok"])
         if do_cpu:
-            res["cpu_baseline"] = cpu_baseline(cfg, host_w)
+            res["cpu_baseline"] = cpu_baseline(cfg, host_w, full_c2=args.cpu_full)
         print(json.dumps(res), flush=True)
     bad = None
     if world > 1 and rank == 0:

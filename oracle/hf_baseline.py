@@ -124,7 +124,8 @@ def pick_threads(probe) -> tuple[int, dict]:
     return best, {str(k): round(v, 3) for k, v in seen.items()}
 
 
-def time_hf_cpu(cfg, host_weights, n_ctx: int, frames: int, new_tokens: int, synth_ids, threads: int | None = None, budget_s: float = 120.0):
+def time_hf_cpu(cfg, host_weights, n_ctx: int, frames: int, new_tokens: int, synth_ids, threads: int | None = None, budget_s: float = 120.0,
+                full_c2: bool = False):
     """C1 (1 clip, 0-shot, L = 48, greedy) end to end, and a bounded sample of C2 (16-shot): one clip through ViT + Q-Former,
     one L = 960 prefill and the decode steps of one sample; C2 = (n_ctx + 1) x clip + LM.  fp32 (the reference's default
     dtype on CPU, ref:samples/eilev_generate_action_narration.py:98-100)."""
@@ -167,6 +168,19 @@ def time_hf_cpu(cfg, host_weights, n_ctx: int, frames: int, new_tokens: int, syn
     t_lm = time.perf_counter() - t0
     assert out2.shape == (1, new_tokens)
     per_sample = (n_ctx + 1) * t_clip + t_lm
-    return {"threads_tried_s_per_vit_block": tried, "effective_cpus": effective_cpus(), "c1_seconds": round(t_c1, 2), "c1_clips_per_s": round(1.0 / t_c1, 4), "clip_encode_seconds": round(t_clip, 2),
+    full = {}
+    if full_c2:  # ONE complete headline sample, nothing scaled: n_ctx + 1 DIFFERENT clips through ViT + Q-Former + projection (one at a time, as
+        # the reference's sample script feeds them), scatter, L = 960 prefill, 32 greedy tokens — the measured anchor of the extrapolation
+        t0 = time.perf_counter()
+        fl = []
+        for c in range(n_ctx + 1):
+            pxc = torch.randn(px.shape, generator=g).clamp_(-2.5, 2.5)
+            fl.append(hf_encode(vit, qf, proj, qt, pxc))
+        t_enc = time.perf_counter() - t0
+        out3 = hf_generate(lm, torch.cat(fl), ids2, vm2, new_tokens)
+        t_full = time.perf_counter() - t0
+        assert out3.shape == (1, new_tokens)
+        full = {"c2_full_seconds": round(t_full, 2), "c2_full_encode_seconds": round(t_enc, 2), "c2_full_clips_per_s": round((n_ctx + 1) / t_full, 4)}
+    return {**full, "threads_tried_s_per_vit_block": tried, "effective_cpus": effective_cpus(), "c1_seconds": round(t_c1, 2), "c1_clips_per_s": round(1.0 / t_c1, 4), "clip_encode_seconds": round(t_clip, 2),
             "lm_16shot_seconds": round(t_lm, 2), "c2_clips_per_s": round((n_ctx + 1) / per_sample, 4), "threads": threads, "cores": cores,
             "torch": torch.__version__, "dtype": "fp32"}
