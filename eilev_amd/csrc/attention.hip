@@ -421,8 +421,9 @@ __global__ __launch_bounds__(64 * NWQ) void attn_prefill_v2_kernel(const AttnArg
             const bool plain = msk[128 + cur] != 0 && (!a.causal || kv0 + 63 <= q0 + off);
             using two = std::integral_constant<int, 2>;
             using one = std::integral_constant<int, 1>;
-            if (NWQ > 8) {
-                // 9 waves per workgroup leave 168 VGPRs per wave: one 32-key block at a time
+            if (NWQ > 8 || (DB == 4 && NWQ == 8)) {
+                // 9 waves per workgroup leave 168 VGPRs per wave: one 32-key block at a time (round 6: also the hd = 128 form at 8 waves: its O
+                // accumulators alone are 64 registers; with two blocks in flight hipcc spilled 31 VGPRs)
                 if (kv0 < vis_end) {
                     if (plain) tile_body(one{}, std::false_type{}, cur, kv0);
                     else tile_body(one{}, std::true_type{}, cur, kv0);
@@ -869,6 +870,9 @@ int launch_attention(const AttnArgs &a_in, hipStream_t s) {
     // hd = 128 (OPT-6.7B prefill), >= 64 query rows: round 6
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && a.hd == 128 && a.sq >= 64 && a.skv >= 64) {
         const int qt = (a.sq + 31) / 32;
+#ifdef EILEV_PROBES
+        if (a.dbg & 64) return launch_attn_v2<4, 4>(a, s);  // probe: 4 waves per workgroup (512 registers per wave, two blocks in flight)
+#endif
         return qt >= 5 ? launch_attn_v2<8, 4>(a, s) : launch_attn_v2<4, 4>(a, s);
     }
     if (!g_attn_force_v1 && !a.rel_tab && !a.drop_thr && (a.hd == 80 || a.hd == 88 || a.hd == 72) && a.skv >= 32) {

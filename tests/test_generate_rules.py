@@ -203,3 +203,43 @@ def test_greedy_custom_criterion_without_eos_keeps_real_tokens(tiny_opt):
     ours = sample_loop(step, first, 12, eos_id=-1, pad_id=1, greedy=True, stopping=StoppingCriteriaList([_StopOnToken(ids)]), prefix=prompt)
     hf = _hf(tiny_opt, prompt, max_new_tokens=12, do_sample=False, num_beams=1, eos_token_id=None, stopping_criteria=StoppingCriteriaList([_StopOnToken(ids)]))
     _eq(ours, hf)
+
+
+# ---- round 6 ----
+class _StopOnScore:
+    """a user StoppingCriteria that READS `scores` (hf `_beam_search` passes the candidates' running log-probabilities): done once a row's
+    score falls below a threshold.  With `scores=None` it would raise."""
+
+    def __init__(self, thr):
+        self.thr = thr
+
+    def __call__(self, input_ids, scores, **kw):
+        assert scores is not None and scores.shape[0] == input_ids.shape[0]
+        return scores.reshape(input_ids.shape[0], -1)[:, -1] < self.thr
+
+
+def test_beam_stopping_criteria_receive_the_candidate_scores(tiny_opt):
+    from transformers import StoppingCriteriaList
+
+    torch.manual_seed(9)
+    prompt = torch.randint(4, 40, (2, 6))
+    step, first = _stepper(tiny_opt, prompt, 6)
+    out = beam_search(step, first, 2, 3, 9, 1.0, -1, 1, False, 1, stopping=StoppingCriteriaList([_StopOnScore(-6.0)]), prefix=prompt)
+    assert out.shape[0] == 2 and 1 <= out.shape[1] <= 9
+
+
+def test_beam_fill_is_the_pad_id_when_the_model_has_an_eos_that_cannot_fire(tiny_opt):
+    """generate(min_new_tokens >= max_new_tokens) empties the EOS list for the search (EOS can never fire) but the model still HAS an EOS id:
+    hf fills the unused tail of a hypothesis shortened by a stopping criterion with the pad id, not -1 (`fill_id`)."""
+    from transformers import StoppingCriteriaList
+
+    torch.manual_seed(6)
+    prompt = torch.randint(4, 40, (2, 6))
+    step, first = _stepper(tiny_opt, prompt, 6)
+    crit = lambda: StoppingCriteriaList([_StopOnToken([7, 12, 25, 30, 31])])
+    a = beam_search(step, first, 2, 3, 9, 1.0, -1, 1, False, 1, stopping=crit(), prefix=prompt)
+    step, first = _stepper(tiny_opt, prompt, 6)
+    b = beam_search(step, first, 2, 3, 9, 1.0, -1, 1, False, 1, stopping=crit(), prefix=prompt, fill_id=1)
+    assert a.shape == b.shape
+    assert torch.equal(torch.where(a < 0, torch.ones_like(a), a), b)  # same hypotheses; only the fill differs
+    assert (b >= 0).all()
