@@ -143,9 +143,53 @@ __device__ __forceinline__ void gelu_erf_pk(f32x2 (&x)[NP]) {
 #define EILEV_GELU_COEFFS                                                                                                   \
     {4.543383146e-02f, -1.712931058e-01f, 2.188764488e-01f, 1.158597774e-02f, -3.094834958e-01f, 2.450403219e-01f,         \
      3.056864685e-02f, -8.538186866e-02f, 1.466789586e-02f}
-// NP independent elements at a time: NP Horner chains interleaved step by step.  Plain v_fma_f32: the packed f32 forms issue at half rate.
+// Round 6 (EILEV_GELU_PHI, the default): the same GELU as x * Phi(x) with Phi(x) = 1 / 2 + xc q(xc^2), xc = x clamped to +-3.95, q of degree 6
+// (minimax with Phi(3.95) = 1 pinned, so that x > 3.95 returns x and x < -3.95 returns 0): max abs error 1.67e-4 (relative 2.6e-3 where
+// |y| > 0.05) against 1.1e-4 / 2.2e-3 of the form above — both an order of magnitude inside the bf16 rounding of the pre-activation the
+// reference evaluates GELU on.  What it buys is VALU issue slots, the one thing the epilogue costs (tools/probes/valu_shadow.hip: a SIMD of
+// gfx950 does not run VALU and MFMA instructions concurrently, §5 of DESIGN.md): one unpacked operation (v_med3) and nine that hipcc packs
+// into v_pk_mul / v_pk_fma_f32, against three unpacked (|x| min, max, the bias of the clamp) and nine packed.
+#ifndef EILEV_GELU_PHI
+#define EILEV_GELU_PHI 1
+#endif
+#define EILEV_GELU_PHI_C 3.95f
+#define EILEV_GELU_PHI_COEFFS                                                                                               \
+    {3.979867044e-01f, -6.472275670e-02f, 8.842919395e-03f, -8.290393928e-04f, 4.955192888e-05f, -1.681151575e-06f, 2.443575809e-08f}
+// NP independent elements at a time: NP Horner chains interleaved step by step.
 template <int NP>
 __device__ __forceinline__ void gelu_erf_n(float (&x)[NP]) {
+#if EILEV_GELU_PHI
+    constexpr float q[7] = EILEV_GELU_PHI_COEFFS;
+    if constexpr (NP % 2 == 0) {  // explicit pairs: v_pk_mul_f32 / v_pk_fma_f32 (left to itself hipcc emits one v_fmaak_f32 per element and step)
+        f32x2 xv[NP / 2], xc[NP / 2], s[NP / 2], p[NP / 2];
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n) {
+            xv[n] = (f32x2){x[2 * n], x[2 * n + 1]};
+            xc[n] = (f32x2){__builtin_amdgcn_fmed3f(x[2 * n], -EILEV_GELU_PHI_C, EILEV_GELU_PHI_C), __builtin_amdgcn_fmed3f(x[2 * n + 1], -EILEV_GELU_PHI_C, EILEV_GELU_PHI_C)};
+            s[n] = xc[n] * xc[n];
+            p[n] = (f32x2){q[6], q[6]};
+        }
+#pragma unroll
+        for (int k = 5; k >= 0; --k)
+#pragma unroll
+            for (int n = 0; n < NP / 2; ++n) p[n] = __builtin_elementwise_fma(p[n], s[n], (f32x2){q[k], q[k]});
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n) {
+            const f32x2 y = xv[n] * __builtin_elementwise_fma(xc[n], p[n], (f32x2){0.5f, 0.5f});
+            x[2 * n] = y.x;
+            x[2 * n + 1] = y.y;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const float xc = __builtin_amdgcn_fmed3f(x[n], -EILEV_GELU_PHI_C, EILEV_GELU_PHI_C), s = xc * xc;
+            float p = q[6];
+#pragma unroll
+            for (int k = 5; k >= 0; --k) p = fmaf(p, s, q[k]);
+            x[n] = x[n] * fmaf(xc, p, 0.5f);
+        }
+    }
+#else
     constexpr float c[EILEV_GELU_DEG + 1] = EILEV_GELU_COEFFS;
     float t[NP], p[NP];
 #pragma unroll
@@ -159,6 +203,7 @@ __device__ __forceinline__ void gelu_erf_n(float (&x)[NP]) {
         for (int n = 0; n < NP; ++n) p[n] = fmaf(p[n], t[n], c[k]);
 #pragma unroll
     for (int n = 0; n < NP; ++n) x[n] = fmaxf(x[n], 0.0f) - p[n];
+#endif
 }
 
 __device__ __forceinline__ float gelu_erf_n1(float x) {
