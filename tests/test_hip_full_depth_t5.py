@@ -65,4 +65,18 @@ def test_full_depth_t5_greedy_ids(full_t5, use_graph):
     g, meta, eng, emb, am = full_t5
     assert np.array_equal(g["fp32_greedy_free"], g["bf16_greedy_free"])
     ids = eng.t5_greedy(emb, am, meta["new_tokens"], eos_id=-1, use_graph=use_graph).cpu().numpy()
-    assert np.array_equal(ids, g["fp32_greedy_free"]), (ids, g["fp32_greedy_free"])
+    assert ids[0, 0] == g["fp32_greedy_free"][0, 0]  # decoder start token
+    # Round 6: free-running ids are compared like the full-depth OPT fixtures' — equal up to the first NEAR-TIE OF THE REFERENCE, where the id must
+    # be the reference's runner-up (oracle/parity.py).  The fixture now stores the reference's eight leading logits of every step
+    # (tools/make_goldens.py full_t5; the older keys regenerated bit-identically): at step 2 the reference's own fp32 run separates 30692 from
+    # 30568 by 0.0003 (4.0008 vs 4.0005; its bf16 run moves those logits by 0.03) — a coin flip that the degree-8 GELU of rounds 2-5 happened to
+    # land on the reference's side of and round 6's x * Phi(x) form (one bf16 ulp away on some fc1 outputs) does not.
+    from oracle.parity import greedy_ids_vs_reference
+
+    view = {k: g[k] for k in ("fp32_step_logits_top8", "fp32_step_logits_top8_ids", "bf16_step_logits_top8", "bf16_step_logits_top8_ids")}
+    view["fp32_greedy_free"] = g["fp32_greedy_free"][:, 1:]
+    verdict = greedy_ids_vs_reference(ids[:, 1:], view)
+    record_parity("full_depth[t5]", **{f"greedy_graph{int(use_graph)}_ids_equal_before_first_flip": verdict["ids_equal_before_first_flip"],
+                                       f"greedy_graph{int(use_graph)}_flips": len(verdict["flips"])})
+    assert verdict["ok"], (verdict, ids, g["fp32_greedy_free"])
+    assert verdict["ids_equal_before_first_flip"] >= 2

@@ -607,8 +607,18 @@ def run_real_t5_case(name):
         out[f"{tag}_logits_checksum"] = np.asarray([lg.astype(np.float64).sum(), np.abs(lg.astype(np.float64)).sum()])
         out[f"{tag}_logits_argmax"] = lg.argmax(-1)
         out[f"{tag}_loss"] = np.asarray(float(o.loss), dtype=np.float64)
-        g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
-                       max_new_tokens=new_tokens, min_new_tokens=new_tokens, num_beams=1, do_sample=False)
+        if name.startswith("full"):  # round 6: the eight leading logits of every greedy step too, so that a free-running comparison knows where
+            # the REFERENCE's near-ties are (oracle/parity.py, as the full-depth OPT fixtures have had since round 4)
+            o2 = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn), max_new_tokens=new_tokens,
+                            min_new_tokens=new_tokens, num_beams=1, do_sample=False, output_scores=True, return_dict_in_generate=True)
+            g = o2.sequences
+            # (min_new_tokens masks EOS in the processed scores: -inf never ranks among the leading eight)
+            sc = torch.stack([s_.float() for s_ in o2.scores])
+            out[f"{tag}_step_logits_top8_ids"] = sc.topk(8, dim=-1).indices.numpy().astype(np.int64)  # (n, B, 8)
+            out[f"{tag}_step_logits_top8"] = sc.topk(8, dim=-1).values.numpy()
+        else:
+            g = m.generate(input_ids=t(input_ids), pixel_values=px, video_input_mask=t(vmask), attention_mask=t(attn),
+                           max_new_tokens=new_tokens, min_new_tokens=new_tokens, num_beams=1, do_sample=False)
         out[f"{tag}_greedy_free"] = g.numpy().astype(np.int64)
     meta = dict(case=name, config=cfg_name, frames=frames, rows=rows, new_tokens=new_tokens, weight_mode="fanin", torch=torch.__version__,
                 transformers=transformers.__version__, generator="tools/make_goldens.py", reference="/root/reference/eilev/model/v2.py")
