@@ -157,3 +157,22 @@ def test_c_abi_library_exports_every_declared_symbol():
 
     for sym in declared:
         assert hasattr(oracle_lib(), sym), sym
+
+
+def test_abi16_vit_weights_layout():
+    """ABI 16 (round 6): EilevVitWeights ends with `int64_t fold_min_rows` behind its nine pointers (include/eilev.h) — the ctypes mirror the
+    engine passes must have exactly that layout, and the header, the binding and the built library must agree on the version."""
+    import ctypes
+    import re
+
+    from eilev_amd import abi
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "eilev.h")).read()
+    assert int(re.search(r"#define EILEV_ABI_VERSION (\d+)", hdr).group(1)) == 16
+    assert [f[0] for f in abi.VitWeights._fields_][-2:] == ["layers_fold_hm", "fold_min_rows"]
+    assert abi.VitWeights.fold_min_rows.offset == 9 * ctypes.sizeof(ctypes.c_void_p) and ctypes.sizeof(abi.VitWeights) == 80
+    body = hdr[hdr.index("typedef struct EilevVitWeights {"):hdr.index("} EilevVitWeights;")]
+    assert body.rstrip().endswith("int64_t fold_min_rows;")
+    assert "eilev_debug_ln_fold_min_rows" not in " ".join(abi.EXPORTS)
+    if os.path.exists(abi.HIP_LIB_PATH):
+        assert ctypes.CDLL(abi.HIP_LIB_PATH).eilev_abi_version() == 16
