@@ -286,20 +286,19 @@ __host__ __device__ static inline int64_t frag32_index(int row, int col) { retur
 int launch_gemm(const GemmArgs &g, int prof_kind, hipStream_t s);
 int launch_pp4_ext(const GemmArgs &g, int grid, hipStream_t s);  // gemm_pp4_ext.hip
 // every tile of a persistent-kernel launch can take the lean epilogue (what the 16 x 16 MFMA instances need: gemm_pp4.h M16)
-// (probe build: the deal's probe flags and the per-tile stamps of tools/gemm_trace.py / gemm_timeline.py run on the product's 16 x 16 instances —
-// in rounds 2-5 ANY probe flag or a trace buffer made the launch fall back to the 32 x 32 instances, whose half tiles cost 0.85-1.0 of a whole
-// tile instead of 0.72-0.74: round 6's first pairing / rotation A/B measured the wrong kernel)
+// Probe build: the per-tile stamps of tools/gemm_trace.py / gemm_timeline.py run on the product's 16 x 16 instances.  (In rounds 2-5 a trace
+// buffer — like any probe flag — made a launch fall back to the 32 x 32 instances, whose half tiles cost 0.85-1.0 of a whole tile instead of
+// 0.72-0.77: a traced or flagged arm of an A/B measured another kernel than the product's.  Probe flags still do: an A/B of two flag values
+// compares like with like, an A/B against flags = 0 does not.)
 #ifdef EILEV_PROBES
-#define EILEV_LEAN_DBG_OK (65536 | 262144 | 33554432)
 #define EILEV_TRACE_M16 true
 #else
-#define EILEV_LEAN_DBG_OK 0
 #define EILEV_TRACE_M16 false
 #endif
 static inline bool pp4_all_lean(const GemmArgs &g) {
     // (column scaling — the q part of a fused q|k|v projection — only on plain bias-only launches, in whole 16-column blocks)
     const bool scale_ok = g.scale_cols == 0 || (g.scale_cols % 16 == 0 && g.epi == 0 && !g.resid && !g.ln_rows && !g.stat_out);
-    return g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && scale_ok && !g.wscale && !g.ascale && !(g.dbg & ~EILEV_LEAN_DBG_OK) && (!g.trace || EILEV_TRACE_M16);
+    return g.N % 128 == 0 && !g.out_f32 && g.patch_group == 0 && scale_ok && !g.wscale && !g.ascale && !g.dbg && (!g.trace || EILEV_TRACE_M16);
 }
 // the launch can write the head-major q|k|v layout (GemmArgs::hm_tok)
 static inline bool hm_takes(const GemmArgs &g) {

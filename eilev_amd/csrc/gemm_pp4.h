@@ -66,53 +66,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, 0x7fffffff, 0x00020000);
     unsigned po[PC];  // per-lane byte offsets of this wave's pieces (chunk-swizzled source): into A for waves 0-3, into W for waves 4-7
     const int pw = late ? wid - NW / 2 : wid;  // which 64-row slab of its operand the wave stages
-    // Scheduling units (round 6).  The static stride deals UNITS, not tiles: a unit is one whole tile, or — when the last column tile of this
-    // instance is a half tile (N = 1408 = 5.5 x 256: ViT fc2 / proj) — TWO half tiles of neighbouring tile rows, run back to back by the same
-    // workgroup.  Dealt as tiles, the half tiles of a 4-row x 6-column group sit at fixed positions of a period of 24 while the stride advances
-    // by 32 = 8 mod 24 per round: half of the workgroups of an XCD never met a half tile, the other half met one every third round and
-    // finished 15 % early — the launch took exactly as long as N = 1536 (profiles/r04_fc2_halftile_diag.log: 4283 us at N = 1408, 4263 us at
-    // N = 1536).  With a pair as one unit every unit costs about one tile and the stride balances (probe flag 65536: the old deal, for the A/B).
-    const bool ht_col = M16K != 1 && tiles_n >= 2 && g.N - (tiles_n - 1) * BN <= 128 && !(g.dbg & (524288 | 256 | 12582912));  // the last column tile is a half tile
-    const bool pair_ht = ht_col && !(g.dbg & 65536) && ((g.dbg & 262144) || ntiles < 8 * (int)gridDim.x);
-    const int gm_rows = tiles_n <= 8 ? 4 : 8;  // (tile_coords' group height for this shape)
-    // probe (flag 33554432): tiles dealt singly, but the workgroups of an XCD rotate through the positions of a round (slot + rho * round), rho
-    // chosen so that every workgroup meets the half-tile positions equally often: the same tiles in flight, the half tiles shared out
-    const int xs = (int)gridDim.x >> 3;  // workgroups per XCD
-    int rot_step = 0;
-    if (ht_col && !pair_ht && (g.dbg & 33554432) && (gridDim.x & 7) == 0 && xs > 1) {
-        const int gw = gm_rows * tiles_n;
-        auto gcd = [](int a, int b) { while (b) { const int c = a % b; a = b; b = c; } return a; };
-        for (rot_step = 1; rot_step < xs && gcd((xs + rot_step) % gw, gw) != 1; ++rot_step) {}
-    }
-    auto unit_at = [&](int rnd) -> int {  // the unit this workgroup runs in round rnd of the static stride
-        if (!rot_step) return (int)blockIdx.x + rnd * (int)gridDim.x;
-        return ((int)blockIdx.x & 7) + 8 * ((((int)blockIdx.x >> 3) + rot_step * rnd) % xs + rnd * xs);
-    };
-    const int uw = gm_rows * (tiles_n - 1) + gm_rows / 2;  // units of a whole group
-    const int nunits = !pair_ht ? ntiles : (tiles_m / gm_rows) * uw + (tiles_m % gm_rows) * (tiles_n - 1) + (tiles_m % gm_rows + 1) / 2;
-    // unit u, part sub (0 / 1) -> tile coordinates; returns the number of parts of the unit
-    auto unit_tile = [&](int u, int sub, int &tm_i, int &tn_i) -> int {
-        if (!pair_ht) {
-            tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, u);
-            return 1;
-        }
-        const int xcd = u & 7, q = nunits >> 3, r = nunits & 7;  // XCD-aware: block b runs on XCD b % 8 and walks a contiguous range of the order
-        const int o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (u >> 3);
-        const int group = o / uw, first = group * gm_rows, gsz = min(tiles_m - first, gm_rows), in = o - group * uw, nfull = gsz * (tiles_n - 1);
-        if (in < nfull) {
-            tm_i = first + in % gsz;
-            tn_i = in / gsz;
-            return 1;
-        }
-        const int p = in - nfull;
-        tm_i = first + 2 * p + sub;
-        tn_i = tiles_n - 1;
-        return 2 * p + 1 < gsz ? 2 : 1;
-    };
-    int unit_parts = 1;  // parts of the unit set_tile was last called for
-    auto set_tile = [&](int u, int sub, int &m0, int &n0) {
+    auto set_tile = [&](int t, int &m0, int &n0) {
         int tm_i, tn_i;
-        unit_parts = unit_tile(u, sub, tm_i, tn_i);
+        tile_coords(g, tiles_m, tiles_n, tm_i, tn_i, t);
         m0 = tm_i * BM;
         n0 = tn_i * BN;
         {
@@ -563,9 +519,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
-    int t = blockIdx.x, tsub = 0, rnd = 0, m0, n0;  // (unit, part) of round rnd
-    if (t >= nunits) return;
-    set_tile(t, 0, m0, n0);
+    int t = blockIdx.x, m0, n0;
+    if (t >= ntiles) return;
+    set_tile(t, m0, n0);
     // half tile: only W rows 0..127 of the tile exist; the late waves 6 and 7 (rows 128..255) have nothing to stage
     auto w_piece_mine = [&](int n0_) { return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2 + 2; };
     stage_step(0, w_piece_mine(n0));
@@ -625,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             g.trace[(((size_t)blockIdx.x * 2 + (late ? 1 : 0)) * g.trace_tiles + trace_i) * 8 + k] =
                 core ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
     };
-    for (;;) {
+    for (; t < ntiles; t += gridDim.x) {
         stamp(0);
         stamp(5, true);
         typedef __attribute__((ext_vector_type(4))) short s16x4_t;  // operand type of the K = 8 bf16 MFMA
@@ -803,14 +759,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         }
         // every wave has finished reading both step buffers.  Lean tiles: both first K-steps of the next tile are staged now and
         // land under the epilogue; otherwise only step 0 (the general epilogue stages through buffer 1).
-        const int cm0 = m0, cn0 = n0;
-        const bool same_unit = tsub + 1 < unit_parts;  // the second half tile of a pair
-        const int tn = same_unit ? t : unit_at(rnd + 1), tnsub = same_unit ? tsub + 1 : 0;
+        const int cm0 = m0, cn0 = n0, tn = t + gridDim.x;
         const bool lean = lean_cur;
         pre1 = false;
         lean_cur = false;
-        if (tn < nunits) {
-            set_tile(tn, tnsub, m0, n0);
+        if (tn < ntiles) {
+            set_tile(tn, m0, n0);
             stage_step(0, w_piece_mine(n0));
             pre1 = lean && ns > 1;
             if (pre1) stage_step(1, w_piece_mine(n0));
@@ -841,10 +795,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
         stamp(4);
         stamp(6, true);
         ++trace_i;
-        if (tn >= nunits) break;
-        if (!same_unit) ++rnd;
-        t = tn;
-        tsub = tnsub;
     }
 #undef PP_BARRIER
 }

@@ -93,6 +93,12 @@ print(f"  workgroup finish times (us): min {last_end.min():.0f}  p25 {np.percent
       f"p75 {np.percentile(last_end, 75):.0f}  max {last_end.max():.0f}   -> mean idle at the end {100 * (1 - last_end.mean() / last_end.max()):.1f} % of the launch")
 busy = np.array([(end[wg][valid[wg]] - start[wg][valid[wg]]).sum() for wg in range(WG)])
 print(f"  tiles per workgroup {ntile_wg.min()}..{ntile_wg.max()}; busy time per workgroup (us): min {busy.min():.0f} mean {busy.mean():.0f} max {busy.max():.0f}")
+# per XCD (block b runs on XCD b % 8): are some XCDs / CUs systematically slower?
+for x in range(8):
+    idx = [wg for wg in range(WG) if (wg & 7) == x]
+    fe = last_end[idx]
+    mt = np.array([np.mean([end[wg, i] - start[wg, i] for i in range(1, TILES) if valid[wg, i] and (wg + i * WG) < ntiles and not (half_col and coords(wg + i * WG)[1] == tiles_n - 1)]) for wg in idx])
+    print(f"  XCD {x}: finish min {fe.min():.0f} mean {fe.mean():.0f} max {fe.max():.0f} | mean WHOLE-tile time per workgroup: min {mt.min():.1f} mean {mt.mean():.1f} max {mt.max():.1f} us")
 print("  round: spread of tile START times inside an XCD (max - min over its 32 workgroups; mean over the 8 XCDs), and of the END times")
 for i in sorted(rounds):
     by = {}
