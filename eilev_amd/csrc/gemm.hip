@@ -63,7 +63,14 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
             EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr16 = true;
         }
-        if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, false, 0, 2>), dim3(grid), dim3(512), smem, s, g);
+        if (g.epi == 0 && g.K >= 8192) {  // long K: the A operand three K-steps deep (gemm_pp4.h A3)
+            static bool attr_a3 = false;
+            if (!attr_a3) {
+                EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_a3 = true;
+            }
+            hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 0, 2, true>), dim3(grid), dim3(512), smem, s, g);
+        } else if (g.epi == 2) hipLaunchKernelGGL((gemm_pp4_kernel<2, false, 0, 2>), dim3(grid), dim3(512), smem, s, g);
         else hipLaunchKernelGGL((gemm_pp4_kernel<0, false, 0, 2>), dim3(grid), dim3(512), smem, s, g);
         EILEV_LAUNCH_CHECK();
         return EILEV_OK;

@@ -29,7 +29,7 @@ namespace {
 // Launches whose every tile can take the lean epilogue (the launcher checks: bf16 output, N % 128 == 0, ...): there is no general epilogue
 // in this layout.  A last column tile with only 128 valid columns (N = 1408, 4224): see M16K below (profiles/r05_m16_ab_all_shapes.log,
 // r05_m16_ht_ab.log).
-template <int EPI, bool F8 = false, int LN = 0, int M16K = 0>
+template <int EPI, bool F8 = false, int LN = 0, int M16K = 0, bool A3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // M16K: 0 = 32 x 32 x 16 MFMAs; 1 = 16 x 16 x 32, a half-valid last column tile runs as a WHOLE tile (its W rows past N are not staged:
     // stale, finite LDS bytes; the waves that own columns >= N skip the epilogue) — no half-tile code in the instance: the folded-LayerNorm
@@ -41,8 +41,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
     constexpr int STEP = (BM + BN) * 128;
     constexpr int PC = 8;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) per wave and K-step
+    // A3 (round 6; an own instance: plain 16 x 16 launches with K >= 8192 — the OPT fc2 of a prefill): the A operand in a ring of THREE K-steps,
+    // W in two: A of step s + 2 is requested in the read phase of (s, half 0), two K-steps of flight instead of one.  LDS: A slots [0, 96 KiB) at
+    // 32 KiB each, W slots [96, 160 KiB); the 32 KiB of epilogue staging OVERLAY A slot 2 — free while an epilogue runs (the next tile's steps
+    // 0 and 1 are what is in flight then) and requested again only behind the barrier at the top of the next tile, which every wave reaches
+    // after its epilogue.  Same-box A/B, bit-identical (profiles/r06_a3_ring_ab.log): OPT fc2 (M = 30 720, N = 2560, K = 10 240) +10 %; the ViT
+    // shapes (K = 1408 / 6144) -0.3 ... -17 % and the other OPT linears -3 %, which is why it is not the default form.
+    static_assert(!A3 || M16, "A3: lean epilogues only");
+    constexpr int STG0 = A3 ? 2 * BM * 128 : 2 * STEP;  // first byte of the epilogue staging
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto a_slot = [&](int st) { return smem + (A3 ? (st % 3) * (BM * 128) : (st & 1) * STEP); };
+    auto w_slot = [&](int st) { return smem + (A3 ? 3 * (BM * 128) + (st & 1) * (BN * 128) : (st & 1) * STEP + BM * 128); };
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     };
     // part: 0 all 8 pieces, 1 pieces 0..3, 2 pieces 4..7 (EILEV_PP4_SPLIT: a wave's pieces of a K-step are issued in two read phases)
     auto stage_step = [&](int st, bool mine = true, int part = 0) {  // mine == false: a late wave whose W rows do not exist in a half tile
-        char *sd = smem + (st & 1) * STEP + (late ? BM * 128 : 0) + (pw * PC) * 1024;
+        char *sd = (late ? w_slot(st) : a_slot(st)) + (pw * PC) * 1024;
         if (!mine) return;
 #ifndef EILEV_PP4_PROBE_SKIP
 #define EILEV_PP4_PROBE_SKIP 0  /* timing probe only (WRONG results): 1 / 2 the early / late group issues half of its pieces, 4 / 8 none */
@@ -120,8 +130,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
     f32x4_t acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
     auto read_half = [&](int st, int h) {
-        const char *sa = smem + (st & 1) * STEP + (wm * WM) * 128;
-        const char *sb = smem + (st & 1) * STEP + BM * 128 + (wn * WN) * 128;
+        const char *sa = a_slot(st) + (wm * WM) * 128;
+        const char *sb = w_slot(st) + (wn * WN) * 128;
         if constexpr (M16) {  // one k-slice of 32 per half step: chunk h * 4 + g4 of rows 16 i + l15 (af / bfr reused as flat arrays of 8 / 4)
             const int kc = h * 4 + g4;
 #pragma unroll
@@ -189,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // wave, same ping-pong schedule); waves 4..7 own W rows 128..255 of the tile and skip their W pieces.
     const int hm = wm * 2 + (wn >> 1), hn = wn & 1;
     auto read_half_ht = [&](int st, int h) {
-        const char *sa = smem + (st & 1) * STEP + (hm * 64) * 128;
-        const char *sb = smem + (st & 1) * STEP + BM * 128 + (hn * 64) * 128;
+        const char *sa = a_slot(st) + (hm * 64) * 128;
+        const char *sb = w_slot(st) + (hn * 64) * 128;
         if constexpr (M16) {  // 64 x 64 per wave: 4 + 4 fragments of the one 32-wide k-slice
             const int kc = h * 4 + g4;
 #pragma unroll
@@ -256,10 +266,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // unit's 8 residual cells fetched from the staging rows in one batch, the next unit's rows in flight), and the GELU is the
     // degree-8 form of common.h.  (Folding the bias into the first MFMAs' C operand — no accumulator initialisation, no bias
     // arithmetic here — was built and makes hipcc spill 200-600 VGPRs in this 256-register kernel: not adopted.)
-    char *const stg = smem + 2 * STEP + wid * 4096;
-    const unsigned stg_sw = (unsigned)(2 * STEP + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
+    char *const stg = smem + STG0 + wid * 4096;
+    const unsigned stg_sw = (unsigned)(STG0 + wid * 4096 + l31 * 128 + hi * 8) ^ (unsigned)((l31 & 7) << 4);
     // 16 x 16 layout: the lane's 4 values of block (ib, j) of a unit = row 16 ib + l15, columns 16 j + 4 g4 ..: chunk 2 j + (g4 >> 1), bytes 8 (g4 & 1)
-    const unsigned stg_sw16 = (unsigned)(2 * STEP + wid * 4096 + l15 * 128 + (g4 & 1) * 8) ^ (unsigned)((((g4 >> 1) ^ (l15 & 7)) << 4));
+    const unsigned stg_sw16 = (unsigned)(STG0 + wid * 4096 + l15 * 128 + (g4 & 1) * 8) ^ (unsigned)((((g4 >> 1) ^ (l15 & 7)) << 4));
     const int srow = lane >> 3, schunk = lane & 7;
     auto is_lean = [&](int n0_) {
         return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) && n0_ + BN <= g.N && !g.out_f32 && g.patch_group == 0 && g.scale_cols == 0 && !g.wscale && !g.ascale &&
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     // half tile: only W rows 0..127 of the tile exist; the late waves 6 and 7 (rows 128..255) have nothing to stage
     auto w_piece_mine = [&](int n0_) { return !(n0_ + 128 >= g.N && !(g.dbg & 524288)) || wid < NW / 2 + 2; };
     stage_step(0, w_piece_mine(n0));
-    bool pre1 = ns > 1 && !(g.dbg & 16777216);  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
+    bool pre1 = ns > 1 && (A3 || !(g.dbg & 16777216));  // step 1 of the coming tile is already staged (prologue / previous tile's tail)
     if (pre1) stage_step(1, w_piece_mine(n0));
     bool lean_cur = M16 || is_lean(n0);  // this tile runs the lean epilogue (M16: every tile does)
     // folded LayerNorm (LN == 1): C = rstd * (A . W^T - mean * csum) + bias.  The rank-1 term -mean[m] * csum[n] is one more K-slice on
@@ -686,7 +696,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
             constexpr bool SPLIT_OK = !HT && (EILEV_PP4_SPLIT_QKV || !(LN == 1 && EPI == 0));
             constexpr bool SPLIT_E = (EILEV_PP4_SPLIT & 1) && SPLIT_OK, SPLIT_L = (EILEV_PP4_SPLIT & 2) && SPLIT_OK;
             if (!late) {
-                if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, SPLIT_E ? 1 : 0);
+                if constexpr (A3) {  // steps 0 and 1 came with the tile's head; A of step st + 2 goes into the slot both groups left at the last barrier
+                    if (st + 2 < ns) stage_step(st + 2, w_mine, SPLIT_E ? 1 : 0);
+                } else if (st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, SPLIT_E ? 1 : 0);
             } else if (FIRST && !pre1 && ns > 1) stage_step(1, w_mine);
             else if (SPLIT_L && !FIRST && st + 1 < ns) stage_step(st + 1, w_mine, 2);  // its first half: the end of this wave's read phase of (st - 1, half 1)
 #else
@@ -710,6 +722,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 // full tile: the W rows this wave stages are read by itself (done: lgkmcnt(0) above) and by its early twin (done one
                 // barrier ago) only.  Half tile: the reads are re-split 4 x 2, two late waves share W rows -> issue after the barrier.
                 if constexpr (!HT) if (st + 2 < ns) stage_step(st + 2, w_mine, SPLIT_L ? 1 : 0);
+            } else if (A3) {
+                if (SPLIT_E && st + 2 < ns) stage_step(st + 2, w_mine, 2);
             } else if (SPLIT_E && st + 1 < ns && !(FIRST && pre1)) stage_step(st + 1, w_mine, 2);
             ITR(5);
             PP_BARRIER();
@@ -719,7 +733,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
                 mma_half_ht();
             } else mma_half();
             __builtin_amdgcn_sched_barrier(0);
-            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (A3) {  // step st + 1 has landed; the 8 pieces of step st + 2 (this wave's most recent loads) stay in flight
+                if (!late) {
+                    if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ITR(7);
             PP_BARRIER();
 #else
