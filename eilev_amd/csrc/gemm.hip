@@ -63,7 +63,10 @@ int launch_pp4(const GemmArgs &g, hipStream_t s) {
             EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<2, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr16 = true;
         }
-        if (g.epi == 0 && g.K >= 8192) {  // long K: the A operand three K-steps deep (gemm_pp4.h A3)
+#ifndef EILEV_A3_MIN_K
+#define EILEV_A3_MIN_K 5120  /* profiles/r06_a3_min_k.log: flan-t5-xl wo (N = 2048, K = 5120) +10 %, K = 4096 / 2560 / 2048 shapes -3 ... +1 % */
+#endif
+        if (g.epi == 0 && g.K >= EILEV_A3_MIN_K) {  // long K: the A operand three K-steps deep (gemm_pp4.h A3)
             static bool attr_a3 = false;
             if (!attr_a3) {
                 EILEV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp4_kernel<0, false, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));

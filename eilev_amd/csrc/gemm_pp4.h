@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(const GemmArgs g) {
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
     constexpr int STEP = (BM + BN) * 128;
     constexpr int PC = 8;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) per wave and K-step
-    // A3 (round 6; an own instance: plain 16 x 16 launches with K >= 8192 — the OPT fc2 of a prefill): the A operand in a ring of THREE K-steps,
+    // A3 (round 6; an own instance: plain 16 x 16 launches with K >= 5120 — the OPT fc2 of a prefill, the flan-t5 wo): the A operand in a ring of THREE K-steps,
     // W in two: A of step s + 2 is requested in the read phase of (s, half 0), two K-steps of flight instead of one.  LDS: A slots [0, 96 KiB) at
     // 32 KiB each, W slots [96, 160 KiB); the 32 KiB of epilogue staging OVERLAY A slot 2 — free while an epilogue runs (the next tile's steps
     // 0 and 1 are what is in flight then) and requested again only behind the barrier at the top of the next tile, which every wave reaches
