@@ -140,7 +140,15 @@ class ClipExchange:
         recv = self.staging[rfirst: rfirst + sum(rrows)]
         ctx = torch.cuda.stream(self.side) if self.side is not None else _null()
         with ctx:
-            dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rrows, input_split_sizes=srows, group=self.group)
+            if self.gpu and dist.get_backend(self.group) == "gloo":
+                # device tensors over a gloo group (bench.py --share-gpu: N ranks rehearsing on ONE GPU): staged through the host explicitly —
+                # `.cpu()` waits for the side stream (which waited for the producer), the collective runs on host tensors, the copy back is
+                # ordered on the side stream.  (Round 6: gloo's own device staging gave one corrupted clip in one of ~7 eight-rank runs.)
+                recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_to_all_single(recv_h, send.contiguous().cpu(), output_split_sizes=rrows, input_split_sizes=srows, group=self.group)
+                recv.copy_(recv_h.pin_memory() if recv_h.numel() else recv_h, non_blocking=False)
+            else:
+                dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rrows, input_split_sizes=srows, group=self.group)
         if t_on:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(self.side)
