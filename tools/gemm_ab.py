@@ -24,7 +24,8 @@ SHAPES = {"fc1": (6144, 1408, 1, False), "fc1_noact": (6144, 1408, 0, False), "f
           # what the bench's folded-LayerNorm ViT blocks launch (eilev_linear_lnfold / eilev_linear_stats)
           "fc1_ln": (6144, 1408, 1, False), "qkv_ln": (4224, 1408, 0, False), "fc2_st": (1408, 6144, 0, True), "proj_st": (1408, 1408, 0, True)}
 # the OPT-2.7B prefill linears of a bench step (32 samples x 960 tokens): AB_SHAPES=opt_qkv,... (rows from AB_MOPT, default 30720)
-SHAPES.update({"opt_t5_wo": (2048, 5120, 0, True), "opt_t5_o": (2048, 2048, 0, True), "opt_67_fc2": (4096, 16384, 0, True), "opt_67_out": (4096, 4096, 0, True),
+SHAPES.update({"opt_x1280": (1280, 6144, 0, True), "opt_x1408": (1408, 6144, 0, True), "opt_x2560": (2560, 6144, 0, True), "opt_x2560k10": (2560, 10240, 0, True),
+               "opt_t5_wo": (2048, 5120, 0, True), "opt_t5_o": (2048, 2048, 0, True), "opt_67_fc2": (4096, 16384, 0, True), "opt_67_out": (4096, 4096, 0, True),
                "opt_67_qkv": (12288, 4096, 0, False),  # (round 6: where does the three-deep A ring start to pay?  flan-t5-xl wo / o, OPT-6.7B linears)
                "opt_qkv": (7680, 2560, 0, False), "opt_fc1": (10240, 2560, 2, False), "opt_fc2": (2560, 10240, 0, True), "opt_out": (2560, 2560, 0, True)})
 only = os.environ.get("AB_SHAPES")
